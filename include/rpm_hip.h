@@ -1,0 +1,211 @@
+/*
+ * rpm_hip.h — C ABI of the MI355X-native Radau-pseudospectral NLP-callback engine.
+ *
+ * This is the drop-in boundary for lpopc's per-iteration hot path.  Every entry
+ * point replaces one interface of the reference (paths relative to
+ * /root/reference/Lpopc/src, cited per function below).  Plain C types only:
+ * `int` is Ipopt::Index, `double` is Ipopt::Number (Core/LpopcIpopt.h:33-82).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero RPM_E_* code on failure;
+ *     no C++ exception ever crosses this boundary (the reference throws
+ *     LP_THROW_EXCEPTION, Common/LpException.hpp:78).  The message of the last
+ *     failure is available from rpm_last_error().
+ *   - the set-up half (rpm_create, rpm_get_nlp_info, rpm_get_bounds_info,
+ *     rpm_get_starting_point, structure pass of rpm_eval_jac_g / rpm_eval_h,
+ *     rpm_get_phase_tables, rpm_shard_*) is host-only and needs no GPU.
+ *   - the evaluation half runs hand-written HIP kernels on gfx950.  There is NO
+ *     CPU fallback: without a usable device these calls fail with RPM_E_DEVICE.
+ *   - an engine may hold `n_instances` structurally identical OCP instances
+ *     (the batched MPC sweep).  All vectors are then instance-major:
+ *     x[inst*n + i], g[inst*m + i], values[inst*nnz + k].  n/m/nnz reported by
+ *     rpm_get_nlp_info are always per instance.
+ */
+#ifndef RPM_HIP_H_
+#define RPM_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPM_ABI_VERSION 1
+
+/* ---- error codes -------------------------------------------------------- */
+enum {
+  RPM_OK = 0,
+  RPM_E_INVALID = 1,  /* bad argument / inconsistent description (LpSizeChecker, LpBoundsChecker,
+                         LpGuessChecker, LpMeshRefiner exceptions in the reference) */
+  RPM_E_UNSUPPORTED = 2,
+  RPM_E_DEVICE = 3,   /* HIP error or no device */
+  RPM_E_NONFINITE = 4 /* a result contains NaN/Inf (the reference always returns true) */
+};
+
+/* ---- problem functor ids ------------------------------------------------- */
+/* The reference's user callbacks are host C++ virtuals on Armadillo matrices
+ * (Core/LpFunctionWrapper.h:50-69); they cannot run on a GPU.  Here the five
+ * callbacks (Mayer, Lagrange, Dae, Event, Link) are pointwise device functors
+ * compiled into the library and selected by id. */
+enum {
+  RPM_PROBLEM_LAUNCH = 1,          /* Delta-III ascent, example/launch/Launch.cpp:620-765 */
+  RPM_PROBLEM_HYPERSENSITIVE = 2,  /* example/hypersensitive/HyperSensitive.cpp:74-167 */
+  RPM_PROBLEM_BRYSON_DENHAM = 3,   /* example/bryson-denham/BrysonDenham.cpp:100-167 */
+  RPM_PROBLEM_BRACHISTOCHRONE = 4, /* authored here (BASELINE config 1) */
+  RPM_PROBLEM_MIN_TIME_CLIMB = 5,  /* authored here (BASELINE config 2) */
+  RPM_PROBLEM_QUADROTOR = 6        /* authored here (BASELINE config 5) */
+};
+
+/* first-derive option, Core/LpOptDerive.hpp:29-32 */
+enum { RPM_DERIVE_FINITE_DIFFERENCE = 0, RPM_DERIVE_ANALYTIC = 1 };
+/* hessian-approximation option, Core/LpNLPWrapper.hpp:71-72 */
+enum { RPM_HESSIAN_LIMITED_MEMORY = 0, RPM_HESSIAN_EXACT = 1 };
+/* how work is split when shard_world > 1 */
+enum { RPM_SHARD_NONE = 0, RPM_SHARD_INTERVALS = 1 };
+
+/* ---- problem description (what Phase/Linkage/OptimalProblem setters collect,
+ *      Core/LpOptimalProblem.hpp:30-326) ------------------------------------- */
+typedef struct rpm_phase_desc {
+  int nx, nu, nq, nc, ne;          /* Phase(idx,nx,nu,nq,nc,ne)  :33-37 */
+  int n_intervals;                 /* SetMeshPoints/SetNodesPerInterval :174-187 */
+  const double* mesh_points;       /* n_intervals+1, must run -1 .. +1 (Core/LpMeshRefiner.cpp:40) */
+  const int* nodes_per_interval;   /* n_intervals, each >= 2 */
+  double t0_min, tf_min;           /* SetTimeMin(t0,tf) :49 */
+  double t0_max, tf_max;           /* SetTimeMax(t0,tf) :57 */
+  const double* state_min;         /* nx*3: {state0,state,statef} per state, SetStateMin :65 */
+  const double* state_max;         /* nx*3 */
+  const double* control_min;       /* nu */
+  const double* control_max;
+  const double* parameter_min;     /* nq */
+  const double* parameter_max;
+  const double* path_min;          /* nc */
+  const double* path_max;
+  const double* event_min;         /* ne */
+  const double* event_max;
+  int has_duration;                /* SetDuration :126 */
+  double duration_min, duration_max;
+  int n_guess;                     /* number of guess knots (>=2), SetTimeGuess :132 */
+  const double* time_guess;        /* n_guess */
+  const double* state_guess;       /* nx*n_guess, knot-fastest per state (SetStateGuess(i,v)) */
+  const double* control_guess;     /* nu*n_guess */
+  const double* parameter_guess;   /* nq */
+} rpm_phase_desc;
+
+typedef struct rpm_link_desc {
+  int left_phase, right_phase;     /* 1-based, Linkage(ipair,left,right) :245 */
+  int n_links;
+  const double* link_min;          /* n_links */
+  const double* link_max;
+} rpm_link_desc;
+
+typedef struct rpm_problem_desc {
+  int abi_version;                 /* RPM_ABI_VERSION */
+  int problem_id;                  /* RPM_PROBLEM_* */
+  int n_phases;
+  const rpm_phase_desc* phases;
+  int n_links;
+  const rpm_link_desc* links;
+  int n_consts;                    /* problem constants handed to the functor (the reference keeps
+                                      them in globals, e.g. CONSTANTS in example/launch/Launch.cpp:47-74) */
+  const double* consts;
+  double fd_tol;                   /* finite-difference-tol, default 1e-6 */
+  int first_derive;                /* RPM_DERIVE_* */
+  int hessian_approximation;       /* RPM_HESSIAN_* */
+  int n_instances;                 /* >=1; structurally identical OCPs evaluated per call */
+  int shard_mode;                  /* RPM_SHARD_* */
+  int shard_rank, shard_world;     /* this engine computes only the tiles it owns */
+} rpm_problem_desc;
+
+typedef struct rpm_engine rpm_engine;
+
+/* ---- lifecycle ------------------------------------------------------------
+ * rpm_create does what LpopcAlgorithm::GetSizes/GetBounds/GetGuess do once per mesh
+ * (Core/LpLpopcAlgorithm.cpp:143-148): size/bounds/guess checks, NLP layout
+ * (Core/LpBoundsChecker.cpp:13-348), collocation tables (Core/RPMGenerator.cpp:43-181),
+ * Jacobian structure (Core/LpNLPWrapper.cpp:1106-1578).  Host only. */
+int rpm_create(const rpm_problem_desc* desc, rpm_engine** out);
+void rpm_destroy(rpm_engine* e);
+/* message of the last failed call on this engine (or of the last failed rpm_create when e==NULL) */
+const char* rpm_last_error(const rpm_engine* e);
+/* bind the engine to HIP device `device_id`, allocate device tables/buffers, create its stream.
+ * Called implicitly (device 0) by the first evaluation if omitted. */
+int rpm_device_init(rpm_engine* e, int device_id);
+
+/* ---- Ipopt::TNLP surface (Core/LpopcIpopt.h:33-82, Core/LpopcIpopt.cpp) ------- */
+/* LpopcIpopt::get_nlp_info, LpopcIpopt.cpp:11-24.  index_style: 0 = C_STYLE. */
+int rpm_get_nlp_info(rpm_engine* e, int* n, int* m, int* nnz_jac_g, int* nnz_h_lag, int* index_style);
+/* LpopcIpopt::get_bounds_info, LpopcIpopt.cpp:26-82 */
+int rpm_get_bounds_info(rpm_engine* e, int n, double* x_l, double* x_u, int m, double* g_l, double* g_u);
+/* LpopcIpopt::get_starting_point, LpopcIpopt.cpp:84-104 (requires init_x=1, init_z=0, init_lambda=0) */
+int rpm_get_starting_point(rpm_engine* e, int n, int init_x, double* x, int init_z, double* z_L,
+                           double* z_U, int m, int init_lambda, double* lambda);
+/* LpopcIpopt::eval_f, LpopcIpopt.cpp:106-116 -> NLPWrapper::GetObjFun, LpNLPWrapper.cpp:863 */
+int rpm_eval_f(rpm_engine* e, int n, const double* x, int new_x, double* obj_value);
+/* LpopcIpopt::eval_grad_f, LpopcIpopt.cpp:118-133 -> GetObjGrad, LpNLPWrapper.cpp:940 */
+int rpm_eval_grad_f(rpm_engine* e, int n, const double* x, int new_x, double* grad_f);
+/* LpopcIpopt::eval_g, LpopcIpopt.cpp:135-150 -> GetAllCons, LpNLPWrapper.cpp:34 */
+int rpm_eval_g(rpm_engine* e, int n, const double* x, int new_x, int m, double* g);
+/* LpopcIpopt::eval_jac_g, LpopcIpopt.cpp:152-181: values==NULL -> structure pass (iRow/jCol,
+ * 0-based), else values pass -> GetConsJacbi, LpNLPWrapper.cpp:230 */
+int rpm_eval_jac_g(rpm_engine* e, int n, const double* x, int new_x, int m, int nele_jac, int* iRow,
+                   int* jCol, double* values);
+/* LpopcIpopt::eval_h, LpopcIpopt.cpp:183-218 -> LpHessianCalculator::GetHessian, LpHessian.cpp:878 */
+int rpm_eval_h(rpm_engine* e, int n, const double* x, int new_x, double obj_factor, int m,
+               const double* lambda, int new_lambda, int nele_hess, int* iRow, int* jCol,
+               double* values);
+/* LpopcIpopt::finalize_solution, LpopcIpopt.cpp:220-246: keeps x, lambda, obj for rpm_get_solution */
+int rpm_finalize_solution(rpm_engine* e, int status, int n, const double* x, const double* z_L,
+                          const double* z_U, int m, const double* g, const double* lambda,
+                          double obj_value);
+int rpm_get_solution(rpm_engine* e, int n, double* x, int m, double* lambda, double* obj_value);
+
+/* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
+ *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
+ *      engine's device; `stream` is a hipStream_t (NULL = the engine's own stream).
+ *      Calls are asynchronous on that stream. ------------------------------------ */
+int rpm_eval_g_dev(rpm_engine* e, const double* d_x, double* d_g, void* stream);
+int rpm_eval_jac_g_dev(rpm_engine* e, const double* d_x, double* d_values, void* stream);
+/* fused pair: one launch produces g and the Jacobian values of the same x */
+int rpm_eval_pair_dev(rpm_engine* e, const double* d_x, double* d_g, double* d_values, void* stream);
+int rpm_eval_f_dev(rpm_engine* e, const double* d_x, double* d_obj, void* stream);
+int rpm_eval_grad_f_dev(rpm_engine* e, const double* d_x, double* d_grad_f, void* stream);
+int rpm_eval_h_dev(rpm_engine* e, const double* d_x, double obj_factor, const double* d_lambda,
+                   double* d_values, void* stream);
+/* block until everything queued on the engine's stream has finished */
+int rpm_synchronize(rpm_engine* e);
+
+/* ---- engine options ------------------------------------------------------------
+ * key                values
+ * "fuse_pair"        1 (default): rpm_eval_g(new_x=1) runs the fused pair kernel and the following
+ *                    rpm_eval_jac_g(new_x=0) on the same x returns the cached values; 0: separate kernels
+ * "dx_mode"          0: scalar ascending-column D.X (bit-identical to the reference's COO loop,
+ *                    SparseMatrix/LpSparseMatrix.cpp:142-153); 1: v_mfma_f64_16x16x4 tiles
+ * "tile_nodes"       16 | 32 | 64: collocation nodes per workgroup (0 = choose from grid size)
+ */
+int rpm_set_option(rpm_engine* e, const char* key, int value);
+int rpm_get_option(rpm_engine* e, const char* key, int* value);
+
+/* ---- collocation tables of one phase (struct ps, Core/LpCalculateData.hpp:35-41; built like
+ *      RPMGenerator::initialize, Core/RPMGenerator.cpp:43-105).  Any output may be NULL.
+ *      D is returned as the reference's COO triplets in its own order. ---------------- */
+int rpm_get_phase_sizes(rpm_engine* e, int phase, int* n_nodes, int* d_nnz, int* doff_nnz);
+int rpm_get_phase_tables(rpm_engine* e, int phase, double* points, double* weights, int* d_rows,
+                         int* d_cols, double* d_vals, double* diag_vals, int* doff_rows,
+                         int* doff_cols, double* doff_vals);
+
+/* ---- interval sharding helpers (shard_mode = RPM_SHARD_INTERVALS) --------------------
+ * A rank's share of g / values is a list of contiguous runs.  Segment s of rank r is
+ * dst[off .. off+len) of the full vector and sits at packed offset `pos` of that rank's
+ * contiguous send buffer.  which: 0 = g, 1 = jacobian values.  Pass seg==NULL to query the
+ * count.  Host only. */
+typedef struct rpm_segment { int off, len, pos; } rpm_segment;
+int rpm_shard_segments(rpm_engine* e, int which, int rank, rpm_segment* seg, int* n_seg,
+                       int* packed_len);
+/* pack this rank's runs of a full-size device vector into a contiguous device buffer / scatter a
+ * gathered [world][max_packed_len] buffer back into TNLP order */
+int rpm_shard_pack_dev(rpm_engine* e, int which, const double* d_full, double* d_packed, void* stream);
+int rpm_shard_unpack_dev(rpm_engine* e, int which, const double* d_gathered, int stride,
+                         double* d_full, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPM_HIP_H_ */

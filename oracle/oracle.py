@@ -1,0 +1,160 @@
+"""ctypes front-end of the CPU ORACLE (oracle/liborpm.so) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED (see oracle/orpm.h): the reference ships no golden vectors and cannot be
+built in this image, so this restatement is pinned by source citation and by mathematical
+invariants only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborpm.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "rpm_hip.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborpm.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liborpm.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.orpm_create.restype = C.c_void_p
+        L.orpm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.orpm_destroy.argtypes = [C.c_void_p]
+        L.orpm_get_nlp_info.argtypes = [C.c_void_p, ip, ip, ip, ip]
+        L.orpm_get_bounds_info.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.orpm_get_starting_point.argtypes = [C.c_void_p, dp]
+        L.orpm_eval_f.restype = C.c_double
+        L.orpm_eval_f.argtypes = [C.c_void_p, dp]
+        L.orpm_eval_grad_f.argtypes = [C.c_void_p, dp, dp]
+        L.orpm_eval_g.argtypes = [C.c_void_p, dp, dp]
+        L.orpm_jac_structure.argtypes = [C.c_void_p, ip, ip]
+        L.orpm_eval_jac_g.argtypes = [C.c_void_p, dp, dp]
+        L.orpm_hess_structure.argtypes = [C.c_void_p, ip, ip]
+        L.orpm_eval_h.argtypes = [C.c_void_p, dp, C.c_double, dp, dp]
+        L.orpm_get_phase_sizes.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.orpm_get_phase_tables.argtypes = [C.c_void_p, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
+        L.orpm_lgr_points.argtypes = [C.c_int, dp, dp]
+        L.orpm_colloc_d.argtypes = [C.c_int, dp, dp]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def lgr_points(n):
+    x, w = np.zeros(n), np.zeros(n)
+    lib().orpm_lgr_points(n, _dp(x), _dp(w))
+    return x, w
+
+
+def colloc_d(points):
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    M = len(pts)
+    D = np.zeros((M - 1) * M)
+    lib().orpm_colloc_d(M, _dp(pts), _dp(D))
+    return D.reshape((M - 1, M), order="F")
+
+
+class Oracle:
+    """CPU restatement of lpopc's NLPWrapper + LpopcIpopt for one OptimalProblem."""
+
+    def __init__(self, problem, options=None):
+        from lpopc_amd._abi import lower  # description structs only (the wire format)
+
+        self._desc, self._keep = lower(problem, options)
+        err = C.create_string_buffer(512)
+        self._h = lib().orpm_create(C.byref(self._desc), err, 512)
+        if not self._h:
+            raise ValueError("oracle: " + err.value.decode())
+        n, m, nj, nh = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().orpm_get_nlp_info(self._h, C.byref(n), C.byref(m), C.byref(nj), C.byref(nh))
+        self.n, self.m, self.nnz_jac, self.nnz_h = n.value, m.value, nj.value, nh.value
+        self.n_phases = problem.GetPhaseNum()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orpm_destroy(self._h)
+            self._h = None
+
+    def bounds(self):
+        xl, xu, gl, gu = np.zeros(self.n), np.zeros(self.n), np.zeros(self.m), np.zeros(self.m)
+        lib().orpm_get_bounds_info(self._h, _dp(xl), _dp(xu), _dp(gl), _dp(gu))
+        return xl, xu, gl, gu
+
+    def starting_point(self):
+        x = np.zeros(self.n)
+        lib().orpm_get_starting_point(self._h, _dp(x))
+        return x
+
+    def eval_f(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        return lib().orpm_eval_f(self._h, _dp(x))
+
+    def eval_grad_f(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.zeros(self.n)
+        lib().orpm_eval_grad_f(self._h, _dp(x), _dp(g))
+        return g
+
+    def eval_g(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.zeros(self.m)
+        lib().orpm_eval_g(self._h, _dp(x), _dp(g))
+        return g
+
+    def jac_structure(self):
+        i, j = np.zeros(self.nnz_jac, dtype=np.int32), np.zeros(self.nnz_jac, dtype=np.int32)
+        lib().orpm_jac_structure(self._h, _ip(i), _ip(j))
+        return i, j
+
+    def eval_jac_g(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        v = np.zeros(self.nnz_jac)
+        lib().orpm_eval_jac_g(self._h, _dp(x), _dp(v))
+        return v
+
+    def hess_structure(self):
+        i, j = np.zeros(self.nnz_h, dtype=np.int32), np.zeros(self.nnz_h, dtype=np.int32)
+        lib().orpm_hess_structure(self._h, _ip(i), _ip(j))
+        return i, j
+
+    def eval_h(self, x, obj_factor, lam):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        v = np.zeros(self.nnz_h)
+        lib().orpm_eval_h(self._h, _dp(x), float(obj_factor), _dp(lam), _dp(v))
+        return v
+
+    def phase_tables(self, phase):
+        N, dn, on = C.c_int(), C.c_int(), C.c_int()
+        lib().orpm_get_phase_sizes(self._h, phase, C.byref(N), C.byref(dn), C.byref(on))
+        N, dn, on = N.value, dn.value, on.value
+        t = dict(points=np.zeros(N), weights=np.zeros(N), d_rows=np.zeros(dn, dtype=np.int32),
+                 d_cols=np.zeros(dn, dtype=np.int32), d_vals=np.zeros(dn), diag_vals=np.zeros(N),
+                 doff_rows=np.zeros(on, dtype=np.int32), doff_cols=np.zeros(on, dtype=np.int32),
+                 doff_vals=np.zeros(on))
+        lib().orpm_get_phase_tables(self._h, phase, _dp(t["points"]), _dp(t["weights"]), _ip(t["d_rows"]),
+                                    _ip(t["d_cols"]), _dp(t["d_vals"]), _dp(t["diag_vals"]),
+                                    _ip(t["doff_rows"]), _ip(t["doff_cols"]), _dp(t["doff_vals"]))
+        return t
