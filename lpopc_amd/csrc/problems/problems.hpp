@@ -1,0 +1,319 @@
+// problems.hpp — pointwise device functors that stand where the reference's host-side
+// FunctionWrapper subclasses stand (Core/LpFunctionWrapper.h:50-69).  One struct per problem:
+//
+//   dims     NX, NU, NC, NE_MAX, NLINK_MAX, NCONST, HAS_ANALYTIC
+//   dae      f(t,x,u) and path c(t,x,u) at ONE collocation node  (FunctionWrapper::DaeFunction)
+//   event    FunctionWrapper::EventFunction      link   FunctionWrapper::LinkFunction
+//   mayer    FunctionWrapper::MayerCost          lagrange  FunctionWrapper::LagrangeCost (one node)
+//   dae_jac_col / lagrange_grad_col / ...  one column of the user's analytic derivative
+//                                          (FunctionWrapper::Deriv*, used with first-derive=analytic)
+//
+// `ph` is the 1-based phase number the reference passes as phase_num_; `c` are the problem
+// constants (the reference keeps them in globals).  Operation order follows the reference's
+// vectorised expressions so that results agree with lpopc's CPU path to rounding of libm.
+// Paths below are relative to /root/reference/Lpopc.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../../include/rpm_hip.h"
+
+namespace rpm {
+
+#define RPM_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// Delta-III launch vehicle ascent — example/launch/Launch.cpp:636-765
+// consts: [0..8] omega_matrix (column-major), 9 mu, 10 cd, 11 sa, 12 rho0, 13 H, 14 Re, 15 g0,
+//         16 thrust_srb, 17 thrust_first, 18 thrust_second, 19 ISP_srb, 20 ISP_first, 21 ISP_second
+struct LaunchProblem {
+  static constexpr int ID = RPM_PROBLEM_LAUNCH;
+  static constexpr int NX = 7, NU = 3, NC = 1, NE_MAX = 5, NLINK_MAX = 7, NCONST = 22;
+  static constexpr bool HAS_ANALYTIC = false;
+
+  RPM_DEV static void dae(int ph, double t, const double* x, const double* u, const double* c,
+                          double* f, double* p) {
+    (void)t;
+    const double r0 = x[0], r1 = x[1], r2 = x[2], m = x[6];
+    const double rad = sqrt((r0 * r0 + r1 * r1) + r2 * r2);            // :670
+    // omegacrossr = r * trans(omega_matrix), :672 (generic 3x3 product, zeros included)
+    double vrel[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      double ocr = 0.0;
+      ocr += r0 * c[cc + 0];
+      ocr += r1 * c[cc + 3];
+      ocr += r2 * c[cc + 6];
+      vrel[cc] = x[3 + cc] - ocr;
+    }
+    const double speedrel = sqrt((vrel[0] * vrel[0] + vrel[1] * vrel[1]) + vrel[2] * vrel[2]);
+    const double altitude = rad - c[14];
+    const double rho = exp(-altitude / c[13]) * c[12];                 // :676-677
+    const double bc = rho / (m * 2) * (c[11] * c[10]);                 // :678
+    const double bcspeed = bc * speedrel;
+    const double mu3 = (1.0 * c[9]) / pow(rad, 3.0);                   // :683-684
+    double T_tot, mdot;
+    if (ph == 1 || ph == 2) {                                          // :688-711
+      const double T_srb = 1.0 * ((ph == 1 ? 6 : 3) * c[16]);
+      const double T_first = 1.0 * c[17];
+      T_tot = T_srb + T_first;
+      double m1dot = 0.0, m2dot = 0.0;
+      m1dot -= T_srb / (c[15] * c[19]);
+      m2dot -= T_first / (c[15] * c[20]);
+      mdot = m1dot + m2dot;
+    } else if (ph == 3) {                                              // :712-717
+      T_tot = 1.0 * c[17];
+      mdot = 0.0;
+      mdot -= T_tot / (c[15] * c[20]);
+    } else {                                                           // :718-724
+      T_tot = 1.0 * c[18];
+      mdot = 0.0;
+      mdot -= T_tot / (c[15] * c[21]);
+    }
+    p[0] = (u[0] * u[0] + u[1] * u[1]) + u[2] * u[2];                  // :726
+    const double Toverm = T_tot / m;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double drag = (bcspeed * (-1.0)) * vrel[j];                // :681-682
+      const double grav = (-mu3) * x[j];                               // :686
+      f[j] = x[3 + j];
+      f[3 + j] = (Toverm * u[j] + drag) + grav;                        // :733
+    }
+    f[6] = mdot;
+  }
+
+  // Armadillo 5.300.4 dot() on 3-vectors: (a0 b0 + a2 b2) + a1 b1
+  RPM_DEV static double dot3(const double* a, const double* b) {
+    double v1 = 0.0, v2 = 0.0;
+    v1 += a[0] * b[0];
+    v2 += a[1] * b[1];
+    v1 += a[2] * b[2];
+    return v1 + v2;
+  }
+  // Launchrv2oe, :592-634 (first five elements) — event of phase 4, :744-754
+  RPM_DEV static void event(int ph, double t0, const double* x0, double tf, const double* xf,
+                            const double* c, double* ev) {
+    (void)t0; (void)x0; (void)tf;
+    if (ph != 4) return;
+    const double mu = c[9];
+    const double* rv = xf;
+    const double* vv = xf + 3;
+    double hv[3], nv[3], e3[3];
+    hv[0] = rv[1] * vv[2] - rv[2] * vv[1];
+    hv[1] = rv[2] * vv[0] - rv[0] * vv[2];
+    hv[2] = rv[0] * vv[1] - rv[1] * vv[0];
+    // cross(K,hv), K = (0,0,1)
+    nv[0] = 0.0 * hv[2] - 1.0 * hv[1];
+    nv[1] = 1.0 * hv[0] - 0.0 * hv[2];
+    nv[2] = 0.0 * hv[1] - 0.0 * hv[0];
+    const double n = sqrt(dot3(nv, nv));
+    const double h2 = dot3(hv, hv);
+    const double v2 = dot3(vv, vv);
+    const double r = sqrt(dot3(rv, rv));
+    const double s1 = v2 - mu / r, s2 = dot3(rv, vv);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) e3[j] = (rv[j] * s1 - vv[j] * s2) * (1.0 / mu);
+    const double p = h2 / mu;
+    const double e = sqrt(dot3(e3, e3));
+    const double twopi = 2 * 3.14159265358979323846;
+    double Om1 = acos(nv[0] / n);
+    if (nv[1] < 0 - 2.220446049250313e-16) Om1 = twopi - Om1;
+    double Om2 = acos(dot3(nv, e3) / n / e);
+    if (e3[2] < 0) Om2 = twopi - Om2;
+    ev[0] = p / (1 - e * e);
+    ev[1] = e;
+    ev[2] = acos(hv[2] / sqrt(h2));
+    ev[3] = Om1;
+    ev[4] = Om2;
+  }
+  RPM_DEV static void link(int lph, int rph, const double* xfl, const double* x0r, const double* c,
+                           int nlink, double* out) {                   // :760-765
+    (void)lph; (void)rph; (void)c;
+    for (int j = 0; j < nlink; ++j) out[j] = x0r[j] - xfl[j];
+  }
+  RPM_DEV static double mayer(int ph, double t0, const double* x0, double tf, const double* xf,
+                              const double* c) {                       // :636-646
+    (void)t0; (void)x0; (void)tf; (void)c;
+    return ph == 4 ? -xf[6] : 0.0;
+  }
+  RPM_DEV static double lagrange(int ph, double t, const double* x, const double* u, const double* c) {
+    (void)ph; (void)t; (void)x; (void)u; (void)c;
+    return 0.0;                                                        // :652-656
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Hypersensitive — example/hypersensitive/HyperSensitive.cpp:74-167 (ships analytic derivatives)
+struct HypersensitiveProblem {
+  static constexpr int ID = RPM_PROBLEM_HYPERSENSITIVE;
+  static constexpr int NX = 1, NU = 1, NC = 0, NE_MAX = 0, NLINK_MAX = 0, NCONST = 0;
+  static constexpr bool HAS_ANALYTIC = true;
+  RPM_DEV static void dae(int, double, const double* x, const double* u, const double*, double* f, double*) {
+    f[0] = ((-x[0]) * x[0]) * x[0] + u[0];                             // :131
+  }
+  // column v of [df/dx, df/du, df/dt] (DerivDae :134-151)
+  RPM_DEV static void dae_jac_col(int, int v, double, const double* x, const double*, const double*,
+                                  double* df, double*) {
+    df[0] = (v == 0) ? -3 * (x[0] * x[0]) : (v == 1 ? 1.0 : 0.0);
+  }
+  RPM_DEV static void event(int, double, const double*, double, const double*, const double*, double*) {}
+  RPM_DEV static void link(int, int, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer(int, double, const double*, double, const double*, const double*) { return 0.0; }
+  RPM_DEV static double lagrange(int, double, const double* x, const double* u, const double*) {
+    return 0.5 * (x[0] * x[0] + u[0] * u[0]);                          // :107
+  }
+  // column v of [dL/dx, dL/du, dL/dt] (DerivLagrange :110-121)
+  RPM_DEV static double lagrange_grad_col(int, int v, double, const double* x, const double* u, const double*) {
+    return v == 0 ? x[0] : (v == 1 ? u[0] : 0.0);
+  }
+  // entry v of [dM/dx0.., dM/dt0, dM/dxf.., dM/dtf] (DerivMayer :88-97)
+  RPM_DEV static double mayer_grad_col(int, int, double, const double*, double, const double*, const double*) {
+    return 0.0;
+  }
+  RPM_DEV static void event_jac_col(int, int, double, const double*, double, const double*, const double*, double*) {}
+  RPM_DEV static void link_jac_col(int, int, int, const double*, const double*, const double*, int, double*) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Bryson-Denham — example/bryson-denham/BrysonDenham.cpp:100-167
+struct BrysonDenhamProblem {
+  static constexpr int ID = RPM_PROBLEM_BRYSON_DENHAM;
+  static constexpr int NX = 3, NU = 1, NC = 0, NE_MAX = 5, NLINK_MAX = 0, NCONST = 0;
+  static constexpr bool HAS_ANALYTIC = false;
+  RPM_DEV static void dae(int, double, const double* x, const double* u, const double*, double* f, double*) {
+    f[0] = x[1];
+    f[1] = u[0];
+    f[2] = 0.5 * (u[0] * u[0]);                                        // :121-123
+  }
+  RPM_DEV static void event(int, double, const double* x0, double, const double* xf, const double*, double* ev) {
+    ev[0] = x0[0]; ev[1] = x0[1]; ev[2] = x0[2]; ev[3] = xf[0]; ev[4] = xf[1];  // :139-153
+  }
+  RPM_DEV static void link(int, int, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer(int, double, const double*, double, const double* xf, const double*) { return xf[2]; }
+  RPM_DEV static double lagrange(int, double, const double*, const double*, const double*) { return 0.0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Brachistochrone (authored, BASELINE config 1; equations in DESIGN.md).  consts[0] = g.
+struct BrachistochroneProblem {
+  static constexpr int ID = RPM_PROBLEM_BRACHISTOCHRONE;
+  static constexpr int NX = 3, NU = 1, NC = 0, NE_MAX = 5, NLINK_MAX = 0, NCONST = 1;
+  static constexpr bool HAS_ANALYTIC = true;
+  RPM_DEV static void dae(int, double, const double* x, const double* u, const double* c, double* f, double*) {
+    const double sn = sin(u[0]), cs = cos(u[0]);
+    f[0] = x[2] * sn;
+    f[1] = x[2] * cs;
+    f[2] = c[0] * cs;
+  }
+  RPM_DEV static void dae_jac_col(int, int v, double, const double* x, const double* u, const double* c,
+                                  double* df, double*) {
+    const double sn = sin(u[0]), cs = cos(u[0]);
+    df[0] = df[1] = df[2] = 0.0;
+    if (v == 2) { df[0] = sn; df[1] = cs; }
+    if (v == 3) { df[0] = x[2] * cs; df[1] = -(x[2] * sn); df[2] = -(c[0] * sn); }
+  }
+  RPM_DEV static void event(int, double, const double* x0, double, const double* xf, const double*, double* ev) {
+    ev[0] = x0[0]; ev[1] = x0[1]; ev[2] = x0[2]; ev[3] = xf[0]; ev[4] = xf[1];
+  }
+  // column v of d event / d [x0.., t0, xf.., tf]
+  RPM_DEV static void event_jac_col(int, int v, double, const double*, double, const double*, const double*, double* de) {
+    for (int i = 0; i < 5; ++i) de[i] = 0.0;
+    if (v < 3) de[v] = 1.0;
+    if (v == 4) de[3] = 1.0;
+    if (v == 5) de[4] = 1.0;
+  }
+  RPM_DEV static void link(int, int, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static void link_jac_col(int, int, int, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer(int, double, const double*, double tf, const double*, const double*) { return tf; }
+  RPM_DEV static double mayer_grad_col(int, int v, double, const double*, double, const double*, const double*) {
+    return v == 2 * NX + 1 ? 1.0 : 0.0;
+  }
+  RPM_DEV static double lagrange(int, double, const double*, const double*, const double*) { return 0.0; }
+  RPM_DEV static double lagrange_grad_col(int, int, double, const double*, const double*, const double*) { return 0.0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Minimum time to climb (authored, BASELINE config 2; equations in DESIGN.md).
+// consts: 0 Re, 1 mu, 2 S, 3 g0, 4 Isp, 5 rho0, 6 Hs, 7 a0, 8 a1, 9 Tmax
+struct MinTimeClimbProblem {
+  static constexpr int ID = RPM_PROBLEM_MIN_TIME_CLIMB;
+  static constexpr int NX = 4, NU = 1, NC = 0, NE_MAX = 7, NLINK_MAX = 0, NCONST = 10;
+  static constexpr bool HAS_ANALYTIC = false;
+  RPM_DEV static void dae(int, double, const double* x, const double* u, const double* c, double* f, double*) {
+    const double h = x[0], v = x[1], gam = x[2], m = x[3], al = u[0];
+    const double r = h + c[0];
+    const double rho = c[5] * exp(-h / c[6]);
+    const double as = c[7] - c[8] * h;
+    const double M = v / as;
+    const double ch = cosh((M - 1.0) / 0.06);
+    const double CLa = 3.44 + 1.0 / (ch * ch);
+    const double CD0 = 0.013 + 0.0144 * (1.0 + tanh((M - 0.98) / 0.06));
+    const double eta = 0.54 + 0.15 * (1.0 + tanh((M - 0.9) / 0.06));
+    const double CD = CD0 + eta * CLa * (al * al);
+    const double CL = CLa * al;
+    const double q = 0.5 * rho * v * v;
+    const double D = q * c[2] * CD;
+    const double Lf = q * c[2] * CL;
+    const double T = c[9] * pow(rho / c[5], 0.7) * (1.0 + 0.3 * M);
+    const double sg = sin(gam), cg = cos(gam), sa = sin(al), ca = cos(al);
+    f[0] = v * sg;
+    f[1] = (T * ca - D) / m - c[1] * sg / (r * r);
+    f[2] = (T * sa + Lf) / (m * v) + cg * (v / r - c[1] / (v * (r * r)));
+    f[3] = -T / (c[3] * c[4]);
+  }
+  RPM_DEV static void event(int, double, const double* x0, double, const double* xf, const double*, double* ev) {
+    ev[0] = x0[0]; ev[1] = x0[1]; ev[2] = x0[2]; ev[3] = x0[3]; ev[4] = xf[0]; ev[5] = xf[1]; ev[6] = xf[2];
+  }
+  RPM_DEV static void link(int, int, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer(int, double, const double*, double tf, const double*, const double*) { return tf; }
+  RPM_DEV static double lagrange(int, double, const double*, const double*, const double*) { return 0.0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Quadrotor (authored, BASELINE config 5; equations in DESIGN.md).
+// consts: 0 mass, 1 g, 2 arm, 3 Ixx, 4 Iyy, 5 Izz, 6 ktau, 7..9 pref, 10 wp, 11 wv, 12 wa, 13 ww, 14 wu
+struct QuadrotorProblem {
+  static constexpr int ID = RPM_PROBLEM_QUADROTOR;
+  static constexpr int NX = 12, NU = 4, NC = 0, NE_MAX = 0, NLINK_MAX = 0, NCONST = 15;
+  static constexpr bool HAS_ANALYTIC = false;
+  RPM_DEV static void dae(int, double, const double* x, const double* f4, const double* c, double* f, double*) {
+    const double ph = x[6], th = x[7], ps = x[8], p = x[9], q = x[10], r = x[11];
+    const double F = ((f4[0] + f4[1]) + f4[2]) + f4[3];
+    const double tx = c[2] * (f4[1] - f4[3]);
+    const double ty = c[2] * (f4[2] - f4[0]);
+    const double tz = c[6] * (((f4[0] - f4[1]) + f4[2]) - f4[3]);
+    const double sph = sin(ph), cph = cos(ph), sth = sin(th), cth = cos(th), sps = sin(ps), cps = cos(ps);
+    const double b3x = cph * sth * cps + sph * sps;
+    const double b3y = cph * sth * sps - sph * cps;
+    const double b3z = cph * cth;
+    const double Fm = F / c[0];
+    f[0] = x[3];
+    f[1] = x[4];
+    f[2] = x[5];
+    f[3] = Fm * b3x;
+    f[4] = Fm * b3y;
+    f[5] = Fm * b3z - c[1];
+    const double w = q * sph + r * cph;
+    f[6] = p + w * (sth / cth);
+    f[7] = q * cph - r * sph;
+    f[8] = w / cth;
+    f[9] = (tx - (c[5] - c[4]) * q * r) / c[3];
+    f[10] = (ty - (c[3] - c[5]) * p * r) / c[4];
+    f[11] = (tz - (c[4] - c[3]) * p * q) / c[5];
+  }
+  RPM_DEV static void event(int, double, const double*, double, const double*, const double*, double*) {}
+  RPM_DEV static void link(int, int, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer(int, double, const double*, double, const double*, const double*) { return 0.0; }
+  RPM_DEV static double lagrange(int, double, const double* x, const double* f4, const double* c) {
+    const double hov = c[0] * c[1] / 4.0;
+    const double d0 = x[0] - c[7], d1 = x[1] - c[8], d2 = x[2] - c[9];
+    const double ep = (d0 * d0 + d1 * d1) + d2 * d2;
+    const double evv = (x[3] * x[3] + x[4] * x[4]) + x[5] * x[5];
+    const double ea = (x[6] * x[6] + x[7] * x[7]) + x[8] * x[8];
+    const double ew = (x[9] * x[9] + x[10] * x[10]) + x[11] * x[11];
+    const double u0 = f4[0] - hov, u1 = f4[1] - hov, u2 = f4[2] - hov, u3 = f4[3] - hov;
+    const double eu = ((u0 * u0 + u1 * u1) + u2 * u2) + u3 * u3;
+    return (((c[10] * ep + c[11] * evv) + c[12] * ea) + c[13] * ew) + c[14] * eu;
+  }
+};
+
+}  // namespace rpm

@@ -1,0 +1,393 @@
+// rpm_abi.cpp — the extern "C" boundary declared in include/rpm_hip.h.  Thin: argument checks,
+// the TNLP value/structure protocol (Core/LpopcIpopt.cpp:11-246), host<->device staging for
+// the host-pointer path, and error capture (no exception leaves this file).
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rpm_engine.hpp"
+
+struct rpm_engine {
+  rpm::Engine e;
+};
+
+static thread_local std::string g_create_error;
+
+using rpm::Engine;
+
+#define RPM_GUARD_BEGIN try {
+#define RPM_GUARD_END(eng)                                   \
+  }                                                          \
+  catch (const std::exception& ex) {                         \
+    (eng).err = std::string("internal error: ") + ex.what(); \
+    return RPM_E_INVALID;                                    \
+  }                                                          \
+  catch (...) {                                              \
+    (eng).err = "internal error";                            \
+    return RPM_E_INVALID;                                    \
+  }
+
+static int fail(Engine& e, int code, const char* msg) {
+  e.err = msg;
+  return code;
+}
+
+static bool all_finite(const double* v, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(v[i])) return false;
+  return true;
+}
+
+extern "C" {
+
+int rpm_create(const rpm_problem_desc* desc, rpm_engine** out) {
+  if (!out) {
+    g_create_error = "rpm_create: out is NULL";
+    return RPM_E_INVALID;
+  }
+  *out = nullptr;
+  rpm_engine* h = new (std::nothrow) rpm_engine();
+  if (!h) {
+    g_create_error = "out of memory";
+    return RPM_E_INVALID;
+  }
+  int rc;
+  try {
+    rc = rpm::setup_engine(h->e, desc);
+  } catch (const std::exception& ex) {
+    h->e.err = std::string("internal error: ") + ex.what();
+    rc = RPM_E_INVALID;
+  }
+  if (rc != RPM_OK) {
+    g_create_error = h->e.err;
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return RPM_OK;
+}
+
+void rpm_destroy(rpm_engine* h) {
+  if (!h) return;
+  rpm::device_destroy(h->e);
+  delete h;
+}
+
+const char* rpm_last_error(const rpm_engine* h) { return h ? h->e.err.c_str() : g_create_error.c_str(); }
+
+int rpm_device_init(rpm_engine* h, int device_id) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  return rpm::device_init(h->e, device_id);
+  RPM_GUARD_END(h->e)
+}
+
+int rpm_get_nlp_info(rpm_engine* h, int* n, int* m, int* nnz_jac_g, int* nnz_h_lag, int* index_style) {
+  if (!h) return RPM_E_INVALID;
+  const Engine& e = h->e;
+  if (n) *n = e.n;
+  if (m) *m = e.m;
+  if (nnz_jac_g) *nnz_jac_g = e.nnz_jac;
+  if (nnz_h_lag) *nnz_h_lag = e.nnz_h;
+  if (index_style) *index_style = 0;  // TNLP::C_STYLE, LpopcIpopt.cpp:22
+  return RPM_OK;
+}
+
+int rpm_get_bounds_info(rpm_engine* h, int n, double* x_l, double* x_u, int m, double* g_l, double* g_u) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  if (n != e.n || m != e.m || !x_l || !x_u || !g_l || !g_u) return fail(e, RPM_E_INVALID, "get_bounds_info: size mismatch");
+  std::memcpy(x_l, e.xl.data(), sizeof(double) * e.n);
+  std::memcpy(x_u, e.xu.data(), sizeof(double) * e.n);
+  std::memcpy(g_l, e.gl.data(), sizeof(double) * e.m);
+  std::memcpy(g_u, e.gu.data(), sizeof(double) * e.m);
+  return RPM_OK;
+}
+
+int rpm_get_starting_point(rpm_engine* h, int n, int init_x, double* x, int init_z, double* z_L, double* z_U,
+                           int m, int init_lambda, double* lambda) {
+  (void)z_L; (void)z_U; (void)lambda;
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  // the reference asserts exactly this combination (LpopcIpopt.cpp:86-88)
+  if (!init_x || init_z || init_lambda) return fail(e, RPM_E_INVALID, "get_starting_point: only init_x is supported");
+  if (n != e.n || m != e.m || !x) return fail(e, RPM_E_INVALID, "get_starting_point: size mismatch");
+  std::memcpy(x, e.guess.data(), sizeof(double) * e.n);
+  return RPM_OK;
+}
+
+// ---- host-pointer evaluations (Ipopt owns every buffer; x/g/values cross PCIe each call) --------
+static int stage_x(Engine& e, int n, const double* x, int new_x) {
+  if (n != e.n || !x) return fail(e, RPM_E_INVALID, "x size mismatch");
+  if (!e.dev) {
+    int rc = rpm::device_init(e, 0);
+    if (rc) return rc;
+    new_x = 1;
+  }
+  if (new_x) {
+    rpm::dev_cache_valid(e) = false;
+    return rpm::dev_upload_x(e, x);
+  }
+  return RPM_OK;
+}
+
+int rpm_eval_f(rpm_engine* h, int n, const double* x, int new_x, double* obj_value) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (!obj_value) return fail(e, RPM_E_INVALID, "eval_f: obj_value is NULL");
+  int rc = stage_x(e, n, x, 1);
+  (void)new_x;
+  if (rc) return rc;
+  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), nullptr, nullptr);
+  if (rc) return rc;
+  rc = rpm::dev_download(e, obj_value, rpm::dev_buf(e, 4), size_t(e.n_instances));
+  if (rc) return rc;
+  if (e.opt_check_finite && !all_finite(obj_value, size_t(e.n_instances))) return fail(e, RPM_E_NONFINITE, "eval_f: non-finite objective");
+  return RPM_OK;
+  RPM_GUARD_END(e)
+}
+
+int rpm_eval_grad_f(rpm_engine* h, int n, const double* x, int new_x, double* grad_f) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (!grad_f) return fail(e, RPM_E_INVALID, "eval_grad_f: grad_f is NULL");
+  int rc = stage_x(e, n, x, 1);
+  (void)new_x;
+  if (rc) return rc;
+  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), rpm::dev_buf(e, 3), nullptr);
+  if (rc) return rc;
+  rc = rpm::dev_download(e, grad_f, rpm::dev_buf(e, 3), size_t(e.n_instances) * e.n);
+  if (rc) return rc;
+  if (e.opt_check_finite && !all_finite(grad_f, size_t(e.n_instances) * e.n)) return fail(e, RPM_E_NONFINITE, "eval_grad_f: non-finite gradient");
+  return RPM_OK;
+  RPM_GUARD_END(e)
+}
+
+int rpm_eval_g(rpm_engine* h, int n, const double* x, int new_x, int m, double* g) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (m != e.m || !g) return fail(e, RPM_E_INVALID, "eval_g: size mismatch");
+  // x is re-uploaded on every eval_g: Ipopt may call eval_g(new_x=false) after eval_f(new_x=true) on the
+  // same x, but the upload is cheap next to the D2H of the results and keeps the cache logic simple.
+  int rc = stage_x(e, n, x, 1);
+  (void)new_x;
+  if (rc) return rc;
+  const int flags = e.opt_fuse_pair ? 3 : 1;  // fused: the Jacobian of the same x is produced by the same launch
+  rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), flags, nullptr);
+  if (rc) return rc;
+  rc = rpm::dev_download(e, g, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m);
+  if (rc) return rc;
+  rpm::dev_cache_valid(e) = (flags == 3);
+  if (e.opt_check_finite && !all_finite(g, size_t(e.n_instances) * e.m)) return fail(e, RPM_E_NONFINITE, "eval_g: non-finite constraint value");
+  return RPM_OK;
+  RPM_GUARD_END(e)
+}
+
+int rpm_eval_jac_g(rpm_engine* h, int n, const double* x, int new_x, int m, int nele_jac, int* iRow, int* jCol,
+                   double* values) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (n != e.n || m != e.m || nele_jac != e.nnz_jac) return fail(e, RPM_E_INVALID, "eval_jac_g: size mismatch");
+  if (!values) {  // structure pass, LpopcIpopt.cpp:156-164
+    if (!iRow || !jCol) return fail(e, RPM_E_INVALID, "eval_jac_g: iRow/jCol are NULL in the structure pass");
+    std::memcpy(iRow, e.jac_i.data(), sizeof(int) * e.nnz_jac);
+    std::memcpy(jCol, e.jac_j.data(), sizeof(int) * e.nnz_jac);
+    return RPM_OK;
+  }
+  if (!x) return fail(e, RPM_E_INVALID, "eval_jac_g: x is NULL");
+  int rc = RPM_OK;
+  const bool cached = e.dev && !new_x && rpm::dev_cache_valid(e);
+  if (!cached) {
+    rc = stage_x(e, n, x, 1);
+    if (rc) return rc;
+    rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), 2, nullptr);
+    if (rc) return rc;
+  }
+  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac);
+  if (rc) return rc;
+  if (e.opt_check_finite && !all_finite(values, size_t(e.n_instances) * e.nnz_jac)) return fail(e, RPM_E_NONFINITE, "eval_jac_g: non-finite Jacobian value");
+  return RPM_OK;
+  RPM_GUARD_END(e)
+}
+
+int rpm_eval_h(rpm_engine* h, int n, const double* x, int new_x, double obj_factor, int m, const double* lambda,
+               int new_lambda, int nele_hess, int* iRow, int* jCol, double* values) {
+  (void)n; (void)x; (void)new_x; (void)obj_factor; (void)m; (void)lambda; (void)new_lambda; (void)nele_hess;
+  (void)iRow; (void)jCol; (void)values;
+  if (!h) return RPM_E_INVALID;
+  // With hessian-approximation=limited-memory (the reference's default, LpNLPWrapper.hpp:71) Ipopt never calls
+  // eval_h.  The exact finite-difference Hessian (LpHessian.cpp) is SURVEY §8 row f-1, not built yet.
+  return fail(h->e, RPM_E_UNSUPPORTED, "eval_h: hessian-approximation=exact is not implemented yet");
+}
+
+int rpm_finalize_solution(rpm_engine* h, int status, int n, const double* x, const double* z_L, const double* z_U,
+                          int m, const double* g, const double* lambda, double obj_value) {
+  (void)status; (void)z_L; (void)z_U; (void)g;
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  if (n != e.n || m != e.m || !x || !lambda) return fail(e, RPM_E_INVALID, "finalize_solution: size mismatch");
+  e.sol_x.assign(x, x + n);            // Data_->nlpreturn_x, LpopcIpopt.cpp:237-238
+  e.sol_lambda.assign(lambda, lambda + m);
+  e.sol_obj = obj_value;
+  e.has_solution = true;
+  return RPM_OK;
+}
+
+int rpm_get_solution(rpm_engine* h, int n, double* x, int m, double* lambda, double* obj_value) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  if (!e.has_solution) return fail(e, RPM_E_INVALID, "no solution stored");
+  if (n != e.n || m != e.m) return fail(e, RPM_E_INVALID, "get_solution: size mismatch");
+  if (x) std::memcpy(x, e.sol_x.data(), sizeof(double) * n);
+  if (lambda) std::memcpy(lambda, e.sol_lambda.data(), sizeof(double) * m);
+  if (obj_value) *obj_value = e.sol_obj;
+  return RPM_OK;
+}
+
+// ---- device-resident variants ----------------------------------------------------------------
+int rpm_eval_g_dev(rpm_engine* h, const double* d_x, double* d_g, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_x || !d_g) return fail(h->e, RPM_E_INVALID, "eval_g_dev: NULL pointer");
+  return rpm::dev_eval_cons(h->e, d_x, d_g, nullptr, 1, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_eval_jac_g_dev(rpm_engine* h, const double* d_x, double* d_values, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_x || !d_values) return fail(h->e, RPM_E_INVALID, "eval_jac_g_dev: NULL pointer");
+  return rpm::dev_eval_cons(h->e, d_x, nullptr, d_values, 2, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_eval_pair_dev(rpm_engine* h, const double* d_x, double* d_g, double* d_values, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_x || !d_g || !d_values) return fail(h->e, RPM_E_INVALID, "eval_pair_dev: NULL pointer");
+  return rpm::dev_eval_cons(h->e, d_x, d_g, d_values, 3, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_eval_f_dev(rpm_engine* h, const double* d_x, double* d_obj, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_x || !d_obj) return fail(h->e, RPM_E_INVALID, "eval_f_dev: NULL pointer");
+  return rpm::dev_eval_obj(h->e, d_x, d_obj, nullptr, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_eval_grad_f_dev(rpm_engine* h, const double* d_x, double* d_grad_f, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_x || !d_grad_f) return fail(h->e, RPM_E_INVALID, "eval_grad_f_dev: NULL pointer");
+  return rpm::dev_eval_obj(h->e, d_x, nullptr, d_grad_f, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_eval_h_dev(rpm_engine* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_values,
+                   void* stream) {
+  (void)d_x; (void)obj_factor; (void)d_lambda; (void)d_values; (void)stream;
+  if (!h) return RPM_E_INVALID;
+  return fail(h->e, RPM_E_UNSUPPORTED, "eval_h_dev: hessian-approximation=exact is not implemented yet");
+}
+int rpm_synchronize(rpm_engine* h) {
+  if (!h) return RPM_E_INVALID;
+  return rpm::dev_sync(h->e);
+}
+
+// ---- options ----------------------------------------------------------------------------------
+int rpm_set_option(rpm_engine* h, const char* key, int value) {
+  if (!h || !key) return RPM_E_INVALID;
+  Engine& e = h->e;
+  const std::string k(key);
+  if (k == "fuse_pair") e.opt_fuse_pair = value ? 1 : 0;
+  else if (k == "check_finite") e.opt_check_finite = value ? 1 : 0;
+  else if (k == "dx_mode") {
+    if (value != 0) return fail(e, RPM_E_UNSUPPORTED, "dx_mode=1 (MFMA D.X) is not implemented yet");
+    e.opt_dx_mode = value;
+  } else if (k == "tile_nodes") {
+    if (value != 0 && value != 16 && value != 32 && value != 64) return fail(e, RPM_E_INVALID, "tile_nodes must be 0, 16, 32 or 64");
+    if (e.dev) return fail(e, RPM_E_INVALID, "tile_nodes must be set before the device is initialised");
+    e.opt_tile_nodes = value;
+    if (value) rpm::build_tiles(e, value);
+  } else
+    return fail(e, RPM_E_INVALID, "unknown option");
+  return RPM_OK;
+}
+int rpm_get_option(rpm_engine* h, const char* key, int* value) {
+  if (!h || !key || !value) return RPM_E_INVALID;
+  Engine& e = h->e;
+  const std::string k(key);
+  if (k == "fuse_pair") *value = e.opt_fuse_pair;
+  else if (k == "check_finite") *value = e.opt_check_finite;
+  else if (k == "dx_mode") *value = e.opt_dx_mode;
+  else if (k == "tile_nodes") *value = e.tile_nodes;
+  else if (k == "n_tiles") *value = int(e.tiles.size());
+  else return fail(e, RPM_E_INVALID, "unknown option");
+  return RPM_OK;
+}
+
+// ---- collocation tables ---------------------------------------------------------------------
+int rpm_get_phase_sizes(rpm_engine* h, int phase, int* n_nodes, int* d_nnz, int* doff_nnz) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  if (phase < 0 || phase >= e.P) return fail(e, RPM_E_INVALID, "The phase index is out of rang");
+  if (n_nodes) *n_nodes = e.ph[phase].N;
+  if (d_nnz) *d_nnz = int(e.ph[phase].d_v.size());
+  if (doff_nnz) *doff_nnz = int(e.ph[phase].off_v.size());
+  return RPM_OK;
+}
+int rpm_get_phase_tables(rpm_engine* h, int phase, double* points, double* weights, int* d_rows, int* d_cols,
+                         double* d_vals, double* diag_vals, int* doff_rows, int* doff_cols, double* doff_vals) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  if (phase < 0 || phase >= e.P) return fail(e, RPM_E_INVALID, "The phase index is out of rang");
+  const rpm::PhaseHost& p = e.ph[phase];
+  auto cp = [](auto* dst, const auto& v) {
+    if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+  };
+  cp(points, p.points);
+  cp(weights, p.weights);
+  cp(d_rows, p.d_i);
+  cp(d_cols, p.d_j);
+  cp(d_vals, p.d_v);
+  cp(diag_vals, p.diag_v);
+  cp(doff_rows, p.off_i);
+  cp(doff_cols, p.off_j);
+  cp(doff_vals, p.off_v);
+  return RPM_OK;
+}
+
+// ---- interval sharding ---------------------------------------------------------------------------
+int rpm_shard_segments(rpm_engine* h, int which, int rank, rpm_segment* seg, int* n_seg, int* packed_len) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (which < 0 || which > 1 || rank < 0 || rank >= e.shard_world) return fail(e, RPM_E_INVALID, "shard_segments: bad argument");
+  int plen = 0;
+  std::vector<rpm_segment> s = rpm::shard_segments(e, which, rank, &plen);
+  if (seg) {
+    if (!n_seg || *n_seg < int(s.size())) return fail(e, RPM_E_INVALID, "shard_segments: segment buffer too small");
+    std::memcpy(seg, s.data(), s.size() * sizeof(rpm_segment));
+  }
+  if (n_seg) *n_seg = int(s.size());
+  if (packed_len) *packed_len = plen;
+  return RPM_OK;
+  RPM_GUARD_END(e)
+}
+int rpm_shard_pack_dev(rpm_engine* h, int which, const double* d_full, double* d_packed, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_full || !d_packed || which < 0 || which > 1) return fail(h->e, RPM_E_INVALID, "shard_pack_dev: bad argument");
+  return rpm::dev_shard_copy(h->e, which, true, d_full, 0, d_packed, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_shard_unpack_dev(rpm_engine* h, int which, const double* d_gathered, int stride, double* d_full, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_gathered || !d_full || which < 0 || which > 1) return fail(h->e, RPM_E_INVALID, "shard_unpack_dev: bad argument");
+  return rpm::dev_shard_copy(h->e, which, false, d_gathered, stride, d_full, stream);
+  RPM_GUARD_END(h->e)
+}
+}  // extern "C"

@@ -1,0 +1,860 @@
+// rpm_device.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4) and the device half of
+// the engine.  No CPU fallback lives here or anywhere else in the product.
+//
+// Kernels (DESIGN.md §Kernels has the roofline of each):
+//   rpm_tile_kernel   K1+K2+K3 fused: per-node dynamics/path evaluation, forward-difference (or
+//                     analytic) node Jacobian, LGR defect D.X - (dt/2) f, and the coalesced block
+//                     scatter of the COO Jacobian values, plus this workgroup's share of the
+//                     constant Doffdiag block.  Replaces NLPWrapper::GetConsFun (LpNLPWrapper.cpp:55-229),
+//                     GetPhaseJacbi (:524-862), LpFDderive::DerivDae (LpFiniteDifferenceDerive.cpp:194-324)
+//                     and dsmatrix::operator* (SparseMatrix/LpSparseMatrix.cpp:127-155).
+//   endpoint block    K4: events, linkages, A_lin.x rows and their Jacobian entries
+//                     (LpNLPWrapper.cpp:125-136,180-211,406-522,833-861; :45,:242); one extra workgroup
+//                     of the same launch.
+//   rpm_obj_kernel    K5: objective quadrature and gradient (GetObjFun :863-939, GetObjGrad :940-1104).
+//
+// Thread layout of rpm_tile_kernel: a workgroup owns a tile of <= T consecutive collocation nodes of one
+// phase; thread = (role, node) with node fastest, so that the N-long diagonal runs of every Jacobian
+// block are written by consecutive lanes (coalesced 8-byte stores).  Role 0 evaluates the unperturbed
+// dynamics, role 1+v the dynamics with variable v perturbed (v = states, controls, time) — the
+// reference's (2+nx+nu) whole-vector user calls become (2+nx+nu) roles evaluated concurrently.
+// State roles also compute their state's D.X row from the LDS-staged D rows and X tile.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "problems/problems.hpp"
+#include "rpm_engine.hpp"
+
+namespace rpm {
+
+// ------------------------------------------------------------------------------------------
+struct KParams {
+  const PhaseDev* phases;
+  const TileDev* tiles;
+  const int* tile_ids;   // tiles owned by this rank
+  int n_my_tiles;
+  const TaskDev* tasks;  // endpoint work items, one extra workgroup each
+  int n_tasks;
+  const NodeDev* nodes;
+  const double* points;
+  const double* weights;
+  const double* diag;
+  const double* dvals;
+  const double* doff_vals;
+  const double* consts;
+  const LinkDev* links;
+  const int* alin_j;     // 2 entries per linear row
+  const double* alin_v;
+  double tol;
+  int P, L, n, m, m_nl, nnz, nnz_nl, nnz_lin, nnz_const;
+  int max_span, max_drow;
+  int diag_mask;                        // ablation mask, only honoured by the -DRPM_DIAG diagnostic build
+};
+
+struct Device {
+  int device_id = -1;
+  hipStream_t stream = nullptr;
+  KParams kp{};
+  // tables
+  PhaseDev* d_phases = nullptr;
+  TileDev* d_tiles = nullptr;
+  int* d_tile_ids = nullptr;
+  TaskDev* d_tasks = nullptr;
+  NodeDev* d_nodes = nullptr;
+  double *d_points = nullptr, *d_weights = nullptr, *d_diag = nullptr, *d_dvals = nullptr,
+         *d_doff = nullptr, *d_consts = nullptr, *d_alin_v = nullptr;
+  LinkDev* d_links = nullptr;
+  int* d_alin_j = nullptr;
+  // staging buffers of the host-pointer TNLP path
+  double *d_x = nullptr, *d_g = nullptr, *d_values = nullptr, *d_grad = nullptr, *d_obj = nullptr,
+         *d_lambda = nullptr, *d_hess = nullptr;
+  double* d_partial = nullptr;  // objective partial sums
+  bool cache_valid = false;     // d_g / d_values hold the pair of the x last uploaded
+  size_t lds_bytes = 0;
+  struct SegTable { void* ptr = nullptr; int count = 0; int stride = -1; };
+  SegTable segtab[2][2];        // [g|values][pack|unpack] run tables of the interval sharding
+};
+
+#define HIP_TRY(e, call)                                                                   \
+  do {                                                                                     \
+    hipError_t _s = (call);                                                                \
+    if (_s != hipSuccess) {                                                                \
+      (e).err = std::string(#call) + ": " + hipGetErrorString(_s);                         \
+      return RPM_E_DEVICE;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// endpoint rows: events, linkages, linear rows.  Each work item (TaskDev) is one workgroup of the same
+// launch, so the three kinds run concurrently on different CUs.
+template <class Prob, bool WG, bool WJ, bool AN>
+__device__ void endpoint_block(const KParams& K, const TaskDev task, const double* __restrict__ x,
+                               double* __restrict__ g, double* __restrict__ vals, double* lds) {
+  constexpr int NX = Prob::NX;
+  constexpr int NE = Prob::NE_MAX > 0 ? Prob::NE_MAX : 1;
+  constexpr int NL = Prob::NLINK_MAX > 0 ? Prob::NLINK_MAX : 1;
+  const int tid = threadIdx.x;
+  const double* c = K.consts;
+  if (task.type == 0) {
+    // linear rows  A_lin * x  (LpNLPWrapper.cpp:45; COO loop order of LpSparseMatrix.cpp:142-153) and
+    // their constant Jacobian entries (:242)
+    for (int r = tid; r < K.P + K.L; r += blockDim.x) {
+      if (WG) {
+        double acc = 0.0;
+        acc += K.alin_v[2 * r] * x[K.alin_j[2 * r]];
+        acc += K.alin_v[2 * r + 1] * x[K.alin_j[2 * r + 1]];
+        g[K.m_nl + r] = acc;
+      }
+      if (WJ) {
+        vals[K.nnz_nl + 2 * r] = K.alin_v[2 * r];
+        vals[K.nnz_nl + 2 * r + 1] = K.alin_v[2 * r + 1];
+      }
+    }
+  } else if (task.type == 1) {
+    // ---- events of one phase: lane 0 = base, lanes 1..2NX+2 = perturbations [x0.., t0, xf.., tf]
+    //      (LpFDderive::DerivEvent, LpFiniteDifferenceDerive.cpp:326-409)
+    const PhaseDev ph = K.phases[task.idx];
+    const int pi = tid;
+    const bool act = pi <= 2 * NX + 2;
+    double x0[NX], xf[NX], ev[NE];
+    double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      x0[j] = x[ph.x_state0 + j * (ph.N + 1)];
+      xf[j] = x[ph.x_state0 + j * (ph.N + 1) + ph.N];
+    }
+    double h = 1.0;
+    if (WJ && !AN && pi >= 1) {
+      const int v = pi - 1;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        if (v == j) { h = K.tol * (fabs(x0[j]) + 1); x0[j] += h; }
+        if (v == NX + 1 + j) { h = K.tol * (fabs(xf[j]) + 1); xf[j] += h; }
+      }
+      if (v == NX) { h = K.tol * (1 + fabs(t0)); t0 += h; }
+      if (v == 2 * NX + 1) { h = K.tol * (1 + fabs(tf)); tf += h; }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) ev[i] = 0.0;
+    if (act && (pi == 0 || !AN)) Prob::event(ph.phase_num, t0, x0, tf, xf, c, ev);
+    if (pi == 0) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        if (i < ph.ne) {
+          lds[i] = ev[i];
+          if (WG) g[ph.g0 + (NX + Prob::NC) * ph.N + i] = ev[i];
+        }
+    }
+    __syncthreads();
+    if (WJ && act && pi >= 1) {
+      const int v = pi - 1;
+      double de[NE];
+      if constexpr (AN) {
+        Prob::event_jac_col(ph.phase_num, v, t0, x0, tf, xf, c, de);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) de[i] = (ev[i] - lds[i]) / h;
+      }
+      // position inside an event's row of entries: (x0_j, xf_j) pairs, then t0, tf (:837-853)
+      int pos;
+      if (v < NX) pos = 2 * v;
+      else if (v == NX) pos = 2 * NX;
+      else if (v <= 2 * NX) pos = 2 * (v - NX - 1) + 1;
+      else pos = 2 * NX + 1;
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        if (i < ph.ne) vals[ph.v_evt0 + i * (2 * NX + 2) + pos] = de[i];
+    }
+  } else {
+    // ---- one linkage pair: lane 0 = base, 1..NX = xf_left perturbations, NX+1..2NX = x0_right
+    //      (LpFDderive::DerivLink, LpFiniteDifferenceDerive.cpp:411-502)
+    const LinkDev lk = K.links[task.idx];
+    const PhaseDev pl = K.phases[lk.left];
+    const PhaseDev pr = K.phases[lk.right];
+    const int pi = tid;
+    const bool act = pi <= 2 * NX;
+    double xl[NX], xr[NX], lo[NL];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      xl[j] = x[pl.x_state0 + j * (pl.N + 1) + pl.N];
+      xr[j] = x[pr.x_state0 + j * (pr.N + 1)];
+    }
+    double h = 1.0;
+    if (WJ && !AN && pi >= 1) {
+      const int v = pi - 1;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        if (v == j) { h = K.tol * (1 + fabs(xl[j])); xl[j] += h; }
+        if (v == NX + j) { h = K.tol * (1 + fabs(xr[j])); xr[j] += h; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) lo[i] = 0.0;
+    if (act && (pi == 0 || !AN)) Prob::link(lk.left + 1, lk.right + 1, xl, xr, c, lk.nlink, lo);
+    if (pi == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (i < lk.nlink) {
+          lds[i] = lo[i];
+          if (WG) g[lk.g0 + i] = lo[i];
+        }
+    }
+    __syncthreads();
+    if (WJ && act && pi >= 1) {
+      const int v = pi - 1;
+      double dl[NL];
+      if constexpr (AN) {
+        Prob::link_jac_col(lk.left + 1, lk.right + 1, v, xl, xr, c, lk.nlink, dl);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) dl[i] = (lo[i] - lds[i]) / (1.0 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (i < lk.nlink) vals[lk.v0 + v * lk.nlink + i] = dl[i];  // column-major, :461-501
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <class Prob, int T, bool WG, bool WJ, bool AN>
+__global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
+                                double* __restrict__ gall, double* __restrict__ vall) {
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
+  constexpr int NO = NX + NC;              // outputs per node: f then c
+  constexpr int NV = NX + NU + 1;          // perturbation variables: states, controls, time
+  constexpr int NB = NX + NU + 2;          // Jacobian blocks per output row: x.., u.., t0, tf
+  constexpr int R = WJ ? NV + 1 : (NX > 0 ? NX : 1);
+  constexpr int NCs = NC > 0 ? NC : 1;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const double* __restrict__ x = xall + size_t(blockIdx.y) * K.n;
+  double* __restrict__ g = gall + size_t(blockIdx.y) * K.m;
+  double* __restrict__ vals = vall + size_t(blockIdx.y) * K.nnz;
+#ifdef RPM_DIAG
+  if (K.diag_mask & 32) return;
+  if ((K.diag_mask & 1) && int(blockIdx.x) >= K.n_my_tiles) return;
+#endif
+  if (int(blockIdx.x) >= K.n_my_tiles) {  // the launch's trailing workgroups: endpoint work items
+    endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
+    return;
+  }
+  const TileDev tl = K.tiles[K.tile_ids[blockIdx.x]];
+  const TileDev& ph = tl;   // the phase fields the kernel needs are replicated in the tile record
+  const double* __restrict__ c = K.consts;
+  double* Xs = lds;                          // [NX][max_span]  state-matrix rows the tile's D rows touch
+  double* Us = Xs + NX * K.max_span;         // [NU][T]
+  double* Ds = Us + NU * T;                  // the tile's D rows, row-major per node
+  double* Fb = Ds + K.max_drow;              // [NO][T] unperturbed f and c
+
+  // ---- stage X tile, U tile and D rows in LDS (coalesced: every run below is contiguous in HBM) ----
+  for (int q = tid; q < NX * tl.span_len; q += nthr) {
+    const int i = q / tl.span_len, r = q - i * tl.span_len;
+    Xs[i * K.max_span + r] = x[ph.x_state0 + i * (ph.N + 1) + tl.span0 + r];
+  }
+  for (int q = tid; q < NU * tl.cnt; q += nthr) {
+    const int j = q / tl.cnt, r = q - j * tl.cnt;
+    Us[j * T + r] = x[ph.x_control0 + j * ph.N + tl.k0 + r];
+  }
+  if (WG)
+    for (int q = tid; q < tl.drow_len; q += nthr) Ds[q] = K.dvals[tl.drow0 + q];
+  const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+  __syncthreads();
+
+#ifdef RPM_DIAG
+  if (K.diag_mask & 16) return;
+#endif
+  const int kk = tid % T, role = tid / T;
+  const bool act = kk < tl.cnt && role < R;
+  const int kc = kk < tl.cnt ? kk : tl.cnt - 1;   // clamp so idle lanes read valid LDS
+  const int k = tl.k0 + kc;
+  const int nidx = ph.node0 + k;
+  const double tau = K.points[nidx];
+  const double tspan = tf - t0;
+  double tk = (tau + 1) * (tspan / 2.0) + t0;      // LpNLPWrapper.cpp:80
+  const NodeDev nd = K.nodes[nidx];
+  double xs[NX > 0 ? NX : 1], us[NU > 0 ? NU : 1];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - tl.span0)];
+#pragma unroll
+  for (int j = 0; j < NU; ++j) us[j] = Us[j * T + kc];
+
+  // ---- D.X for this thread's state: ascending-column sum, separate multiply and add, exactly the
+  //      order of the reference's COO loop for one output row (LpSparseMatrix.cpp:142-153) ----
+  const int sv = WJ ? role - 1 : role;
+  double dx = 0.0;
+  if (WG && sv >= 0 && sv < NX) {
+    const double* drow = Ds + (nd.drow_off - tl.drow0);
+    const double* xcol = Xs + sv * K.max_span + (nd.dcol0 - tl.span0);
+    for (int j = 0; j < nd.dlen; ++j) dx += drow[j] * xcol[j];
+  }
+
+  // ---- perturb this role's variable: h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214) ----
+  double h = 1.0;
+  const int v = role - 1;
+  if (WJ && !AN && role >= 1) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      if (v == i) { h = K.tol * (1 + fabs(xs[i])); xs[i] += h; }
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+      if (v == NX + j) { h = K.tol * (1 + fabs(us[j])); us[j] += h; }
+    if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
+  }
+  double f[NX > 0 ? NX : 1], cp[NCs];
+#ifdef RPM_DIAG
+  if (K.diag_mask & 2) {
+    for (int i = 0; i < NX; ++i) f[i] = xs[i] * tk;
+    for (int j = 0; j < NCs; ++j) cp[j] = us[0];
+  } else
+#endif
+  if (!AN || role == 0) {
+    Prob::dae(ph.phase_num, tk, xs, us, c, f, cp);
+  } else if constexpr (AN) {
+    Prob::dae_jac_col(ph.phase_num, v, tk, xs, us, c, f, cp);  // f, cp now hold column v of the Jacobian
+  }
+  if (role == 0 && act) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Fb[i * T + kk] = f[i];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      Fb[(NX + j) * T + kk] = cp[j];
+      if (WG) g[ph.g0 + (NX + j) * ph.N + k] = cp[j];           // path rows, :138-164
+    }
+  }
+  __syncthreads();
+
+  if (act) {
+    const int N = ph.N;
+    if (WG && sv >= 0 && sv < NX)
+      g[ph.g0 + sv * N + k] = dx - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
+#ifdef RPM_DIAG
+    if (!(K.diag_mask & 8))
+#endif
+    if (WJ && role >= 1) {
+      double J[NO];
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const double pert = o < NX ? f[o < NX ? o : 0] : cp[o >= NX ? o - NX : 0];
+        J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
+      }
+      double* vb = vals + ph.v_nl0 + k;
+      if (v < NX + NU) {
+        // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          double val;
+          if (o < NX) {
+            const double ret = J[o] * (tf - t0) / 2.0;
+            val = (o == v) ? K.diag[nidx] - ret : -ret;          // Ddiag - ret on the diagonal block, :712
+          } else {
+            val = J[o];
+          }
+          vb[size_t(o * NB + v) * N] = val;
+        }
+      } else {
+        // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign of the reference kept
+        const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          double v0, vf;
+          if (o < NX) {
+            const double fb = Fb[o * T + kk];
+            const double dt = J[o] * (tf - t0) / 2.0;
+            v0 = fb * (0.5) - a0 * dt;
+            vf = -fb * (0.5) + af * dt;
+          } else {
+            v0 = a0 * J[o];
+            vf = af * J[o];
+          }
+          vb[size_t(o * NB + NX + NU) * N] = v0;
+          vb[size_t(o * NB + NX + NU + 1) * N] = vf;
+        }
+      }
+    }
+  }
+
+  // ---- this workgroup's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718): the block is
+  //      nx back-to-back copies of the phase's off-diagonal value list; read each source value once,
+  //      store it into every state's copy (all runs contiguous across lanes) ----
+#ifdef RPM_DIAG
+  if (!(K.diag_mask & 4))
+#endif
+  if (WJ) {
+    const double* __restrict__ src = K.doff_vals + tl.c_src0;
+    double* __restrict__ dst = vals + tl.c_dst0;
+    for (int q = tid; q < tl.c_cnt; q += nthr) {
+      const double dv = src[q];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = dv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Objective and gradient.  One workgroup per phase; thread = node (strided).  Sums use a fixed
+// binary tree over the workgroup so the result is deterministic (independent of timing).
+template <class Prob, bool GRAD, bool AN>
+__global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall, double* __restrict__ objall,
+                               double* __restrict__ gradall, double* __restrict__ partial) {
+  constexpr int NX = Prob::NX, NU = Prob::NU;
+  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1;
+  __shared__ double red[3][256];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  const int inst = blockIdx.y;
+  const double* __restrict__ x = xall + size_t(inst) * K.n;
+  double* grad = GRAD ? gradall + size_t(inst) * K.n : nullptr;
+  const PhaseDev ph = K.phases[p];
+  const double* c = K.consts;
+  const int N = ph.N;
+  const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+  const double tspan = tf - t0;
+  double s_wl = 0.0, s_t0 = 0.0;   // sum w_k L_k ; sum (w_k dt/2 dL/dt)_k (1-tau_k)/2
+  for (int k = tid; k < N; k += blockDim.x) {
+    const double tau = K.points[ph.node0 + k], w = K.weights[ph.node0 + k];
+    const double tk = (tau + 1) * (tspan / 2.0) + t0;
+    double xs[NXs], us[NUs];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = x[ph.x_state0 + i * (N + 1) + k];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) us[j] = x[ph.x_control0 + j * N + k];
+    const double L0 = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+    s_wl += w * L0;
+    if (GRAD) {
+      const double wk = w * tspan / 2.0;                       // Weights*tspan/2.0, :1051
+      double dLt;
+      if constexpr (AN) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          grad[ph.x_state0 + i * (N + 1) + k] = wk * Prob::lagrange_grad_col(ph.phase_num, i, tk, xs, us, c);
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+          grad[ph.x_control0 + j * N + k] = wk * Prob::lagrange_grad_col(ph.phase_num, NX + j, tk, xs, us, c);
+        dLt = Prob::lagrange_grad_col(ph.phase_num, NX + NU, tk, xs, us, c);
+      } else {
+        // LpFDderive::DerivLagrange, LpFiniteDifferenceDerive.cpp:100-192
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const double b = xs[i], hh = K.tol * (1 + fabs(b));
+          xs[i] = b + hh;
+          const double Lp = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+          xs[i] = b;
+          grad[ph.x_state0 + i * (N + 1) + k] = wk * ((Lp - L0) / hh);
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          const double b = us[j], hh = K.tol * (1 + fabs(b));
+          us[j] = b + hh;
+          const double Lp = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+          us[j] = b;
+          grad[ph.x_control0 + j * N + k] = wk * ((Lp - L0) / hh);
+        }
+        const double ht = K.tol * (1 + fabs(tk));
+        dLt = (Prob::lagrange(ph.phase_num, tk + ht, xs, us, c) - L0) / ht;
+      }
+      s_t0 += ((w * (tspan / 2.0)) * dLt) * (tau * (-0.5) + 0.5);   // ret2*ret3, :1072-1077
+    }
+  }
+  red[0][tid] = s_wl;
+  red[1][tid] = s_t0;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (tid < s) {
+      red[0][tid] += red[0][tid + s];
+      red[1][tid] += red[1][tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double x0[NXs], xf[NXs];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      x0[i] = x[ph.x_state0 + i * (N + 1)];
+      xf[i] = x[ph.x_state0 + i * (N + 1) + N];
+    }
+    const double wl = red[0][0];
+    const double mayer = Prob::mayer(ph.phase_num, t0, x0, tf, xf, c);
+    // per-phase cost  Mayer + (w'L)(dt/2)  (:926-932); phases are summed in order by phase 0's thread below
+    partial[size_t(inst) * K.P + p] = mayer + wl * (tspan / 2.0);
+    if (GRAD) {
+      // Mayer derivative w.r.t. [x0.., t0, xf.., tf]  (LpFDderive::DerivMayer :11-98 or the analytic callback)
+      double dM[2 * NXs + 2];
+      if constexpr (AN) {
+        for (int q = 0; q < 2 * NX + 2; ++q) dM[q] = Prob::mayer_grad_col(ph.phase_num, q, t0, x0, tf, xf, c);
+      } else {
+        const double m0 = mayer;
+        const double h0 = K.tol * (1 + fabs(t0)), hf = K.tol * (1 + fabs(tf));
+        dM[NX] = (Prob::mayer(ph.phase_num, t0 + h0, x0, tf, xf, c) - m0) / h0;
+        dM[2 * NX + 1] = (Prob::mayer(ph.phase_num, t0, x0, tf + hf, xf, c) - m0) / hf;
+        for (int i = 0; i < NX; ++i) {
+          const double b0 = x0[i], hb0 = K.tol * (1 + fabs(b0));
+          x0[i] = b0 + hb0;
+          dM[i] = (Prob::mayer(ph.phase_num, t0, x0, tf, xf, c) - m0) / hb0;
+          x0[i] = b0;
+          const double bf = xf[i], hbf = K.tol * (1 + fabs(bf));
+          xf[i] = bf + hbf;
+          dM[NX + 1 + i] = (Prob::mayer(ph.phase_num, t0, x0, tf, xf, c) - m0) / hbf;
+          xf[i] = bf;
+        }
+      }
+      // terminal-state entries (:1054).  The initial-state Mayer entry is overwritten by the Lagrange
+      // run in the reference (:1050-1053) — kept, it is zero in every supported problem anyway.
+      for (int i = 0; i < NX; ++i) grad[ph.x_state0 + i * (N + 1) + N] = dM[NX + 1 + i];
+      // d/dt0 (:1069-1078) and d/dtf (:1081-1087, which keeps only node 0 of the dL/dt term)
+      grad[ph.x_t0] = (red[1][0] + dM[NX]) + (-0.5) * wl;
+      double dLt0;
+      {
+        double xs[NXs], us[NUs];
+        for (int i = 0; i < NX; ++i) xs[i] = x0[i];
+        for (int j = 0; j < NU; ++j) us[j] = x[ph.x_control0 + j * N];
+        const double tau = K.points[ph.node0];
+        const double tk = (tau + 1) * (tspan / 2.0) + t0;
+        if constexpr (AN) {
+          dLt0 = Prob::lagrange_grad_col(ph.phase_num, NX + NU, tk, xs, us, c);
+        } else {
+          const double ht = K.tol * (1 + fabs(tk));
+          dLt0 = (Prob::lagrange(ph.phase_num, tk + ht, xs, us, c) - Prob::lagrange(ph.phase_num, tk, xs, us, c)) / ht;
+        }
+        const double r2 = (K.weights[ph.node0] * (tspan / 2.0)) * dLt0;
+        grad[ph.x_t0 + 1] = (dM[2 * NX + 1] + 0.5 * wl) + (tau * 0.5 + 0.5) * r2;
+      }
+    }
+  }
+  (void)objall;
+}
+
+// sum the per-phase costs in phase order (GetObjFun's `cost +=` loop, :872-937)
+__global__ void rpm_obj_sum_kernel(int P, int B, const double* __restrict__ partial, double* __restrict__ obj) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= B) return;
+  double cost = 0.0;
+  for (int p = 0; p < P; ++p) cost += partial[size_t(inst) * P + p];
+  obj[inst] = cost;
+}
+
+// ------------------------------------------------------------------------------------------
+// problem registry
+template <class F>
+static bool with_problem(int id, F&& fn) {
+  switch (id) {
+    case RPM_PROBLEM_LAUNCH: fn(LaunchProblem{}); return true;
+    case RPM_PROBLEM_HYPERSENSITIVE: fn(HypersensitiveProblem{}); return true;
+    case RPM_PROBLEM_BRYSON_DENHAM: fn(BrysonDenhamProblem{}); return true;
+    case RPM_PROBLEM_BRACHISTOCHRONE: fn(BrachistochroneProblem{}); return true;
+    case RPM_PROBLEM_MIN_TIME_CLIMB: fn(MinTimeClimbProblem{}); return true;
+    case RPM_PROBLEM_QUADROTOR: fn(QuadrotorProblem{}); return true;
+  }
+  return false;
+}
+
+bool problem_dims(int id, ProblemDims* out) {
+  return with_problem(id, [&](auto prob) {
+    using P = decltype(prob);
+    *out = ProblemDims{P::NX, P::NU, P::NC, P::NE_MAX, P::NLINK_MAX, P::NCONST, P::HAS_ANALYTIC};
+  });
+}
+
+template <class T>
+static hipError_t upload(T** dst, const std::vector<T>& src) {
+  const size_t bytes = (src.size() ? src.size() : 1) * sizeof(T);
+  hipError_t s = hipMalloc(reinterpret_cast<void**>(dst), bytes);
+  if (s != hipSuccess) return s;
+  if (!src.empty()) s = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+  return s;
+}
+
+void device_destroy(Engine& e) {
+  Device* d = e.dev;
+  if (!d) return;
+  (void)hipSetDevice(d->device_id);
+  void* ptrs[] = {d->d_phases, d->d_tiles, d->d_tile_ids, d->d_tasks, d->d_nodes, d->d_points, d->d_weights, d->d_diag,
+                  d->d_dvals, d->d_doff, d->d_consts, d->d_alin_v, d->d_links, d->d_alin_j, d->d_x, d->d_g,
+                  d->d_values, d->d_grad, d->d_obj, d->d_lambda, d->d_hess, d->d_partial};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& row : d->segtab)
+    for (auto& t : row)
+      if (t.ptr) (void)hipFree(t.ptr);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  e.dev = nullptr;
+}
+
+static size_t tile_lds_doubles(const Engine& e, int NX, int NU, int NC) {
+  size_t n = size_t(NX) * e.max_span + size_t(NU) * e.tile_nodes + e.max_drow + size_t(NX + NC) * e.tile_nodes;
+  return n < 64 ? 64 : n;
+}
+
+int device_init(Engine& e, int device_id) {
+  if (e.dev) {
+    if (e.dev->device_id == device_id) return RPM_OK;
+    device_destroy(e);
+  }
+  int count = 0;
+  hipError_t s = hipGetDeviceCount(&count);
+  if (s != hipSuccess || count <= 0) {
+    e.err = "no HIP device available (this engine has no CPU fallback)";
+    return RPM_E_DEVICE;
+  }
+  if (device_id < 0 || device_id >= count) {
+    e.err = "device id out of range";
+    return RPM_E_DEVICE;
+  }
+  HIP_TRY(e, hipSetDevice(device_id));
+  Device* d = new Device();
+  e.dev = d;
+  d->device_id = device_id;
+  HIP_TRY(e, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  HIP_TRY(e, upload(&d->d_phases, e.phd));
+  HIP_TRY(e, upload(&d->d_tiles, e.tiles));
+  HIP_TRY(e, upload(&d->d_tile_ids, e.my_tiles));
+  HIP_TRY(e, upload(&d->d_tasks, e.tasks));
+  HIP_TRY(e, upload(&d->d_nodes, e.nodes));
+  HIP_TRY(e, upload(&d->d_points, e.points));
+  HIP_TRY(e, upload(&d->d_weights, e.weights));
+  HIP_TRY(e, upload(&d->d_diag, e.diag));
+  HIP_TRY(e, upload(&d->d_dvals, e.dvals));
+  HIP_TRY(e, upload(&d->d_doff, e.doff_vals));
+  HIP_TRY(e, upload(&d->d_consts, e.consts));
+  HIP_TRY(e, upload(&d->d_links, e.links));
+  HIP_TRY(e, upload(&d->d_alin_j, e.alin_j));
+  HIP_TRY(e, upload(&d->d_alin_v, e.alin_v));
+  const size_t B = size_t(e.n_instances);
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_x), B * e.n * sizeof(double)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_g), B * e.m * sizeof(double)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_values), B * size_t(e.nnz_jac) * sizeof(double)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_grad), B * e.n * sizeof(double)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_obj), B * sizeof(double)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_partial), B * e.P * sizeof(double)));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_lambda), B * e.m * sizeof(double)));
+  HIP_TRY(e, hipMemset(d->d_grad, 0, B * e.n * sizeof(double)));
+  KParams& k = d->kp;
+  k.phases = d->d_phases;
+  k.tiles = d->d_tiles;
+  k.tile_ids = d->d_tile_ids;
+  k.n_my_tiles = int(e.my_tiles.size());
+  k.nodes = d->d_nodes;
+  k.points = d->d_points;
+  k.weights = d->d_weights;
+  k.diag = d->d_diag;
+  k.dvals = d->d_dvals;
+  k.doff_vals = d->d_doff;
+  k.consts = d->d_consts;
+  k.links = d->d_links;
+  k.alin_j = d->d_alin_j;
+  k.alin_v = d->d_alin_v;
+  k.tol = e.fd_tol;
+  k.P = e.P;
+  k.L = e.L;
+  k.n = e.n;
+  k.m = e.m;
+  k.m_nl = e.m_nl;
+  k.nnz = e.nnz_jac;
+  k.nnz_nl = e.nnz_nl;
+  k.nnz_lin = e.nnz_lin;
+  k.nnz_const = e.nnz_const;
+  k.max_span = e.max_span;
+  k.max_drow = e.max_drow;
+  const bool sharded = e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1;
+  k.tasks = d->d_tasks;
+  k.n_tasks = (!sharded || e.shard_rank == 0) ? int(e.tasks.size()) : 0;  // rank 0 owns the endpoint rows
+  k.diag_mask = 0;
+#ifdef RPM_DIAG
+  if (const char* dm = getenv("RPM_DIAG_MASK")) k.diag_mask = atoi(dm);
+#endif
+  ProblemDims pd;
+  problem_dims(e.problem_id, &pd);
+  d->lds_bytes = tile_lds_doubles(e, pd.nx, pd.nu, pd.nc) * sizeof(double);
+  if (d->lds_bytes > 160 * 1024) {
+    e.err = "mesh interval too large for the LDS-staged D tile (reduce nodes per interval)";
+    return RPM_E_UNSUPPORTED;
+  }
+  return RPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+template <class Prob, int T, bool WG, bool WJ, bool AN>
+static hipError_t launch_tile_inst(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
+  constexpr int R = WJ ? Prob::NX + Prob::NU + 2 : (Prob::NX > 0 ? Prob::NX : 1);
+  int threads = T * R;
+  threads = (threads + 63) / 64 * 64;
+  if (threads < 64) threads = 64;
+  const Device& d = *e.dev;
+  auto kern = rpm_tile_kernel<Prob, T, WG, WJ, AN>;
+  if (d.lds_bytes > 64 * 1024) {
+    hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(d.lds_bytes));
+    if (s != hipSuccess) return s;
+  }
+  dim3 grid(unsigned(d.kp.n_my_tiles + d.kp.n_tasks), unsigned(e.n_instances));
+  hipLaunchKernelGGL(kern, grid, dim3(threads), d.lds_bytes, st, d.kp, dx, dg, dv);
+  return hipGetLastError();
+}
+
+template <class Prob, int T>
+static hipError_t launch_tile_T(const Engine& e, bool wg, bool wj, const double* dx, double* dg, double* dv,
+                                hipStream_t st) {
+  const bool an = e.first_derive == RPM_DERIVE_ANALYTIC;
+  if constexpr (Prob::HAS_ANALYTIC) {
+    if (an) {
+      if (wg && wj) return launch_tile_inst<Prob, T, true, true, true>(e, dx, dg, dv, st);
+      if (wj) return launch_tile_inst<Prob, T, false, true, true>(e, dx, dg, dv, st);
+    }
+  }
+  if (wg && wj) return launch_tile_inst<Prob, T, true, true, false>(e, dx, dg, dv, st);
+  if (wj) return launch_tile_inst<Prob, T, false, true, false>(e, dx, dg, dv, st);
+  return launch_tile_inst<Prob, T, true, false, false>(e, dx, dg, dv, st);
+}
+
+// flags: bit0 = g, bit1 = jacobian values
+int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, int flags, void* stream) {
+  if (!e.dev) {
+    int rc = device_init(e, 0);
+    if (rc) return rc;
+  }
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e.dev->stream;
+  const bool wg = flags & 1, wj = flags & 2;
+  hipError_t s = hipErrorInvalidValue;
+  with_problem(e.problem_id, [&](auto prob) {
+    using P = decltype(prob);
+    switch (e.tile_nodes) {
+      case 64: s = launch_tile_T<P, 64>(e, wg, wj, d_x, d_g, d_values, st); break;
+      case 32: s = launch_tile_T<P, 32>(e, wg, wj, d_x, d_g, d_values, st); break;
+      default: s = launch_tile_T<P, 16>(e, wg, wj, d_x, d_g, d_values, st); break;
+    }
+  });
+  if (s != hipSuccess) {
+    e.err = std::string("rpm_tile_kernel launch: ") + hipGetErrorString(s);
+    return RPM_E_DEVICE;
+  }
+  return RPM_OK;
+}
+
+int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream) {
+  if (!e.dev) {
+    int rc = device_init(e, 0);
+    if (rc) return rc;
+  }
+  Device& d = *e.dev;
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : d.stream;
+  const bool an = e.first_derive == RPM_DERIVE_ANALYTIC;
+  hipError_t s = hipSuccess;
+  with_problem(e.problem_id, [&](auto prob) {
+    using P = decltype(prob);
+    dim3 grid(unsigned(e.P), unsigned(e.n_instances));
+    if (d_grad) {
+      bool done = false;
+      if constexpr (P::HAS_ANALYTIC) {
+        if (an) {
+          hipLaunchKernelGGL((rpm_obj_kernel<P, true, true>), grid, dim3(256), 0, st, d.kp, d_x, d_obj, d_grad, d.d_partial);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((rpm_obj_kernel<P, true, false>), grid, dim3(256), 0, st, d.kp, d_x, d_obj, d_grad, d.d_partial);
+    } else {
+      hipLaunchKernelGGL((rpm_obj_kernel<P, false, false>), grid, dim3(256), 0, st, d.kp, d_x, d_obj, d_grad, d.d_partial);
+    }
+    s = hipGetLastError();
+  });
+  if (s == hipSuccess && d_obj) {
+    const int B = e.n_instances;
+    const int thr = B < 256 ? B : 256;
+    hipLaunchKernelGGL(rpm_obj_sum_kernel, dim3(unsigned((B + thr - 1) / thr)), dim3(unsigned(thr)), 0, st, e.P, B,
+                       d.d_partial, d_obj);
+    s = hipGetLastError();
+  }
+  if (s != hipSuccess) {
+    e.err = std::string("rpm_obj_kernel launch: ") + hipGetErrorString(s);
+    return RPM_E_DEVICE;
+  }
+  return RPM_OK;
+}
+
+// ---- small helpers used by the C ABI (rpm_abi.cpp) ---------------------------------------------
+int dev_upload_x(Engine& e, const double* x) {
+  if (!e.dev) {
+    int rc = device_init(e, 0);
+    if (rc) return rc;
+  }
+  HIP_TRY(e, hipSetDevice(e.dev->device_id));
+  HIP_TRY(e, hipMemcpyAsync(e.dev->d_x, x, size_t(e.n_instances) * e.n * sizeof(double), hipMemcpyHostToDevice,
+                            e.dev->stream));
+  return RPM_OK;
+}
+int dev_download(Engine& e, double* host, const double* dev, size_t count) {
+  HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e.dev->stream));
+  HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+  return RPM_OK;
+}
+int dev_upload(Engine& e, double* dev, const double* host, size_t count) {
+  HIP_TRY(e, hipMemcpyAsync(dev, host, count * sizeof(double), hipMemcpyHostToDevice, e.dev->stream));
+  return RPM_OK;
+}
+int dev_sync(Engine& e) {
+  if (!e.dev) return RPM_OK;
+  HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+  return RPM_OK;
+}
+double* dev_buf(Engine& e, int which) {
+  Device& d = *e.dev;
+  switch (which) {
+    case 0: return d.d_x;
+    case 1: return d.d_g;
+    case 2: return d.d_values;
+    case 3: return d.d_grad;
+    case 4: return d.d_obj;
+    case 5: return d.d_lambda;
+    case 6: return d.d_hess;
+  }
+  return nullptr;
+}
+bool& dev_cache_valid(Engine& e) { return e.dev->cache_valid; }
+
+// ---- interval sharding: pack a rank's runs / scatter the gathered runs of every rank -----------
+struct SegCopy { int src, dst, len, pad; };
+__global__ void rpm_seg_copy_kernel(const SegCopy* __restrict__ segs, const double* __restrict__ src,
+                                    double* __restrict__ dst) {
+  const SegCopy s = segs[blockIdx.x];
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < s.len; i += gridDim.y * blockDim.x)
+    dst[s.dst + i] = src[s.src + i];
+}
+
+int dev_shard_copy(Engine& e, int which, bool pack, const double* src, int stride, double* dst, void* stream) {
+  if (!e.dev) {
+    int rc = device_init(e, 0);
+    if (rc) return rc;
+  }
+  Device& d = *e.dev;
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : d.stream;
+  Device::SegTable& tab = d.segtab[which][pack ? 0 : 1];
+  if (!tab.ptr || tab.stride != stride) {   // built once per (vector, direction, stride)
+    std::vector<SegCopy> segs;
+    if (pack) {
+      for (const rpm_segment& s : shard_segments(e, which, e.shard_rank, nullptr)) segs.push_back(SegCopy{s.off, s.pos, s.len, 0});
+    } else {
+      for (int r = 0; r < e.shard_world; ++r)
+        for (const rpm_segment& s : shard_segments(e, which, r, nullptr)) segs.push_back(SegCopy{r * stride + s.pos, s.off, s.len, 0});
+    }
+    if (tab.ptr) HIP_TRY(e, hipFree(tab.ptr));
+    tab.ptr = nullptr;
+    tab.count = int(segs.size());
+    tab.stride = stride;
+    if (tab.count) {
+      HIP_TRY(e, hipMalloc(&tab.ptr, segs.size() * sizeof(SegCopy)));
+      HIP_TRY(e, hipMemcpy(tab.ptr, segs.data(), segs.size() * sizeof(SegCopy), hipMemcpyHostToDevice));
+    }
+  }
+  if (!tab.count) return RPM_OK;
+  hipLaunchKernelGGL(rpm_seg_copy_kernel, dim3(unsigned(tab.count), 4), dim3(256), 0, st,
+                     static_cast<const SegCopy*>(tab.ptr), src, dst);
+  HIP_TRY(e, hipGetLastError());
+  return RPM_OK;
+}
+
+}  // namespace rpm

@@ -1,0 +1,151 @@
+// rpm_engine.hpp — engine state shared by the host set-up code (rpm_setup.cpp), the C ABI
+// (rpm_abi.cpp) and the HIP side (rpm_device.hip).  Plain C++17, no HIP types here so the
+// set-up half builds and runs without a GPU.
+//
+// Reference counterparts (paths relative to /root/reference/Lpopc/src):
+//   PhaseHost  <- struct ps + struct indices, Core/LpCalculateData.hpp:29-41
+//   Engine     <- LpCalculateData, Core/LpCalculateData.hpp:43-111 (the per-mesh blackboard)
+#pragma once
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "../../include/rpm_hip.h"
+
+namespace rpm {
+
+// ---- device-visible POD tables (copied to HBM verbatim by rpm_device_init) ---------------
+struct PhaseDev {
+  int N, nx, nu, nc, ne;
+  int phase_num;     // 1-based, what the reference hands the user callbacks (LpNLPWrapper.cpp:107)
+  int x_state0;      // index of X(0,0) in x          (phase_indices[i]->state[0]-1)
+  int x_control0;    // index of U(0,0) in x
+  int x_t0;          // index of t0 in x; tf = x_t0+1
+  int g0;            // first constraint row of the phase
+  int v_nl0;         // offset of the phase's NL block in `values`
+  int v_evt0;        // offset of the phase's event entries in `values`
+  int node0;         // offset of the phase in the per-node tables
+  int doff_base;     // offset of the phase's Doffdiag values in doff_vals
+  int off_nnz;       // number of Doffdiag entries of the phase
+  int const_cum;     // offset of the phase inside the CONST block of `values`
+  int tile0, ntiles; // tiles of this phase (all ranks)
+};
+
+// One workgroup's share of a phase: a run of consecutive collocation nodes.
+// Everything a workgroup needs is in this one record (one scalar load burst, no dependent
+// second lookup of the phase table on the critical path).
+struct TileDev {
+  int phase;
+  int k0, cnt;       // nodes [k0, k0+cnt) of the phase
+  int span0, span_len;  // rows of the (N+1) x nx state matrix the tile's D rows touch
+  int drow0, drow_len;  // the tile's D rows inside dvals (row-major per node, contiguous)
+  // copied from the phase record
+  int N, phase_num, x_state0, x_control0, x_t0, g0, v_nl0, node0;
+  // this tile's share of the phase's constant Doffdiag block: source doff_vals[c_src0 .. +c_cnt),
+  // written to values[c_dst0 + i*c_stride + q], i = 0..c_copies-1 (one copy per state)
+  int c_src0, c_cnt, c_dst0, c_stride, c_copies;
+};
+
+// endpoint work items, one workgroup each: 0 = linear rows, 1 = events of phase idx, 2 = linkage pair idx
+struct TaskDev { int type, idx; };
+
+struct NodeDev {     // per collocation node
+  int drow_off;      // offset of the node's D row in dvals
+  int dcol0;         // first state-matrix row (= column of D) of that row
+  int dlen;          // N_k + 1
+  int interval;      // mesh interval index inside the phase
+};
+
+struct LinkDev {
+  int left, right;   // 0-based phases
+  int nlink;
+  int g0;            // first constraint row
+  int v0;            // offset of the pair's entries in `values`
+};
+
+// ---- host-side phase tables ----------------------------------------------------------
+struct PhaseHost {
+  int nx = 0, nu = 0, nq = 0, nc = 0, ne = 0, K = 0, N = 0;
+  std::vector<double> mesh;
+  std::vector<int> nk;
+  std::vector<double> points, weights;            // ps.Points / ps.Weights
+  std::vector<int> d_i, d_j;                       // ps.D triplets, reference order
+  std::vector<double> d_v;
+  std::vector<double> diag_v;                      // ps.Diag values (N)
+  std::vector<int> off_i, off_j;                   // ps.Doffdiag triplets
+  std::vector<double> off_v;
+  std::vector<double> drows;                       // D rows, row-major per node (device layout)
+  std::vector<NodeDev> nodes;
+  int var0 = 0, con0 = 0, nvar = 0, ncon = 0;
+};
+
+struct Device;  // HIP-side state, defined in rpm_device.hip
+
+struct Engine {
+  // description
+  int problem_id = 0, P = 0, L = 0;
+  std::vector<double> consts;
+  double fd_tol = 1e-6;
+  int first_derive = 0, hessian_mode = 0;
+  int n_instances = 1;
+  int shard_mode = 0, shard_rank = 0, shard_world = 1;
+  // per-mesh data
+  std::vector<PhaseHost> ph;
+  std::vector<LinkDev> links;
+  std::vector<std::vector<double>> link_min, link_max;
+  int n = 0, m_nl = 0, m = 0;
+  int nnz_nl = 0, nnz_lin = 0, nnz_const = 0, nnz_jac = 0, nnz_h = 0;
+  std::vector<double> xl, xu, gl, gu, guess;
+  std::vector<int> alin_i, alin_j;                // A_lin triplets (LpBoundsChecker.cpp:265-346)
+  std::vector<double> alin_v;
+  std::vector<int> jac_i, jac_j;                  // cached structure (NLPWrapper::GetConsSparsity)
+  std::vector<int> hes_i, hes_j;
+  // device tables (host copies)
+  std::vector<PhaseDev> phd;
+  std::vector<TileDev> tiles;                      // all tiles, phase-major
+  std::vector<int> my_tiles;                       // indices of the tiles this rank computes
+  std::vector<TaskDev> tasks;                      // endpoint work items (rank 0 of a sharded run)
+  std::vector<NodeDev> nodes;                      // all phases concatenated
+  std::vector<double> points, weights, diag, dvals, doff_vals;
+  int tile_nodes = 16;
+  int max_span = 0, max_drow = 0;
+  // options
+  int opt_fuse_pair = 1, opt_dx_mode = 0, opt_tile_nodes = 0, opt_check_finite = 1, opt_const_once = 0;
+  // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
+  std::vector<double> sol_x, sol_lambda;
+  double sol_obj = 0.0;
+  bool has_solution = false;
+  // state
+  std::string err;
+  Device* dev = nullptr;
+};
+
+// rpm_setup.cpp
+int setup_engine(Engine& e, const rpm_problem_desc* d);  // returns RPM_* code, message in e.err
+void build_tiles(Engine& e, int tile_nodes);
+void lgr_points(int n, std::vector<double>& x, std::vector<double>& w);
+void colloc_d(const std::vector<double>& pts, std::vector<double>& D);  // (M-1) x M, column-major
+
+// rpm_shard.cpp: rank's contiguous runs of g (which=0) or of the Jacobian values (which=1)
+std::vector<rpm_segment> shard_segments(const Engine& e, int which, int rank, int* packed_len);
+int dev_shard_copy(Engine& e, int which, bool pack, const double* src, int stride, double* dst, void* stream);
+
+// problem registry (rpm_device.hip): static dimensions of a functor, for validation on the host
+struct ProblemDims { int nx, nu, nc, ne_max, nlink_max, nconst; bool has_analytic; };
+bool problem_dims(int problem_id, ProblemDims* out);
+
+// rpm_device.hip
+int device_init(Engine& e, int device_id);
+void device_destroy(Engine& e);
+// flags: bit0 = constraint vector g, bit1 = Jacobian values.  Pointers are device pointers.
+int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, int flags, void* stream);
+// objective (d_obj, one per instance) and, when d_grad != nullptr, its gradient
+int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream);
+int dev_upload_x(Engine& e, const double* x);
+int dev_upload(Engine& e, double* dev, const double* host, size_t count);
+int dev_download(Engine& e, double* host, const double* dev, size_t count);
+int dev_sync(Engine& e);
+double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 lambda, 6 hess
+bool& dev_cache_valid(Engine& e);
+
+}  // namespace rpm

@@ -1,0 +1,285 @@
+"""Python host side above the C ABI (include/rpm_hip.h): loads lpopc_amd/csrc/librpm_hip.so and
+exposes the engine with the reference's TNLP method names (Core/LpopcIpopt.h:33-82).
+
+There is no fallback of any kind: if the shared library is missing this module raises at
+import of `lib()`, and every evaluation fails loudly when no HIP device is usable.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+from .problem import LpopcException
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# RPM_HIP_LIB lets profiling sessions load the -DRPM_DIAG ablation build; it is never a different backend
+_SO = os.environ.get("RPM_HIP_LIB") or os.path.join(_HERE, "csrc", "librpm_hip.so")
+_LIB = None
+
+RPM_OK, RPM_E_INVALID, RPM_E_UNSUPPORTED, RPM_E_DEVICE, RPM_E_NONFINITE = 0, 1, 2, 3, 4
+
+# every symbol include/rpm_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "rpm_create", "rpm_destroy", "rpm_last_error", "rpm_device_init", "rpm_get_nlp_info",
+    "rpm_get_bounds_info", "rpm_get_starting_point", "rpm_eval_f", "rpm_eval_grad_f", "rpm_eval_g",
+    "rpm_eval_jac_g", "rpm_eval_h", "rpm_finalize_solution", "rpm_get_solution", "rpm_eval_g_dev",
+    "rpm_eval_jac_g_dev", "rpm_eval_pair_dev", "rpm_eval_f_dev", "rpm_eval_grad_f_dev", "rpm_eval_h_dev",
+    "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_get_phase_sizes", "rpm_get_phase_tables",
+    "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev",
+]
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc] + (["-B"] if force else []) + ["librpm_hip.so"]
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the engine has no CPU fallback)" % _SO)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7.  Importing torch first makes the
+    # loader resolve this library's libamdhip64.so.7 dependency to the copy torch already mapped; loading in
+    # the other order leaves two runtimes in the process and torch then reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(_SO)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.rpm_create.argtypes = [C.POINTER(_abi.rpm_problem_desc), C.POINTER(vp)]
+    L.rpm_destroy.argtypes = [vp]
+    L.rpm_destroy.restype = None
+    L.rpm_last_error.argtypes = [vp]
+    L.rpm_last_error.restype = C.c_char_p
+    L.rpm_device_init.argtypes = [vp, C.c_int]
+    L.rpm_get_nlp_info.argtypes = [vp, ip, ip, ip, ip, ip]
+    L.rpm_get_bounds_info.argtypes = [vp, C.c_int, dp, dp, C.c_int, dp, dp]
+    L.rpm_get_starting_point.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int, dp, dp, C.c_int, C.c_int, dp]
+    L.rpm_eval_f.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    L.rpm_eval_grad_f.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    L.rpm_eval_g.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, dp]
+    L.rpm_eval_jac_g.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_int, ip, ip, dp]
+    L.rpm_eval_h.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp, C.c_int, C.c_int, ip, ip, dp]
+    L.rpm_finalize_solution.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, C.c_double]
+    L.rpm_get_solution.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
+    L.rpm_eval_g_dev.argtypes = [vp, vp, vp, vp]
+    L.rpm_eval_jac_g_dev.argtypes = [vp, vp, vp, vp]
+    L.rpm_eval_pair_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.rpm_eval_f_dev.argtypes = [vp, vp, vp, vp]
+    L.rpm_eval_grad_f_dev.argtypes = [vp, vp, vp, vp]
+    L.rpm_eval_h_dev.argtypes = [vp, vp, C.c_double, vp, vp, vp]
+    L.rpm_synchronize.argtypes = [vp]
+    L.rpm_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.rpm_get_option.argtypes = [vp, C.c_char_p, ip]
+    L.rpm_get_phase_sizes.argtypes = [vp, C.c_int, ip, ip, ip]
+    L.rpm_get_phase_tables.argtypes = [vp, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
+    L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
+    L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class RpmError(LpopcException):
+    def __init__(self, code, msg):
+        super().__init__("rpm error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NLPEngine:
+    """One NLP (one mesh) on one GPU.  Method names and argument order follow LpopcIpopt
+    (Core/LpopcIpopt.h:33-82); host arrays are numpy float64, device arrays are torch CUDA
+    tensors (used only as HBM handles)."""
+
+    def __init__(self, problem, options=None, n_instances=1, shard_mode=0, shard_rank=0, shard_world=1,
+                 tile_nodes=0, device=None):
+        self._L = lib()
+        self._desc, self._keep = _abi.lower(problem, options, n_instances, shard_mode, shard_rank, shard_world)
+        h = C.c_void_p()
+        rc = self._L.rpm_create(C.byref(self._desc), C.byref(h))
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_last_error(None).decode())
+        self._h = h
+        if tile_nodes:
+            self.set_option("tile_nodes", tile_nodes)
+        n, m, nj, nh, st = (C.c_int() for _ in range(5))
+        self._check(self._L.rpm_get_nlp_info(h, C.byref(n), C.byref(m), C.byref(nj), C.byref(nh), C.byref(st)))
+        self.n, self.m, self.nnz_jac, self.nnz_h, self.index_style = n.value, m.value, nj.value, nh.value, st.value
+        self.n_instances = n_instances
+        self.n_phases = problem.GetPhaseNum()
+        if device is not None:
+            self.device_init(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rpm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_last_error(self._h).decode())
+
+    def device_init(self, device_id=0):
+        self._check(self._L.rpm_device_init(self._h, int(device_id)))
+
+    def set_option(self, key, value):
+        self._check(self._L.rpm_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int()
+        self._check(self._L.rpm_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # ---- TNLP surface, host buffers --------------------------------------------------------
+    def get_nlp_info(self):
+        return self.n, self.m, self.nnz_jac, self.nnz_h, self.index_style
+
+    def get_bounds_info(self):
+        xl, xu, gl, gu = np.zeros(self.n), np.zeros(self.n), np.zeros(self.m), np.zeros(self.m)
+        self._check(self._L.rpm_get_bounds_info(self._h, self.n, _dp(xl), _dp(xu), self.m, _dp(gl), _dp(gu)))
+        return xl, xu, gl, gu
+
+    def get_starting_point(self):
+        x = np.zeros(self.n)
+        self._check(self._L.rpm_get_starting_point(self._h, self.n, 1, _dp(x), 0, None, None, self.m, 0, None))
+        return x
+
+    def _x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        if x.size != self.n * self.n_instances:
+            raise RpmError(RPM_E_INVALID, "x has %d entries, expected %d" % (x.size, self.n * self.n_instances))
+        return x
+
+    def eval_f(self, x, new_x=True):
+        x = self._x(x)
+        out = np.zeros(self.n_instances)
+        self._check(self._L.rpm_eval_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
+        return out[0] if self.n_instances == 1 else out
+
+    def eval_grad_f(self, x, new_x=True):
+        x = self._x(x)
+        out = np.zeros(self.n * self.n_instances)
+        self._check(self._L.rpm_eval_grad_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
+        return out
+
+    def eval_g(self, x, new_x=True):
+        x = self._x(x)
+        out = np.zeros(self.m * self.n_instances)
+        self._check(self._L.rpm_eval_g(self._h, self.n, _dp(x), int(new_x), self.m, _dp(out)))
+        return out
+
+    def eval_jac_g_structure(self):
+        i, j = np.zeros(self.nnz_jac, dtype=np.int32), np.zeros(self.nnz_jac, dtype=np.int32)
+        self._check(self._L.rpm_eval_jac_g(self._h, self.n, None, 0, self.m, self.nnz_jac, _ip(i), _ip(j), None))
+        return i, j
+
+    def eval_jac_g(self, x, new_x=True):
+        x = self._x(x)
+        out = np.zeros(self.nnz_jac * self.n_instances)
+        self._check(self._L.rpm_eval_jac_g(self._h, self.n, _dp(x), int(new_x), self.m, self.nnz_jac, None, None, _dp(out)))
+        return out
+
+    def eval_h_structure(self):
+        i, j = np.zeros(self.nnz_h, dtype=np.int32), np.zeros(self.nnz_h, dtype=np.int32)
+        self._check(self._L.rpm_eval_h(self._h, self.n, None, 0, 1.0, self.m, None, 0, self.nnz_h, _ip(i), _ip(j), None))
+        return i, j
+
+    def eval_h(self, x, obj_factor, lam, new_x=True, new_lambda=True):
+        x = self._x(x)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        out = np.zeros(self.nnz_h * self.n_instances)
+        self._check(self._L.rpm_eval_h(self._h, self.n, _dp(x), int(new_x), float(obj_factor), self.m, _dp(lam),
+                                       int(new_lambda), self.nnz_h, None, None, _dp(out)))
+        return out
+
+    def finalize_solution(self, status, x, lam, obj_value):
+        x = self._x(x)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        self._check(self._L.rpm_finalize_solution(self._h, int(status), self.n, _dp(x), None, None, self.m, None,
+                                                  _dp(lam), float(obj_value)))
+
+    def get_solution(self):
+        x, lam, obj = np.zeros(self.n), np.zeros(self.m), C.c_double()
+        self._check(self._L.rpm_get_solution(self._h, self.n, _dp(x), self.m, _dp(lam), C.byref(obj)))
+        return x, lam, obj.value
+
+    # ---- device-resident variants (torch CUDA tensors as HBM handles) -------------------------
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            import torch
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(stream)
+
+    def eval_g_dev(self, d_x, d_g, stream=None):
+        self._check(self._L.rpm_eval_g_dev(self._h, self._ptr(d_x), self._ptr(d_g), self._stream(stream)))
+
+    def eval_jac_g_dev(self, d_x, d_values, stream=None):
+        self._check(self._L.rpm_eval_jac_g_dev(self._h, self._ptr(d_x), self._ptr(d_values), self._stream(stream)))
+
+    def eval_pair_dev(self, d_x, d_g, d_values, stream=None):
+        self._check(self._L.rpm_eval_pair_dev(self._h, self._ptr(d_x), self._ptr(d_g), self._ptr(d_values),
+                                              self._stream(stream)))
+
+    def eval_f_dev(self, d_x, d_obj, stream=None):
+        self._check(self._L.rpm_eval_f_dev(self._h, self._ptr(d_x), self._ptr(d_obj), self._stream(stream)))
+
+    def eval_grad_f_dev(self, d_x, d_grad, stream=None):
+        self._check(self._L.rpm_eval_grad_f_dev(self._h, self._ptr(d_x), self._ptr(d_grad), self._stream(stream)))
+
+    def synchronize(self):
+        self._check(self._L.rpm_synchronize(self._h))
+
+    # ---- tables and sharding ---------------------------------------------------------------
+    def phase_tables(self, phase):
+        N, dn, on = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._L.rpm_get_phase_sizes(self._h, phase, C.byref(N), C.byref(dn), C.byref(on)))
+        N, dn, on = N.value, dn.value, on.value
+        t = dict(points=np.zeros(N), weights=np.zeros(N), d_rows=np.zeros(dn, dtype=np.int32),
+                 d_cols=np.zeros(dn, dtype=np.int32), d_vals=np.zeros(dn), diag_vals=np.zeros(N),
+                 doff_rows=np.zeros(on, dtype=np.int32), doff_cols=np.zeros(on, dtype=np.int32),
+                 doff_vals=np.zeros(on))
+        self._check(self._L.rpm_get_phase_tables(self._h, phase, _dp(t["points"]), _dp(t["weights"]),
+                                                 _ip(t["d_rows"]), _ip(t["d_cols"]), _dp(t["d_vals"]),
+                                                 _dp(t["diag_vals"]), _ip(t["doff_rows"]), _ip(t["doff_cols"]),
+                                                 _dp(t["doff_vals"])))
+        return t
+
+    def shard_segments(self, which, rank):
+        ns, pl = C.c_int(0), C.c_int(0)
+        self._check(self._L.rpm_shard_segments(self._h, which, rank, None, C.byref(ns), C.byref(pl)))
+        segs = (_abi.rpm_segment * max(ns.value, 1))()
+        self._check(self._L.rpm_shard_segments(self._h, which, rank, segs, C.byref(ns), C.byref(pl)))
+        return [(segs[i].off, segs[i].len, segs[i].pos) for i in range(ns.value)], pl.value
+
+    def shard_pack_dev(self, which, d_full, d_packed, stream=None):
+        self._check(self._L.rpm_shard_pack_dev(self._h, which, self._ptr(d_full), self._ptr(d_packed),
+                                               self._stream(stream)))
+
+    def shard_unpack_dev(self, which, d_gathered, stride, d_full, stream=None):
+        self._check(self._L.rpm_shard_unpack_dev(self._h, which, self._ptr(d_gathered), int(stride),
+                                                 self._ptr(d_full), self._stream(stream)))

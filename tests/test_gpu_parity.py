@@ -1,0 +1,181 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances (north_star: "within a stated floating-point tolerance"):
+  eval_g, eval_f             |d| <= 1e-12 * max(1,|ref|)   (libm differences exp/pow/acos only)
+  eval_jac_g finite diff.    |d| <= 1e-8  * max(1,|ref|)   (a 1-ulp difference in f divided by h ~ 1e-6)
+  eval_jac_g analytic, constant and linear entries          bit-exact / 1e-12
+"""
+import numpy as np
+import pytest
+
+from lpopc_amd import problems
+from lpopc_amd.engine import NLPEngine
+from lpopc_amd.problem import Options
+
+pytestmark = pytest.mark.gpu
+
+G_TOL, JFD_TOL, JAN_TOL = 1e-12, 1e-8, 1e-12
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def oracle_for(prob, opts=None):
+    from oracle.oracle import Oracle
+    return Oracle(prob, opts)
+
+
+CASES = [
+    ("brachistochrone", lambda: problems.brachistochrone(1, 10), "perturb"),
+    ("bryson_denham_default", lambda: problems.bryson_denham(), "perturb"),
+    ("launch_default_1x20", lambda: problems.launch(), "perturb"),
+    ("launch_ragged", lambda: _launch_ragged(), "perturb"),
+    ("climb_16x16", lambda: problems.min_time_climb(16, 16), "perturb"),
+    ("hypersensitive_hp", lambda: problems.config("hypersensitive"), "uniform"),
+    ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), "perturb"),
+    ("launch_metric_64x16", lambda: problems.launch(64, 16), "perturb"),
+]
+
+
+def _launch_ragged():
+    """Delta-III on ragged hp meshes: unequal widths, N_k from 2 to 23 (wider than a 16-node tile)."""
+    p = problems.launch()
+    meshes = [([-1, -0.6, 0.1, 1], [5, 23, 2]), ([-1, 0.5, 1], [16, 17]), ([-1, 1], [33]),
+              ([-1, -0.9, -0.5, 0.0, 0.25, 1], [3, 4, 7, 12, 16])]
+    for i, (mesh, nodes) in enumerate(meshes):
+        problems.set_mesh(p.GetPhase(i), mesh, nodes)
+    return p
+
+
+@pytest.mark.parametrize("name,make,mode", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("tile", [0, 16, 32, 64])
+def test_eval_g_and_jac_fd(built, name, make, mode, tile):
+    prob = make()
+    eng = NLPEngine(prob, tile_nodes=tile, device=0)
+    orc = oracle_for(prob)
+    xl, xu, _, _ = eng.get_bounds_info()
+    for seed in (3, 11):
+        x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, seed, mode)
+        g = eng.eval_g(x, True)
+        v = eng.eval_jac_g(x, False)      # served from the fused launch of eval_g
+        g_ref, v_ref = orc.eval_g(x), orc.eval_jac_g(x)
+        assert rel_err(g, g_ref) <= G_TOL
+        assert rel_err(v, v_ref) <= JFD_TOL
+        # the constant (Doffdiag) and linear blocks are copies: bit-exact
+        assert np.array_equal(v[-_n_const(eng):], v_ref[-_n_const(eng):])
+        # separate (unfused) kernels give the same numbers
+        eng.set_option("fuse_pair", 0)
+        assert np.array_equal(eng.eval_g(x, True), g)
+        assert np.array_equal(eng.eval_jac_g(x, True), v)
+        eng.set_option("fuse_pair", 1)
+    eng.close()
+
+
+def _n_const(eng):
+    tot = 0
+    for p in range(eng.n_phases):
+        tot += eng.phase_tables(p)["doff_vals"].size * _nx(eng, p)
+    return tot
+
+
+def _nx(eng, p):
+    return eng._desc.phases[p].nx
+
+
+@pytest.mark.parametrize("name,make", [("hypersensitive", lambda: problems.config("hypersensitive")),
+                                       ("brachistochrone", lambda: problems.brachistochrone(3, 7))])
+def test_analytic_mode(built, name, make):
+    prob = make()
+    opts = Options()
+    opts.SetStringValue("first-derive", "analytic")
+    eng = NLPEngine(prob, opts, device=0)
+    orc = oracle_for(prob, opts)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 5, "uniform")
+    assert rel_err(eng.eval_g(x), orc.eval_g(x)) <= G_TOL
+    assert rel_err(eng.eval_jac_g(x), orc.eval_jac_g(x)) <= JAN_TOL
+    assert abs(eng.eval_f(x) - orc.eval_f(x)) <= 1e-12 * max(1.0, abs(orc.eval_f(x)))
+    assert rel_err(eng.eval_grad_f(x), orc.eval_grad_f(x)) <= 1e-12
+    eng.close()
+
+
+@pytest.mark.parametrize("name,make,mode", CASES[:7], ids=[c[0] for c in CASES[:7]])
+def test_objective_and_gradient(built, name, make, mode):
+    prob = make()
+    eng = NLPEngine(prob, device=0)
+    orc = oracle_for(prob)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 7, mode)
+    f, f_ref = eng.eval_f(x), orc.eval_f(x)
+    assert abs(f - f_ref) <= 1e-12 * max(1.0, abs(f_ref))
+    assert rel_err(eng.eval_grad_f(x), orc.eval_grad_f(x)) <= 1e-8
+    eng.close()
+
+
+def test_jacobian_matches_central_differences_of_eval_g(built):
+    """Oracle-free check: J(x) dx ~ (g(x+e dx) - g(x-e dx)) / 2e along random directions."""
+    import scipy.sparse as sp
+    prob = problems.launch(3, 6)
+    eng = NLPEngine(prob, device=0)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 9)
+    i, j = eng.eval_jac_g_structure()
+    J = sp.coo_matrix((eng.eval_jac_g(x), (i, j)), shape=(eng.m, eng.n)).tocsr()
+    rng = np.random.RandomState(0)
+    for _ in range(3):
+        dx = rng.uniform(-1, 1, eng.n)
+        e = 1e-6
+        fd = (eng.eval_g(x + e * dx) - eng.eval_g(x - e * dx)) / (2 * e)
+        assert np.max(np.abs(J @ dx - fd)) <= 2e-4 * max(1.0, np.max(np.abs(fd)))  # forward-difference truncation O(h f")
+    eng.close()
+
+
+def test_batched_instances(built):
+    """MPC sweep: B structurally identical instances in one launch == B single evaluations."""
+    import torch
+    B = 37
+    prob = problems.quadrotor(8, 8)
+    one = NLPEngine(prob, device=0)
+    many = NLPEngine(prob, n_instances=B, device=0)
+    xl, xu, _, _ = one.get_bounds_info()
+    xs = np.stack([problems.seeded_iterate(one.get_starting_point(), xl, xu, 5 + b) for b in range(B)])
+    dx = torch.from_numpy(xs).cuda()
+    dg = torch.empty((B, one.m), dtype=torch.float64, device="cuda")
+    dv = torch.empty((B, one.nnz_jac), dtype=torch.float64, device="cuda")
+    many.eval_pair_dev(dx, dg, dv)
+    torch.cuda.synchronize()
+    for b in (0, 1, B // 2, B - 1):
+        assert np.array_equal(dg[b].cpu().numpy(), one.eval_g(xs[b]))
+        assert np.array_equal(dv[b].cpu().numpy(), one.eval_jac_g(xs[b], False))
+    f = many.eval_f(xs)
+    assert f.shape == (B,) and abs(f[3] - one.eval_f(xs[3])) == 0.0
+    one.close()
+    many.close()
+
+
+def test_full_size_properties(built):
+    """Metric config (4 x 64 x 16): size-independent properties — determinism, linearity of the
+    D.X part in the states, structure/value consistency."""
+    prob = problems.launch(64, 16)
+    eng = NLPEngine(prob, device=0)
+    assert (eng.n, eng.m, eng.nnz_jac) == (40996, 32801, 852356)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 3)
+    g1, v1 = eng.eval_g(x), eng.eval_jac_g(x, False)
+    g2, v2 = eng.eval_g(x), eng.eval_jac_g(x, False)
+    assert np.array_equal(g1, g2) and np.array_equal(v1, v2)          # deterministic
+    assert np.all(np.isfinite(g1)) and np.all(np.isfinite(v1))
+    i, j = eng.eval_jac_g_structure()
+    assert len(set(zip(i.tolist(), j.tolist()))) == eng.nnz_jac          # no duplicate (i,j) entries
+    eng.close()
+
+
+def test_nonfinite_is_reported(built):
+    prob = problems.launch(2, 4)
+    eng = NLPEngine(prob, device=0)
+    x = eng.get_starting_point()
+    x[0] = np.nan
+    with pytest.raises(Exception) as ei:
+        eng.eval_g(x)
+    assert "non-finite" in str(ei.value)
+    eng.close()
