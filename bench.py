@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-nodes", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="NLP iterates evaluated per launch (independent instances of the same problem)")
     ap.add_argument("--intervals", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=16)
     args = ap.parse_args()
@@ -95,11 +97,15 @@ def main():
 
     prob = problems.launch(args.intervals, args.nodes)
     sharded = args.shard == "intervals" and world > 1
-    eng = NLPEngine(prob, shard_mode=1 if sharded else 0, shard_rank=rank if sharded else 0,
+    B = max(1, args.batch)
+    if sharded and B != 1:
+        raise SystemExit("--shard intervals evaluates one iterate per launch")
+    eng = NLPEngine(prob, n_instances=B, shard_mode=1 if sharded else 0, shard_rank=rank if sharded else 0,
                     shard_world=world if sharded else 1, tile_nodes=args.tile_nodes, device=local_rank)
     xl, xu, _, _ = eng.get_bounds_info()
     x0 = eng.get_starting_point()
-    R = args.iterates
+    R = max(args.iterates, 2 * B)
+    R -= R % B
     # rank-specific iterates in the weak-scaling mode, identical ones when one problem is sharded
     seed0 = 3 if sharded else 3 + 1000 * rank
     xs = [problems.seeded_iterate(x0, xl, xu, seed0 + r) for r in range(R)]
@@ -112,7 +118,7 @@ def main():
         comm = IntervalGather(eng, dist, world)
 
     def step(k):
-        r = k % R
+        r = (k * B) % R          # this step's batch of B consecutive resident iterates
         if args.unfused:
             eng.eval_g_dev(d_x[r], d_g[r])
             eng.eval_jac_g_dev(d_x[r], d_v[r])
@@ -166,21 +172,24 @@ def main():
         elapsed, dev_ms = float(t[0]), float(t[1])
 
     # sanity: results of the timed region are finite and equal to a fresh single evaluation
-    chk_g = torch.empty(eng.m, dtype=torch.float64, device="cuda")
-    chk_v = torch.empty(eng.nnz_jac, dtype=torch.float64, device="cuda")
     if comm is None and not os.environ.get("RPM_DIAG_MASK"):
-        eng.eval_pair_dev(d_x[1 % R], chk_g, chk_v)
-        torch.cuda.synchronize()
-        assert torch.equal(chk_g, d_g[1 % R]) and torch.equal(chk_v, d_v[1 % R]) and bool(torch.isfinite(chk_v).all())
+        one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
+        chk_g = torch.empty(eng.m, dtype=torch.float64, device="cuda")
+        chk_v = torch.empty(eng.nnz_jac, dtype=torch.float64, device="cuda")
+        for r in (0, R - 1):
+            one.eval_pair_dev(d_x[r], chk_g, chk_v)
+            torch.cuda.synchronize()
+            assert torch.equal(chk_g, d_g[r]) and torch.equal(chk_v, d_v[r]) and bool(torch.isfinite(chk_v).all())
+        one.close()
 
     if rank == 0:
-        units_per_step = 1 if sharded else world
+        units_per_step = B * (1 if sharded else world)
         pairs = args.steps * units_per_step
         value = pairs / elapsed
-        B = algorithmic_bytes(eng)
+        bytes_per_launch = algorithmic_bytes(eng) * B
         launches_per_step = 2 if args.unfused else 1
         launch_us = dev_ms * 1e3 / (args.steps * launches_per_step)
-        achieved = B / (dev_ms * 1e-3 / args.steps) / 1e9
+        achieved = bytes_per_launch / (dev_ms * 1e-3 / args.steps) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
@@ -203,8 +212,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "Delta-III 4-phase launch ascent, %d intervals/phase x %d LGR points (n=%d, m=%d, nnz_jac=%d), "
-                            "first-derive=finite-difference tol=1e-6, %d seeded iterates resident in HBM"
-                            % (args.intervals, args.nodes, eng.n, eng.m, eng.nnz_jac, R),
+                            "first-derive=finite-difference tol=1e-6, %d seeded iterates resident in HBM, %d iterate(s) per step"
+                            % (args.intervals, args.nodes, eng.n, eng.m, eng.nnz_jac, R, B),
                 "pair": "unfused: eval_g kernel + eval_jac_g kernel" if args.unfused else
                         "fused: one rpm_tile_kernel launch writes g and all Jacobian values of x_k",
                 "launch": "hipGraph replay of the K steps" if graph is not None else "eager launches",
@@ -216,24 +225,25 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "rpm_tile_kernel", "algorithmic_bytes_per_launch": B,
+                "kernel": "rpm_tile_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,
+                "algorithmic_bytes_per_pair": bytes_per_launch // B,
                 "avg_launch_us": launch_us,
             },
         }
         # synthetic "ms per IPOPT iteration": one each of eval_f, eval_grad_f, eval_g, eval_jac_g at one x
-        d_obj = torch.empty(1, dtype=torch.float64, device="cuda")
-        d_grad = torch.empty(eng.n, dtype=torch.float64, device="cuda")
+        d_obj = torch.empty(B, dtype=torch.float64, device="cuda")
+        d_grad = torch.empty((B, eng.n), dtype=torch.float64, device="cuda")
         if comm is None:
             torch.cuda.synchronize()
             ti = time.perf_counter()
             nit = 200
             for k in range(nit):
-                r = k % R
+                r = (k * B) % R
                 eng.eval_f_dev(d_x[r], d_obj)
                 eng.eval_grad_f_dev(d_x[r], d_grad)
                 eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
             torch.cuda.synchronize()
-            out["config"]["ms_per_ipopt_iter_synthetic"] = (time.perf_counter() - ti) * 1e3 / nit
+            out["config"]["ms_per_ipopt_iter_synthetic"] = (time.perf_counter() - ti) * 1e3 / (nit * B)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, xs, args.cpu_seconds)
         else:

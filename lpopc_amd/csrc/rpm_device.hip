@@ -34,8 +34,7 @@ namespace rpm {
 // ------------------------------------------------------------------------------------------
 struct KParams {
   const PhaseDev* phases;
-  const TileDev* tiles;
-  const int* tile_ids;   // tiles owned by this rank
+  const TileDev* tiles;  // the tiles this rank computes, compact
   int n_my_tiles;
   const TaskDev* tasks;  // endpoint work items, one extra workgroup each
   int n_tasks;
@@ -62,7 +61,6 @@ struct Device {
   // tables
   PhaseDev* d_phases = nullptr;
   TileDev* d_tiles = nullptr;
-  int* d_tile_ids = nullptr;
   TaskDev* d_tasks = nullptr;
   NodeDev* d_nodes = nullptr;
   double *d_points = nullptr, *d_weights = nullptr, *d_diag = nullptr, *d_dvals = nullptr,
@@ -243,13 +241,32 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
     endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
     return;
   }
-  const TileDev tl = K.tiles[K.tile_ids[blockIdx.x]];
+  const TileDev tl = K.tiles[blockIdx.x];
   const TileDev& ph = tl;   // the phase fields the kernel needs are replicated in the tile record
   const double* __restrict__ c = K.consts;
   double* Xs = lds;                          // [NX][max_span]  state-matrix rows the tile's D rows touch
   double* Us = Xs + NX * K.max_span;         // [NU][T]
   double* Ds = Us + NU * T;                  // the tile's D rows, row-major per node
   double* Fb = Ds + K.max_drow;              // [NO][T] unperturbed f and c
+
+  // ---- issue the loads nothing depends on first: this thread's node record and its share of the
+  //      constant-block sources (stored at the very end) ----
+  const int kk = tid % T, role = tid / T;
+  const int kc = kk < tl.cnt ? kk : tl.cnt - 1;   // clamp so idle lanes read valid memory
+  const int k = tl.k0 + kc;
+  const int nidx = ph.node0 + k;
+  const double tau = K.points[nidx];
+  const NodeDev nd = K.nodes[nidx];
+  const double ddiag = WJ ? K.diag[nidx] : 0.0;
+  constexpr int CPRE = 8;                          // constant-block sources prefetched per thread
+  double cpre[CPRE];
+  if (WJ) {
+#pragma unroll
+    for (int u = 0; u < CPRE; ++u) {
+      const int q = tid + u * nthr;
+      cpre[u] = q < tl.c_cnt ? K.doff_vals[tl.c_src0 + q] : 0.0;
+    }
+  }
 
   // ---- stage X tile, U tile and D rows in LDS (coalesced: every run below is contiguous in HBM) ----
   for (int q = tid; q < NX * tl.span_len; q += nthr) {
@@ -268,15 +285,9 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
 #ifdef RPM_DIAG
   if (K.diag_mask & 16) return;
 #endif
-  const int kk = tid % T, role = tid / T;
   const bool act = kk < tl.cnt && role < R;
-  const int kc = kk < tl.cnt ? kk : tl.cnt - 1;   // clamp so idle lanes read valid LDS
-  const int k = tl.k0 + kc;
-  const int nidx = ph.node0 + k;
-  const double tau = K.points[nidx];
   const double tspan = tf - t0;
   double tk = (tau + 1) * (tspan / 2.0) + t0;      // LpNLPWrapper.cpp:80
-  const NodeDev nd = K.nodes[nidx];
   double xs[NX > 0 ? NX : 1], us[NU > 0 ? NU : 1];
 #pragma unroll
   for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - tl.span0)];
@@ -350,7 +361,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
           double val;
           if (o < NX) {
             const double ret = J[o] * (tf - t0) / 2.0;
-            val = (o == v) ? K.diag[nidx] - ret : -ret;          // Ddiag - ret on the diagonal block, :712
+            val = (o == v) ? ddiag - ret : -ret;          // Ddiag - ret on the diagonal block, :712
           } else {
             val = J[o];
           }
@@ -387,7 +398,15 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   if (WJ) {
     const double* __restrict__ src = K.doff_vals + tl.c_src0;
     double* __restrict__ dst = vals + tl.c_dst0;
-    for (int q = tid; q < tl.c_cnt; q += nthr) {
+#pragma unroll
+    for (int u = 0; u < CPRE; ++u) {
+      const int q = tid + u * nthr;
+      if (q < tl.c_cnt) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = cpre[u];
+      }
+    }
+    for (int q = tid + CPRE * nthr; q < tl.c_cnt; q += nthr) {
       const double dv = src[q];
 #pragma unroll
       for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = dv;
@@ -572,7 +591,7 @@ void device_destroy(Engine& e) {
   Device* d = e.dev;
   if (!d) return;
   (void)hipSetDevice(d->device_id);
-  void* ptrs[] = {d->d_phases, d->d_tiles, d->d_tile_ids, d->d_tasks, d->d_nodes, d->d_points, d->d_weights, d->d_diag,
+  void* ptrs[] = {d->d_phases, d->d_tiles, d->d_tasks, d->d_nodes, d->d_points, d->d_weights, d->d_diag,
                   d->d_dvals, d->d_doff, d->d_consts, d->d_alin_v, d->d_links, d->d_alin_j, d->d_x, d->d_g,
                   d->d_values, d->d_grad, d->d_obj, d->d_lambda, d->d_hess, d->d_partial};
   for (void* p : ptrs)
@@ -611,8 +630,11 @@ int device_init(Engine& e, int device_id) {
   d->device_id = device_id;
   HIP_TRY(e, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   HIP_TRY(e, upload(&d->d_phases, e.phd));
-  HIP_TRY(e, upload(&d->d_tiles, e.tiles));
-  HIP_TRY(e, upload(&d->d_tile_ids, e.my_tiles));
+  {
+    std::vector<TileDev> mine;
+    for (int id : e.my_tiles) mine.push_back(e.tiles[id]);
+    HIP_TRY(e, upload(&d->d_tiles, mine));
+  }
   HIP_TRY(e, upload(&d->d_tasks, e.tasks));
   HIP_TRY(e, upload(&d->d_nodes, e.nodes));
   HIP_TRY(e, upload(&d->d_points, e.points));
@@ -636,7 +658,6 @@ int device_init(Engine& e, int device_id) {
   KParams& k = d->kp;
   k.phases = d->d_phases;
   k.tiles = d->d_tiles;
-  k.tile_ids = d->d_tile_ids;
   k.n_my_tiles = int(e.my_tiles.size());
   k.nodes = d->d_nodes;
   k.points = d->d_points;
