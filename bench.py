@@ -61,16 +61,17 @@ def cpu_baseline(prob, xs, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--iterates", type=int, default=16, help="distinct NLP iterates resident in HBM")
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--iterates", type=int, default=64,
+                    help="distinct NLP iterates resident in HBM (64 x 7.1 MB of outputs > the 256 MiB Infinity Cache)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--unfused", action="store_true", help="separate eval_g and eval_jac_g kernels per step")
     ap.add_argument("--shard", choices=["instances", "intervals"], default="instances")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-nodes", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--batch", type=int, default=16,
                     help="NLP iterates evaluated per launch (independent instances of the same problem)")
     ap.add_argument("--intervals", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=16)
@@ -244,6 +245,28 @@ def main():
                 eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
             torch.cuda.synchronize()
             out["config"]["ms_per_ipopt_iter_synthetic"] = (time.perf_counter() - ti) * 1e3 / (nit * B)
+        if comm is None and B > 1:
+            # the same kernel with ONE iterate per launch (what a sequential Ipopt loop sees): latency-bound
+            one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g1 = torch.cuda.CUDAGraph()
+            for k in range(20):
+                one.eval_pair_dev(d_x[k % R], d_g[k % R], d_v[k % R])
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g1):
+                for k in range(256):
+                    one.eval_pair_dev(d_x[k % R], d_g[k % R], d_v[k % R])
+            g1.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            g1.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us1 = e0.elapsed_time(e1) * 1e3 / 256
+            out["config"]["single_iterate_per_launch"] = {
+                "pairs_per_s": 1e6 / us1, "launch_us": us1,
+                "hbm_frac": algorithmic_bytes(one) / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            one.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, xs, args.cpu_seconds)
         else:

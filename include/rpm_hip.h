@@ -159,8 +159,9 @@ int rpm_get_solution(rpm_engine* e, int n, double* x, int m, double* lambda, dou
 
 /* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
  *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
- *      engine's device; `stream` is a hipStream_t (NULL = the engine's own stream).
- *      Calls are asynchronous on that stream. ------------------------------------ */
+ *      engine's device; `stream` is a hipStream_t with HIP's own meaning (NULL = the legacy
+ *      default stream).  Calls are asynchronous on that stream; the host-pointer entry points
+ *      above use a private stream of the engine instead. ------------------------------- */
 int rpm_eval_g_dev(rpm_engine* e, const double* d_x, double* d_g, void* stream);
 int rpm_eval_jac_g_dev(rpm_engine* e, const double* d_x, double* d_values, void* stream);
 /* fused pair: one launch produces g and the Jacobian values of the same x */

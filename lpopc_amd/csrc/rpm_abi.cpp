@@ -140,7 +140,7 @@ int rpm_eval_f(rpm_engine* h, int n, const double* x, int new_x, double* obj_val
   int rc = stage_x(e, n, x, 1);
   (void)new_x;
   if (rc) return rc;
-  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), nullptr, nullptr);
+  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), nullptr, rpm::dev_stream(e));
   if (rc) return rc;
   rc = rpm::dev_download(e, obj_value, rpm::dev_buf(e, 4), size_t(e.n_instances));
   if (rc) return rc;
@@ -157,7 +157,7 @@ int rpm_eval_grad_f(rpm_engine* h, int n, const double* x, int new_x, double* gr
   int rc = stage_x(e, n, x, 1);
   (void)new_x;
   if (rc) return rc;
-  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), rpm::dev_buf(e, 3), nullptr);
+  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), rpm::dev_buf(e, 3), rpm::dev_stream(e));
   if (rc) return rc;
   rc = rpm::dev_download(e, grad_f, rpm::dev_buf(e, 3), size_t(e.n_instances) * e.n);
   if (rc) return rc;
@@ -177,7 +177,7 @@ int rpm_eval_g(rpm_engine* h, int n, const double* x, int new_x, int m, double* 
   (void)new_x;
   if (rc) return rc;
   const int flags = e.opt_fuse_pair ? 3 : 1;  // fused: the Jacobian of the same x is produced by the same launch
-  rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), flags, nullptr);
+  rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), flags, rpm::dev_stream(e));
   if (rc) return rc;
   rc = rpm::dev_download(e, g, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m);
   if (rc) return rc;
@@ -205,7 +205,7 @@ int rpm_eval_jac_g(rpm_engine* h, int n, const double* x, int new_x, int m, int 
   if (!cached) {
     rc = stage_x(e, n, x, 1);
     if (rc) return rc;
-    rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), 2, nullptr);
+    rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), 2, rpm::dev_stream(e));
     if (rc) return rc;
   }
   rc = rpm::dev_download(e, values, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac);

@@ -219,8 +219,13 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 }
 
 // ------------------------------------------------------------------------------------------
+#ifdef RPM_EXP_WAVES
+#define RPM_TILE_ATTR __attribute__((amdgpu_waves_per_eu(RPM_EXP_WAVES, 8)))
+#else
+#define RPM_TILE_ATTR
+#endif
 template <class Prob, int T, bool WG, bool WJ, bool AN>
-__global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
+__global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
                                 double* __restrict__ gall, double* __restrict__ vall) {
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
   constexpr int NO = NX + NC;              // outputs per node: f then c
@@ -241,8 +246,20 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
     endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
     return;
   }
-  const TileDev tl = K.tiles[blockIdx.x];
+  // XCD-aware tile order: workgroups b, b+8, b+16, ... are dealt to the same XCD, so give each XCD a
+  // contiguous run of tiles; neighbouring 128-byte pieces of every Jacobian block then meet in one L2
+  // and leave it as longer contiguous write-backs (speed only, correctness does not depend on placement)
+#ifndef RPM_EXP_NOXCD
+  const int nt = K.n_my_tiles, per = nt >> 3, rem = nt & 7, xcd = int(blockIdx.x) & 7, slot = int(blockIdx.x) >> 3;
+  const int tix = xcd * per + (xcd < rem ? xcd : rem) + slot;
+#else
+  const int tix = blockIdx.x;
+#endif
+  const TileDev tl = K.tiles[tix];
   const TileDev& ph = tl;   // the phase fields the kernel needs are replicated in the tile record
+#ifdef RPM_DIAG
+  if (K.diag_mask & 64) { if (tl.cnt < 0) vals[0] = 0; return; }
+#endif
   const double* __restrict__ c = K.consts;
   double* Xs = lds;                          // [NX][max_span]  state-matrix rows the tile's D rows touch
   double* Us = Xs + NX * K.max_span;         // [NU][T]
@@ -268,6 +285,9 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
     }
   }
 
+#ifdef RPM_DIAG
+  if (K.diag_mask & 128) { if (tau + cpre[0] + cpre[5] + ddiag + nd.dlen == 1e300) vals[0] = 0; return; }
+#endif
   // ---- stage X tile, U tile and D rows in LDS (coalesced: every run below is contiguous in HBM) ----
   for (int q = tid; q < NX * tl.span_len; q += nthr) {
     const int i = q / tl.span_len, r = q - i * tl.span_len;
@@ -280,6 +300,9 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   if (WG)
     for (int q = tid; q < tl.drow_len; q += nthr) Ds[q] = K.dvals[tl.drow0 + q];
   const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+#ifdef RPM_DIAG
+  if (K.diag_mask & 256) { if (t0 == 1e300) vals[0] = 0; return; }
+#endif
   __syncthreads();
 
 #ifdef RPM_DIAG
@@ -348,10 +371,17 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
 #endif
     if (WJ && role >= 1) {
       double J[NO];
+#ifdef RPM_EXP_RCP
+      const double rh = 1.0 / h;
+#endif
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
         const double pert = o < NX ? f[o < NX ? o : 0] : cp[o >= NX ? o - NX : 0];
+#ifdef RPM_EXP_RCP
+        J[o] = AN ? pert : (pert - Fb[o * T + kk]) * rh;
+#else
         J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
+#endif
       }
       double* vb = vals + ph.v_nl0 + k;
       if (v < NX + NU) {
@@ -738,7 +768,7 @@ int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, i
     int rc = device_init(e, 0);
     if (rc) return rc;
   }
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e.dev->stream;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   const bool wg = flags & 1, wj = flags & 2;
   hipError_t s = hipErrorInvalidValue;
   with_problem(e.problem_id, [&](auto prob) {
@@ -762,7 +792,7 @@ int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, vo
     if (rc) return rc;
   }
   Device& d = *e.dev;
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : d.stream;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   const bool an = e.first_derive == RPM_DERIVE_ANALYTIC;
   hipError_t s = hipSuccess;
   with_problem(e.problem_id, [&](auto prob) {
@@ -836,6 +866,7 @@ double* dev_buf(Engine& e, int which) {
   return nullptr;
 }
 bool& dev_cache_valid(Engine& e) { return e.dev->cache_valid; }
+void* dev_stream(Engine& e) { return e.dev->stream; }
 
 // ---- interval sharding: pack a rank's runs / scatter the gathered runs of every rank -----------
 struct SegCopy { int src, dst, len, pad; };
@@ -852,7 +883,7 @@ int dev_shard_copy(Engine& e, int which, bool pack, const double* src, int strid
     if (rc) return rc;
   }
   Device& d = *e.dev;
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : d.stream;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   Device::SegTable& tab = d.segtab[which][pack ? 0 : 1];
   if (!tab.ptr || tab.stride != stride) {   // built once per (vector, direction, stride)
     std::vector<SegCopy> segs;

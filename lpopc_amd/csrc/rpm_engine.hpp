@@ -147,5 +147,6 @@ int dev_download(Engine& e, double* host, const double* dev, size_t count);
 int dev_sync(Engine& e);
 double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 lambda, 6 hess
 bool& dev_cache_valid(Engine& e);
+void* dev_stream(Engine& e);            // the engine's own stream (host-pointer TNLP path)
 
 }  // namespace rpm

@@ -1,0 +1,58 @@
+"""Worker of tests/test_dist_gloo.py (world_size 2, gloo, CPU).  Exercises the interval-sharding
+partition / pack / all-gather / unpack logic of lpopc_amd.dist with the CPU oracle standing in for
+the per-rank device evaluation, and the max-over-ranks timing reduction bench.py uses."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lpopc_amd import problems  # noqa: E402
+from lpopc_amd.dist import pack_host, unpack_host  # noqa: E402
+from lpopc_amd.engine import NLPEngine  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    prob = problems.launch(6, 5)
+    eng = NLPEngine(prob, shard_mode=1, shard_rank=rank, shard_world=world)
+    orc = Oracle(prob)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 3)
+    full = {0: orc.eval_g(x), 1: orc.eval_jac_g(x)}
+    for which in (0, 1):
+        all_segs = [eng.shard_segments(which, r)[0] for r in range(world)]
+        stride = max(eng.shard_segments(which, r)[1] for r in range(world))
+        # what this rank's GPU would have produced: only its own runs are valid, the rest is poison
+        mine = np.full_like(full[which], np.nan)
+        for off, ln, _ in all_segs[rank]:
+            mine[off:off + ln] = full[which][off:off + ln]
+        send = np.zeros(stride)
+        packed = pack_host(mine, all_segs[rank])
+        send[:packed.size] = packed
+        recv = [torch.zeros(stride, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(recv, torch.from_numpy(send))
+        gathered = torch.cat(recv).numpy()
+        out = unpack_host(gathered, stride, all_segs, np.full_like(full[which], np.nan))
+        assert np.array_equal(out, full[which]), "gathered vector differs from the single-rank result"
+    # bench.py's timing reduction: MAX over ranks
+    t = torch.tensor([1.0 + rank, 10.0 - rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.tolist() == [float(world), 10.0]
+    # weak scaling (independent instances): rank-specific iterates, nothing to exchange but the count
+    cnt = torch.tensor([7.0])
+    dist.all_reduce(cnt)
+    assert cnt.item() == 7.0 * world
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

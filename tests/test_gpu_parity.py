@@ -179,3 +179,37 @@ def test_nonfinite_is_reported(built):
         eng.eval_g(x)
     assert "non-finite" in str(ei.value)
     eng.close()
+
+
+def test_interval_sharding_on_one_gpu(built):
+    """"Fake rank" mode: the shards of an 8-way interval sharding run one after another on one
+    GPU; packing each rank's runs, concatenating as an all-gather would and unpacking reproduces the
+    unsharded vectors bit for bit."""
+    import torch
+    prob = problems.launch(16, 8)
+    world = 8
+    ref = NLPEngine(prob, device=0)
+    xl, xu, _, _ = ref.get_bounds_info()
+    x = problems.seeded_iterate(ref.get_starting_point(), xl, xu, 3)
+    g_ref, v_ref = ref.eval_g(x), ref.eval_jac_g(x, False)
+    dx = torch.from_numpy(x).cuda()
+    engs = [NLPEngine(prob, shard_mode=1, shard_rank=r, shard_world=world, device=0) for r in range(world)]
+    stride = [max(engs[0].shard_segments(w, r)[1] for r in range(world)) for w in (0, 1)]
+    gathered = [torch.zeros(world * stride[w], dtype=torch.float64, device="cuda") for w in (0, 1)]
+    for r, e in enumerate(engs):
+        dg = torch.full((e.m,), float("nan"), dtype=torch.float64, device="cuda")
+        dv = torch.full((e.nnz_jac,), float("nan"), dtype=torch.float64, device="cuda")
+        e.eval_pair_dev(dx, dg, dv)
+        for w, full in ((0, dg), (1, dv)):
+            e.shard_pack_dev(w, full, gathered[w][r * stride[w]:(r + 1) * stride[w]])
+    out_g = torch.full((ref.m,), float("nan"), dtype=torch.float64, device="cuda")
+    out_v = torch.full((ref.nnz_jac,), float("nan"), dtype=torch.float64, device="cuda")
+    engs[3].shard_unpack_dev(0, gathered[0], stride[0], out_g)
+    engs[3].shard_unpack_dev(1, gathered[1], stride[1], out_v)
+    torch.cuda.synchronize()
+    og, ov = out_g.cpu().numpy(), out_v.cpu().numpy()
+    bad_g, bad_v = np.flatnonzero(~(og == g_ref)), np.flatnonzero(~(ov == v_ref))
+    assert bad_g.size == 0, (bad_g[:10], bad_g.size)
+    assert bad_v.size == 0, (bad_v[:10], bad_v.size, ref.nnz_jac, ov[bad_v[:6]], v_ref[bad_v[:6]], np.unique(bad_v // 128)[:40])
+    for e in engs + [ref]:
+        e.close()
