@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--shard", choices=["instances", "intervals"], default="instances")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="profiling run: only the warm-up and the timed launches (no extra checks/sections), so that\n"
+                         "rocprofv3 --stats averages exactly the launches bench.py times")
     ap.add_argument("--tile-nodes", type=int, default=0)
     ap.add_argument("--batch", type=int, default=16,
                     help="NLP iterates evaluated per launch (independent instances of the same problem)")
@@ -173,7 +176,7 @@ def main():
         elapsed, dev_ms = float(t[0]), float(t[1])
 
     # sanity: results of the timed region are finite and equal to a fresh single evaluation
-    if comm is None and not os.environ.get("RPM_DIAG_MASK"):
+    if comm is None and not os.environ.get("RPM_DIAG_MASK") and not args.profile:
         one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
         chk_g = torch.empty(eng.m, dtype=torch.float64, device="cuda")
         chk_v = torch.empty(eng.nnz_jac, dtype=torch.float64, device="cuda")
@@ -192,8 +195,10 @@ def main():
         launch_us = dev_ms * 1e3 / (args.steps * launches_per_step)
         achieved = bytes_per_launch / (dev_ms * 1e-3 / args.steps) / 1e9
         traffic = None
+        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this
+        # exact command, committed under profiles/ (tools/collect_profiles.sh regenerates it)
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and B == 16 and not args.unfused and args.intervals == 64 and args.nodes == 16:
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
@@ -234,7 +239,7 @@ def main():
         # synthetic "ms per IPOPT iteration": one each of eval_f, eval_grad_f, eval_g, eval_jac_g at one x
         d_obj = torch.empty(B, dtype=torch.float64, device="cuda")
         d_grad = torch.empty((B, eng.n), dtype=torch.float64, device="cuda")
-        if comm is None:
+        if comm is None and not args.profile:
             torch.cuda.synchronize()
             ti = time.perf_counter()
             nit = 200
@@ -245,7 +250,7 @@ def main():
                 eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
             torch.cuda.synchronize()
             out["config"]["ms_per_ipopt_iter_synthetic"] = (time.perf_counter() - ti) * 1e3 / (nit * B)
-        if comm is None and B > 1:
+        if comm is None and B > 1 and not args.profile:
             # the same kernel with ONE iterate per launch (what a sequential Ipopt loop sees): latency-bound
             one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -267,7 +272,7 @@ def main():
                 "pairs_per_s": 1e6 / us1, "launch_us": us1,
                 "hbm_frac": algorithmic_bytes(one) / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
             one.close()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.profile:
             out["cpu_baseline"] = cpu_baseline(prob, xs, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None

@@ -1,0 +1,71 @@
+// RpmTNLP.hpp — the adaptor that takes LpopcIpopt's place (Core/LpopcIpopt.h:18-104): an
+// Ipopt::TNLP subclass whose eight virtuals forward to the C ABI of librpm_hip.so.
+//
+// It is a template over the TNLP base so that it can be compiled (and unit-tested) without
+// Ipopt's headers; with Ipopt available use
+//     #include <IpTNLP.hpp>
+//     using RpmTNLP = lpopc_amd::RpmTNLPT<Ipopt::TNLP>;
+// `Base` must provide the typedefs Index, Number, IndexStyleEnum (with C_STYLE), SolverReturn and the
+// forward declarations IpoptData / IpoptCalculatedQuantities used by finalize_solution, exactly as
+// Ipopt::TNLP does.
+#pragma once
+#include <string>
+
+#include "../rpm_hip.h"
+
+namespace lpopc_amd {
+
+template <class Base>
+class RpmTNLPT : public Base {
+ public:
+  using Index = typename Base::Index;
+  using Number = typename Base::Number;
+  using IndexStyleEnum = typename Base::IndexStyleEnum;
+  using SolverReturn = typename Base::SolverReturn;
+
+  explicit RpmTNLPT(rpm_engine* engine) : e_(engine) {}
+
+  bool get_nlp_info(Index& n, Index& m, Index& nnz_jac_g, Index& nnz_h_lag, IndexStyleEnum& index_style) override {
+    int n_, m_, nj, nh, st;
+    if (rpm_get_nlp_info(e_, &n_, &m_, &nj, &nh, &st)) return false;
+    n = n_; m = m_; nnz_jac_g = nj; nnz_h_lag = nh;
+    index_style = Base::C_STYLE;                                 // LpopcIpopt.cpp:22
+    return true;
+  }
+  bool get_bounds_info(Index n, Number* x_l, Number* x_u, Index m, Number* g_l, Number* g_u) override {
+    return rpm_get_bounds_info(e_, n, x_l, x_u, m, g_l, g_u) == RPM_OK;
+  }
+  bool get_starting_point(Index n, bool init_x, Number* x, bool init_z, Number* z_L, Number* z_U, Index m,
+                          bool init_lambda, Number* lambda) override {
+    return rpm_get_starting_point(e_, n, init_x, x, init_z, z_L, z_U, m, init_lambda, lambda) == RPM_OK;
+  }
+  bool eval_f(Index n, const Number* x, bool new_x, Number& obj_value) override {
+    return rpm_eval_f(e_, n, x, new_x, &obj_value) == RPM_OK;
+  }
+  bool eval_grad_f(Index n, const Number* x, bool new_x, Number* grad_f) override {
+    return rpm_eval_grad_f(e_, n, x, new_x, grad_f) == RPM_OK;
+  }
+  bool eval_g(Index n, const Number* x, bool new_x, Index m, Number* g) override {
+    return rpm_eval_g(e_, n, x, new_x, m, g) == RPM_OK;
+  }
+  bool eval_jac_g(Index n, const Number* x, bool new_x, Index m, Index nele_jac, Index* iRow, Index* jCol,
+                  Number* values) override {
+    return rpm_eval_jac_g(e_, n, x, new_x, m, nele_jac, iRow, jCol, values) == RPM_OK;
+  }
+  bool eval_h(Index n, const Number* x, bool new_x, Number obj_factor, Index m, const Number* lambda, bool new_lambda,
+              Index nele_hess, Index* iRow, Index* jCol, Number* values) override {
+    return rpm_eval_h(e_, n, x, new_x, obj_factor, m, lambda, new_lambda, nele_hess, iRow, jCol, values) == RPM_OK;
+  }
+  void finalize_solution(SolverReturn status, Index n, const Number* x, const Number* z_L, const Number* z_U, Index m,
+                         const Number* g, const Number* lambda, Number obj_value,
+                         const typename Base::IpoptData* /*ip_data*/,
+                         typename Base::IpoptCalculatedQuantities* /*ip_cq*/) override {
+    rpm_finalize_solution(e_, int(status), n, x, z_L, z_U, m, g, lambda, obj_value);  // LpopcIpopt.cpp:220-246
+  }
+  std::string last_error() const { return rpm_last_error(e_); }
+
+ private:
+  rpm_engine* e_;
+};
+
+}  // namespace lpopc_amd

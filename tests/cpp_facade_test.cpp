@@ -1,0 +1,79 @@
+// Compiled and run by tests/test_cpp_facade.py: builds Bryson-Denham with the C++ façade exactly the way
+// example/bryson-denham/BrysonDenham.cpp:9-98 does, creates an engine through the C ABI, and drives it
+// through the TNLP adaptor instantiated over a test-local stand-in for Ipopt::TNLP's interface.
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "lpopc_amd/OptimalProblem.hpp"
+#include "lpopc_amd/RpmTNLP.hpp"
+
+struct FakeTNLP {   // the shape of Ipopt::TNLP (IpTNLP.hpp) as far as LpopcIpopt uses it
+  typedef int Index;
+  typedef double Number;
+  enum IndexStyleEnum { C_STYLE = 0, FORTRAN_STYLE = 1 };
+  typedef int SolverReturn;
+  struct IpoptData;
+  struct IpoptCalculatedQuantities;
+  virtual ~FakeTNLP() {}
+  virtual bool get_nlp_info(Index&, Index&, Index&, Index&, IndexStyleEnum&) = 0;
+  virtual bool get_bounds_info(Index, Number*, Number*, Index, Number*, Number*) = 0;
+  virtual bool get_starting_point(Index, bool, Number*, bool, Number*, Number*, Index, bool, Number*) = 0;
+  virtual bool eval_f(Index, const Number*, bool, Number&) = 0;
+  virtual bool eval_grad_f(Index, const Number*, bool, Number*) = 0;
+  virtual bool eval_g(Index, const Number*, bool, Index, Number*) = 0;
+  virtual bool eval_jac_g(Index, const Number*, bool, Index, Index, Index*, Index*, Number*) = 0;
+  virtual bool eval_h(Index, const Number*, bool, Number, Index, const Number*, bool, Index, Index*, Index*, Number*) = 0;
+  virtual void finalize_solution(SolverReturn, Index, const Number*, const Number*, const Number*, Index, const Number*,
+                                 const Number*, Number, const IpoptData*, IpoptCalculatedQuantities*) = 0;
+};
+
+using namespace lpopc_amd;
+
+int main() {
+  shared_ptr<Phase> phase1(new Phase(1, 3, 1, 0, 0, 5));
+  phase1->SetTimeMin(0.0, 0.0);
+  phase1->SetTimeMax(0, 50);
+  phase1->SetStateMin(0, 0, 0);
+  phase1->SetStateMax(1.0 / 9.0, 1.0 / 9.0, 1.0 / 9.0);
+  phase1->SetStateMin(-10, -10, -10);
+  phase1->SetStateMax(10, 10, 10);
+  phase1->SetStateMin(-10, -10, -10);
+  phase1->SetStateMax(10, 10, 10);
+  phase1->SetcontrolMin(-10);
+  phase1->SetcontrolMax(10);
+  phase1->SetTimeGuess(0.0);
+  phase1->SetTimeGuess(1.0);
+  const double ev[5] = {0, 1, 0, 0, -1};
+  for (double v : ev) phase1->SeteventMin(v);
+  for (double v : ev) phase1->SeteventMax(v);
+  phase1->SetStateGuess(1, 0); phase1->SetStateGuess(1, 0);
+  phase1->SetStateGuess(2, 1.0); phase1->SetStateGuess(2, -1.0);
+  phase1->SetStateGuess(3, 0.0); phase1->SetStateGuess(3, 0.0);
+  phase1->SetControlGuess(1, 0.0); phase1->SetControlGuess(1, 0.0);
+  shared_ptr<ProblemFunctor> userfun(new ProblemFunctor{RPM_PROBLEM_BRYSON_DENHAM, {}});
+  shared_ptr<OptimalProblem> optpro(new OptimalProblem(1, 0, userfun));
+  optpro->AddPhase(phase1);
+
+  rpm_engine* eng = nullptr;
+  if (rpm_create(&optpro->Lower(), &eng) != RPM_OK) {
+    std::printf("create failed: %s\n", rpm_last_error(nullptr));
+    return 1;
+  }
+  RpmTNLPT<FakeTNLP> nlp(eng);
+  int n, m, nj, nh;
+  FakeTNLP::IndexStyleEnum st;
+  if (!nlp.get_nlp_info(n, m, nj, nh, st) || st != FakeTNLP::C_STYLE) return 2;
+  std::printf("n=%d m=%d nnz_jac=%d nnz_h=%d\n", n, m, nj, nh);
+  std::vector<double> xl(n), xu(n), gl(m), gu(m), x(n), g(m);
+  if (!nlp.get_bounds_info(n, xl.data(), xu.data(), m, gl.data(), gu.data())) return 3;
+  if (!nlp.get_starting_point(n, true, x.data(), false, nullptr, nullptr, m, false, nullptr)) return 4;
+  std::vector<int> ir(nj), jc(nj);
+  if (!nlp.eval_jac_g(n, nullptr, false, m, nj, ir.data(), jc.data(), nullptr)) return 5;   // structure pass
+  // values pass: true on a GPU box, false (never a silent CPU fallback) elsewhere
+  const bool ok = nlp.eval_g(n, x.data(), true, m, g.data());
+  std::printf("eval_g -> %s%s%s\n", ok ? "true" : "false", ok ? "" : ": ", ok ? "" : nlp.last_error().c_str());
+  nlp.finalize_solution(0, n, x.data(), nullptr, nullptr, m, g.data(), g.data(), 1.5, nullptr, nullptr);
+  rpm_destroy(eng);
+  return 0;
+}

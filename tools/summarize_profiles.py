@@ -1,0 +1,61 @@
+"""Copies the rocprofv3 summaries collected by tools/collect_profiles.sh from gpurun_out/ (scratch)
+into profiles/ (tracked): the kernel-stats CSV, a PMC summary and profiles/pmc_traffic.json, which
+bench.py reports as roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def one(pattern):
+    fs = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return fs[0] if fs else None
+
+
+stats = one("%s_stats/*/*kernel_stats.csv" % tag)
+shutil.copy(stats, os.path.join(out, "%s_kernel_stats.csv" % tag))
+summary = {"tag": tag, "command": "python3 bench.py --profile --steps 200 --warmup 20 (default workload: batch 16, tile 16)"}
+for r in csv.DictReader(open(stats)):
+    if "rpm_tile_kernel" in r["Name"]:
+        summary["rpm_tile_kernel_calls"] = int(r["Calls"])
+        summary["rpm_tile_kernel_avg_us"] = float(r["AverageNs"]) / 1e3
+pmc = {}
+for sub in ("fetch", "write", "sq"):
+    f = one("%s_%s/*/*counter_collection.csv" % (tag, sub))
+    if not f:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "rpm_tile_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[k] = sum(v) / len(v)
+summary["pmc_per_launch"] = pmc
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads 1/2 of
+    # the bytes of a WIDE (16 B/lane) streaming read and is uncalibrated for other widths; this kernel's loads are
+    # 8 B/lane, so both the raw and the doubled figure are recorded and the raw one is used (it matches the
+    # expected x + per-XCD table reads).  WRITE_SIZE reads exact.
+    fetch, write = pmc["FETCH_SIZE"] * 1024.0, pmc["WRITE_SIZE"] * 1024.0
+    summary["hbm_read_bytes_raw"] = fetch
+    summary["hbm_read_bytes_if_doubled"] = 2 * fetch
+    summary["hbm_write_bytes"] = write
+    json.dump({"tag": tag, "hbm_bytes_per_launch": fetch + write, "fetch_bytes_raw": fetch, "write_bytes": write,
+               "note": "FETCH_SIZE raw (8 B/lane loads, see tools/summarize_profiles.py), WRITE_SIZE exact"},
+              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+bj = os.path.join(ROOT, "gpurun_out", "%s_bench.json" % tag)
+if os.path.exists(bj):
+    line = [l for l in open(bj) if l.startswith("{")]
+    if line:
+        summary["bench"] = json.loads(line[-1])
+        open(os.path.join(out, "%s_bench.json" % tag), "w").write(line[-1])
+json.dump(summary, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "bench"}, indent=1))
