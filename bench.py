@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--profile", action="store_true",
                     help="profiling run: only the warm-up and the timed launches (no extra checks/sections), so that\n"
                          "rocprofv3 --stats averages exactly the launches bench.py times")
+    ap.add_argument("--dx-mode", type=int, default=0, help="0: scalar D.X in the reference's order, 1: FP64 MFMA tiles")
     ap.add_argument("--tile-nodes", type=int, default=0)
     ap.add_argument("--batch", type=int, default=16,
                     help="NLP iterates evaluated per launch (independent instances of the same problem)")
@@ -106,6 +107,8 @@ def main():
         raise SystemExit("--shard intervals evaluates one iterate per launch")
     eng = NLPEngine(prob, n_instances=B, shard_mode=1 if sharded else 0, shard_rank=rank if sharded else 0,
                     shard_world=world if sharded else 1, tile_nodes=args.tile_nodes, device=local_rank)
+    if args.dx_mode:
+        eng.set_option("dx_mode", args.dx_mode)
     xl, xu, _, _ = eng.get_bounds_info()
     x0 = eng.get_starting_point()
     R = max(args.iterates, 2 * B)
@@ -178,6 +181,8 @@ def main():
     # sanity: results of the timed region are finite and equal to a fresh single evaluation
     if comm is None and not os.environ.get("RPM_DIAG_MASK") and not args.profile:
         one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
+        if args.dx_mode:
+            one.set_option("dx_mode", args.dx_mode)
         chk_g = torch.empty(eng.m, dtype=torch.float64, device="cuda")
         chk_v = torch.empty(eng.nnz_jac, dtype=torch.float64, device="cuda")
         for r in (0, R - 1):
@@ -224,6 +229,7 @@ def main():
                         "fused: one rpm_tile_kernel launch writes g and all Jacobian values of x_k",
                 "launch": "hipGraph replay of the K steps" if graph is not None else "eager launches",
                 "tile_nodes": eng.get_option("tile_nodes"),
+                "dx_mode": "mfma_f64_16x16x4" if args.dx_mode else "scalar, reference summation order",
                 "parallelism": ("intervals sharded x%d + RCCL all-gather" % world) if sharded else
                                ("independent instances x%d" % world),
                 "ms_per_ipopt_iter_synthetic": None,

@@ -304,7 +304,9 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   if (k == "fuse_pair") e.opt_fuse_pair = value ? 1 : 0;
   else if (k == "check_finite") e.opt_check_finite = value ? 1 : 0;
   else if (k == "dx_mode") {
-    if (value != 0) return fail(e, RPM_E_UNSUPPORTED, "dx_mode=1 (MFMA D.X) is not implemented yet");
+    if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "dx_mode must be 0 (scalar, reference order) or 1 (MFMA)");
+    if (value == 1 && e.first_derive == RPM_DERIVE_ANALYTIC)
+      return fail(e, RPM_E_UNSUPPORTED, "dx_mode=1 is only built for first-derive=finite-difference");
     e.opt_dx_mode = value;
   } else if (k == "tile_nodes") {
     if (value != 0 && value != 16 && value != 32 && value != 64) return fail(e, RPM_E_INVALID, "tile_nodes must be 0, 16, 32 or 64");

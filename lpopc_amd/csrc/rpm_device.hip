@@ -224,7 +224,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 #else
 #define RPM_TILE_ATTR
 #endif
-template <class Prob, int T, bool WG, bool WJ, bool AN>
+template <class Prob, int T, bool WG, bool WJ, bool AN, bool DXM = false>
 __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
                                 double* __restrict__ gall, double* __restrict__ vall) {
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
@@ -265,6 +265,7 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
   double* Us = Xs + NX * K.max_span;         // [NU][T]
   double* Ds = Us + NU * T;                  // the tile's D rows, row-major per node
   double* Fb = Ds + K.max_drow;              // [NO][T] unperturbed f and c
+  double* DXs = Fb + NO * T;                 // [NX][T] D.X of the tile (MFMA variant only)
 
   // ---- issue the loads nothing depends on first: this thread's node record and its share of the
   //      constant-block sources (stored at the very end) ----
@@ -275,8 +276,12 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
   const double tau = K.points[nidx];
   const NodeDev nd = K.nodes[nidx];
   const double ddiag = WJ ? K.diag[nidx] : 0.0;
+#ifdef RPM_EXP_CPRE
+  constexpr int CPRE = RPM_EXP_CPRE;
+#else
   constexpr int CPRE = 8;                          // constant-block sources prefetched per thread
-  double cpre[CPRE];
+#endif
+  double cpre[CPRE > 0 ? CPRE : 1];
   if (WJ) {
 #pragma unroll
     for (int u = 0; u < CPRE; ++u) {
@@ -321,10 +326,46 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
   //      order of the reference's COO loop for one output row (LpSparseMatrix.cpp:142-153) ----
   const int sv = WJ ? role - 1 : role;
   double dx = 0.0;
-  if (WG && sv >= 0 && sv < NX) {
+  if (WG && !DXM && sv >= 0 && sv < NX) {
     const double* drow = Ds + (nd.drow_off - tl.drow0);
     const double* xcol = Xs + sv * K.max_span + (nd.dcol0 - tl.span0);
     for (int j = 0; j < nd.dlen; ++j) dx += drow[j] * xcol[j];
+  }
+  // ---- MFMA variant (dx_mode = 1): the tile's D.X as dense 16x16x4 FP64 matrix-core products.  The tile's D
+  //      rows form a block-banded (cnt x span_len) matrix A (zero outside each row's interval), B = the staged X
+  //      rows (span_len x nx); wave 0 accumulates ceil(span_len/4) v_mfma_f64_16x16x4_f64 per 16 rows x 16 states.
+  //      Operand maps (cdna_hip_programming.md §3): A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],
+  //      C/D: col = l&15, row = (l>>4) + 4*reg.  The k-order of the sum differs from the reference's ascending
+  //      column loop, so results agree to rounding (~1e-16 relative), not bit for bit. ----
+  if constexpr (DXM && WG) {
+    if (tid < 64) {
+      typedef double d4 __attribute__((ext_vector_type(4)));
+      const int lr = tid & 15, kq = tid >> 4;
+      const int ksteps = (tl.span_len + 3) >> 2;
+      for (int rb = 0; rb < T; rb += 16) {
+        const int row = rb + lr;
+        const bool row_ok = row < tl.cnt;
+        const NodeDev ndr = K.nodes[ph.node0 + tl.k0 + (row_ok ? row : tl.cnt - 1)];
+        const int rel0 = ndr.dcol0 - tl.span0;
+        const double* drow = Ds + (ndr.drow_off - tl.drow0);
+        for (int cb = 0; cb < NX; cb += 16) {
+          const int st = cb + lr;
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+          for (int s = 0; s < ksteps; ++s) {
+            const int kcol = 4 * s + kq;
+            const int rel = kcol - rel0;
+            const double a = (row_ok && rel >= 0 && rel < ndr.dlen) ? drow[rel] : 0.0;
+            const double b = (st < NX && kcol < tl.span_len) ? Xs[st * K.max_span + kcol] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int orow = rb + kq + 4 * i;
+            if (st < NX && orow < tl.cnt) DXs[st * T + orow] = acc[i];
+          }
+        }
+      }
+    }
   }
 
   // ---- perturb this role's variable: h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214) ----
@@ -365,7 +406,7 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
   if (act) {
     const int N = ph.N;
     if (WG && sv >= 0 && sv < NX)
-      g[ph.g0 + sv * N + k] = dx - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
+      g[ph.g0 + sv * N + k] = (DXM ? DXs[sv * T + kk] : dx) - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
 #ifdef RPM_DIAG
     if (!(K.diag_mask & 8))
 #endif
@@ -635,7 +676,7 @@ void device_destroy(Engine& e) {
 }
 
 static size_t tile_lds_doubles(const Engine& e, int NX, int NU, int NC) {
-  size_t n = size_t(NX) * e.max_span + size_t(NU) * e.tile_nodes + e.max_drow + size_t(NX + NC) * e.tile_nodes;
+  size_t n = size_t(NX) * e.max_span + size_t(NU) * e.tile_nodes + e.max_drow + size_t(NX + NC) * e.tile_nodes + size_t(NX) * e.tile_nodes;
   return n < 64 ? 64 : n;
 }
 
@@ -729,14 +770,14 @@ int device_init(Engine& e, int device_id) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <class Prob, int T, bool WG, bool WJ, bool AN>
+template <class Prob, int T, bool WG, bool WJ, bool AN, bool DXM = false>
 static hipError_t launch_tile_inst(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
   constexpr int R = WJ ? Prob::NX + Prob::NU + 2 : (Prob::NX > 0 ? Prob::NX : 1);
   int threads = T * R;
   threads = (threads + 63) / 64 * 64;
   if (threads < 64) threads = 64;
   const Device& d = *e.dev;
-  auto kern = rpm_tile_kernel<Prob, T, WG, WJ, AN>;
+  auto kern = rpm_tile_kernel<Prob, T, WG, WJ, AN, DXM>;
   if (d.lds_bytes > 64 * 1024) {
     hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(d.lds_bytes));
@@ -756,6 +797,10 @@ static hipError_t launch_tile_T(const Engine& e, bool wg, bool wj, const double*
       if (wg && wj) return launch_tile_inst<Prob, T, true, true, true>(e, dx, dg, dv, st);
       if (wj) return launch_tile_inst<Prob, T, false, true, true>(e, dx, dg, dv, st);
     }
+  }
+  if (e.opt_dx_mode == 1) {   // MFMA D.X (finite-difference derivative mode)
+    if (wg && wj) return launch_tile_inst<Prob, T, true, true, false, true>(e, dx, dg, dv, st);
+    if (wg) return launch_tile_inst<Prob, T, true, false, false, true>(e, dx, dg, dv, st);
   }
   if (wg && wj) return launch_tile_inst<Prob, T, true, true, false>(e, dx, dg, dv, st);
   if (wj) return launch_tile_inst<Prob, T, false, true, false>(e, dx, dg, dv, st);

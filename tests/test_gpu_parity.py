@@ -213,3 +213,25 @@ def test_interval_sharding_on_one_gpu(built):
     assert bad_v.size == 0, (bad_v[:10], bad_v.size, ref.nnz_jac, ov[bad_v[:6]], v_ref[bad_v[:6]], np.unique(bad_v // 128)[:40])
     for e in engs + [ref]:
         e.close()
+
+
+@pytest.mark.parametrize("name,make,mode", [CASES[2], CASES[3], CASES[5], CASES[6], CASES[7]],
+                         ids=[CASES[i][0] for i in (2, 3, 5, 6, 7)])
+@pytest.mark.parametrize("tile", [16, 32, 64])
+def test_mfma_dx_mode(built, name, make, mode, tile):
+    """dx_mode=1: the tile's D.X on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).  Same result as the
+    scalar reference-order sum up to the summation order (<= 1e-12 relative here); the Jacobian is untouched."""
+    prob = make()
+    eng = NLPEngine(prob, tile_nodes=tile, device=0)
+    orc = oracle_for(prob)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 13, mode)
+    g0, v0 = eng.eval_g(x), eng.eval_jac_g(x, False)
+    eng.set_option("dx_mode", 1)
+    g1, v1 = eng.eval_g(x), eng.eval_jac_g(x, False)
+    assert rel_err(g1, orc.eval_g(x)) <= 5e-12
+    assert rel_err(g1, g0) <= 5e-12   # summation order only; terms |d_j x_j| reach 1e3 on 1/64-wide intervals
+    assert np.array_equal(v1, v0)
+    eng.set_option("fuse_pair", 0)
+    assert np.array_equal(eng.eval_g(x), g1)
+    eng.close()
