@@ -85,7 +85,13 @@ int rpm_device_init(rpm_engine* h, int device_id) {
 
 int rpm_get_nlp_info(rpm_engine* h, int* n, int* m, int* nnz_jac_g, int* nnz_h_lag, int* index_style) {
   if (!h) return RPM_E_INVALID;
-  const Engine& e = h->e;
+  Engine& e = h->e;
+  if (e.hessian_mode == RPM_HESSIAN_EXACT && nnz_h_lag) {
+    // the Hessian pattern comes from a NaN-propagation probe of the device functor (LpDerivDependciesChecker.cpp),
+    // so in exact mode the structure needs the GPU once per mesh
+    int rc = rpm::ensure_hessian(e);
+    if (rc) return rc;
+  }
   if (n) *n = e.n;
   if (m) *m = e.m;
   if (nnz_jac_g) *nnz_jac_g = e.nnz_jac;
@@ -217,12 +223,35 @@ int rpm_eval_jac_g(rpm_engine* h, int n, const double* x, int new_x, int m, int 
 
 int rpm_eval_h(rpm_engine* h, int n, const double* x, int new_x, double obj_factor, int m, const double* lambda,
                int new_lambda, int nele_hess, int* iRow, int* jCol, double* values) {
-  (void)n; (void)x; (void)new_x; (void)obj_factor; (void)m; (void)lambda; (void)new_lambda; (void)nele_hess;
-  (void)iRow; (void)jCol; (void)values;
+  (void)new_x; (void)new_lambda;
   if (!h) return RPM_E_INVALID;
-  // With hessian-approximation=limited-memory (the reference's default, LpNLPWrapper.hpp:71) Ipopt never calls
-  // eval_h.  The exact finite-difference Hessian (LpHessian.cpp) is SURVEY §8 row f-1, not built yet.
-  return fail(h->e, RPM_E_UNSUPPORTED, "eval_h: hessian-approximation=exact is not implemented yet");
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  // With hessian-approximation=limited-memory (the reference's default, LpNLPWrapper.hpp:71) Ipopt never calls eval_h.
+  if (e.hessian_mode != RPM_HESSIAN_EXACT) return fail(e, RPM_E_UNSUPPORTED, "eval_h: the engine was created with hessian-approximation=limited-memory");
+  int rc = rpm::ensure_hessian(e);
+  if (rc) return rc;
+  if (n != e.n || m != e.m || nele_hess != e.nnz_h) return fail(e, RPM_E_INVALID, "eval_h: size mismatch");
+  if (!values) {  // structure pass, LpopcIpopt.cpp:187-195
+    if (!iRow || !jCol) return fail(e, RPM_E_INVALID, "eval_h: iRow/jCol are NULL in the structure pass");
+    std::memcpy(iRow, e.hes_i.data(), sizeof(int) * e.nnz_h);
+    std::memcpy(jCol, e.hes_j.data(), sizeof(int) * e.nnz_h);
+    return RPM_OK;
+  }
+  if (!x || !lambda) return fail(e, RPM_E_INVALID, "eval_h: x or lambda is NULL");
+  rc = stage_x(e, n, x, 1);
+  if (rc) return rc;
+  // the reference copies only m-1 multipliers (LpopcIpopt.cpp:205-208); the last one belongs to a linear row and
+  // never enters the Hessian, so all m are uploaded here
+  rc = rpm::dev_upload(e, rpm::dev_buf(e, 5), lambda, size_t(e.n_instances) * e.m);
+  if (rc) return rc;
+  rc = rpm::dev_eval_h(e, rpm::dev_buf(e, 0), obj_factor, rpm::dev_buf(e, 5), rpm::dev_buf(e, 6), rpm::dev_stream(e));
+  if (rc) return rc;
+  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 6), size_t(e.n_instances) * e.nnz_h);
+  if (rc) return rc;
+  if (e.opt_check_finite && !all_finite(values, size_t(e.n_instances) * e.nnz_h)) return fail(e, RPM_E_NONFINITE, "eval_h: non-finite Hessian value");
+  return RPM_OK;
+  RPM_GUARD_END(e)
 }
 
 int rpm_finalize_solution(rpm_engine* h, int status, int n, const double* x, const double* z_L, const double* z_U,
@@ -287,9 +316,12 @@ int rpm_eval_grad_f_dev(rpm_engine* h, const double* d_x, double* d_grad_f, void
 }
 int rpm_eval_h_dev(rpm_engine* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_values,
                    void* stream) {
-  (void)d_x; (void)obj_factor; (void)d_lambda; (void)d_values; (void)stream;
   if (!h) return RPM_E_INVALID;
-  return fail(h->e, RPM_E_UNSUPPORTED, "eval_h_dev: hessian-approximation=exact is not implemented yet");
+  RPM_GUARD_BEGIN
+  if (h->e.hessian_mode != RPM_HESSIAN_EXACT) return fail(h->e, RPM_E_UNSUPPORTED, "eval_h_dev: the engine was created with hessian-approximation=limited-memory");
+  if (!d_x || !d_lambda || !d_values) return fail(h->e, RPM_E_INVALID, "eval_h_dev: NULL pointer");
+  return rpm::dev_eval_h(h->e, d_x, obj_factor, d_lambda, d_values, stream);
+  RPM_GUARD_END(h->e)
 }
 int rpm_synchronize(rpm_engine* h) {
   if (!h) return RPM_E_INVALID;

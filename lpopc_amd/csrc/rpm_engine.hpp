@@ -46,6 +46,28 @@ struct TileDev {
   int c_src0, c_cnt, c_dst0, c_stride, c_copies;
 };
 
+// ---- exact-Hessian mode (hessian-approximation=exact), LpHessian.cpp ------------------------------
+// One record per perturbation pair (a >= b over the node variables [x.., u.., t]) of a phase.
+struct HessPairDev {
+  int a, b;
+  int kind;        // 0: not stored (pattern H(a,b) = 0), 1: N-long block, 2: (t, v) pair -> t0 and tf row blocks, 3: (t, t)
+  int dst0, dst1;  // offsets inside the phase's I-part (kind 1: dst0; kind 2: t0 block, tf block)
+};
+struct HessPhaseDev {
+  int pair0;             // first HessPairDev of the phase
+  int v0;                // offset of the phase's entries in the Hessian values
+  int nI, nE;
+  int tt_dst[3];         // I-part offsets of the t0t0, tft0, tftf scalars
+  int end0, n_end;       // endpoint entries (HessEndDev) of the phase
+  int tt_tmp;            // offset of the phase's per-node tt terms in the scratch array (3 x N)
+};
+// One E-part (events + Mayer) entry: second difference w.r.t. endpoint variables a then b of
+// W = [x0.., xf.., t0, tf]; the denominator is pert(da)*pert(db) exactly as the reference writes it
+// (including its pertxf(istate) quirk, LpHessian.cpp:1588,1612,1826,1850).
+struct HessEndDev { int phase, a, b, da, db, dst; };
+// One linkage entry: variables a then b of [xf_left.., x0_right..]
+struct HessLinkDev { int pair, a, b, dst; };
+
 // endpoint work items, one workgroup each: 0 = linear rows, 1 = events of phase idx, 2 = linkage pair idx
 struct TaskDev { int type, idx; };
 
@@ -100,6 +122,13 @@ struct Engine {
   std::vector<double> alin_v;
   std::vector<int> jac_i, jac_j;                  // cached structure (NLPWrapper::GetConsSparsity)
   std::vector<int> hes_i, hes_j;
+  bool hess_ready = false;                         // dependency probe done, structure + tables built
+  std::vector<std::vector<int>> hess_dep;          // per phase (nx+nc) x (nx+nu), column-major 0/1
+  std::vector<HessPairDev> hess_pairs;
+  std::vector<HessPhaseDev> hess_phases;
+  std::vector<HessEndDev> hess_ends;
+  std::vector<HessLinkDev> hess_links;
+  int hess_tmp_len = 0;
   // device tables (host copies)
   std::vector<PhaseDev> phd;
   std::vector<TileDev> tiles;                      // all tiles, phase-major
@@ -125,6 +154,12 @@ int setup_engine(Engine& e, const rpm_problem_desc* d);  // returns RPM_* code, 
 void build_tiles(Engine& e, int tile_nodes);
 void lgr_points(int n, std::vector<double>& x, std::vector<double>& w);
 void colloc_d(const std::vector<double>& pts, std::vector<double>& D);  // (M-1) x M, column-major
+
+// rpm_hess.cpp: Hessian structure and device tables from the dependency patterns (host only)
+void build_hessian_tables(Engine& e);
+// rpm_device.hip: runs the NaN-propagation dependency probe on the device, then build_hessian_tables
+int ensure_hessian(Engine& e);
+int dev_eval_h(Engine& e, const double* d_x, double obj_factor, const double* d_lambda, double* d_values, void* stream);
 
 // rpm_shard.cpp: rank's contiguous runs of g (which=0) or of the Jacobian values (which=1)
 std::vector<rpm_segment> shard_segments(const Engine& e, int which, int rank, int* packed_len);

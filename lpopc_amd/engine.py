@@ -251,6 +251,10 @@ class NLPEngine:
     def eval_grad_f_dev(self, d_x, d_grad, stream=None):
         self._check(self._L.rpm_eval_grad_f_dev(self._h, self._ptr(d_x), self._ptr(d_grad), self._stream(stream)))
 
+    def eval_h_dev(self, d_x, obj_factor, d_lambda, d_values, stream=None):
+        self._check(self._L.rpm_eval_h_dev(self._h, self._ptr(d_x), float(obj_factor), self._ptr(d_lambda),
+                                           self._ptr(d_values), self._stream(stream)))
+
     def synchronize(self):
         self._check(self._L.rpm_synchronize(self._h))
 

@@ -23,55 +23,9 @@
 #define M_PI 3.14159265358979323846
 #endif
 
-/* ------------------------------------------------------------------------- */
-typedef struct {
-  int nx, nu, nq, nc, ne, K, N;
-  double* mesh;
-  int* nk;
-  /* struct ps, Core/LpCalculateData.hpp:35-41 */
-  double* points;
-  double* weights;
-  int d_nnz;
-  int *d_i, *d_j;
-  double* d_v;
-  int diag_nnz;
-  double* diag_v;
-  int off_nnz;
-  int *off_i, *off_j;
-  double* off_v;
-  /* layout, 0-based absolute indices (phase_indices are 1-based in the reference) */
-  int var0, con0, nvar, ncon;
-  int state0, control0, t0_idx, tf_idx, param0;
-} ophase;
+#include "orpm_internal.h"
 
-typedef struct {
-  int left, right; /* 0-based */
-  int nlink;
-  double *lmin, *lmax;
-} olink;
-
-struct orpm {
-  int P, L;
-  ophase* ph;
-  olink* lk;
-  const orpm_functions* fun;
-  int nconsts;
-  double* consts;
-  double tol;
-  int first_derive;
-  int hessian_mode;
-  int n, m_nl, m, nnz_nl, nnz_lin, nnz_const, nnz;
-  double *xl, *xu, *gl, *gu;
-  double* guess;
-  int alin_nnz;
-  int *alin_i, *alin_j;
-  double* alin_v;
-  double *linmin, *linmax;
-  /* Hessian (oracle/orpm_hess.c) */
-  void* hess;
-};
-
-static void* xcalloc(size_t n, size_t s) {
+void* orpm_xcalloc(size_t n, size_t s) {
   void* p = calloc(n ? n : 1, s);
   if (!p) {
     fprintf(stderr, "orpm: out of memory\n");
@@ -79,12 +33,11 @@ static void* xcalloc(size_t n, size_t s) {
   }
   return p;
 }
-#define NEW(T, n) ((T*)xcalloc((size_t)(n), sizeof(T)))
 
 /* ---------------------------------------------------------------------------
  * Armadillo 5.300.4 arrayops::accumulate (two running sums over even/odd
  * elements, then their sum) — the order used by sum(X) on a column. */
-static double arma_accumulate(const double* a, int n) {
+double orpm_arma_accumulate(const double* a, int n) {
   double acc1 = 0.0, acc2 = 0.0;
   int j;
   for (j = 1; j < n; j += 2) {
@@ -95,7 +48,7 @@ static double arma_accumulate(const double* a, int n) {
   return acc1 + acc2;
 }
 /* Armadillo 5.300.4 op_dot::direct_dot_arma (two accumulators) */
-static double arma_dot(const double* a, const double* b, int n) {
+double orpm_arma_dot(const double* a, const double* b, int n) {
   double v1 = 0.0, v2 = 0.0;
   int i, j;
   for (i = 0, j = 1; j < n; i += 2, j += 2) {
@@ -172,7 +125,7 @@ void orpm_colloc_d(int M, const double* x, double* D) {
     for (int i = 0; i < M; i++) D0[i + (size_t)j * M] = ww[i] / (ww[j] * Yd[i + (size_t)j * M]);
   /* D(j,j) = 1 - sum(D)(j)  (column sums, Armadillo accumulate order) */
   for (int j = 0; j < M; j++) {
-    double s = arma_accumulate(D0 + (size_t)j * M, M);
+    double s = orpm_arma_accumulate(D0 + (size_t)j * M, M);
     D0[j + (size_t)j * M] = 1 - s;
   }
   /* D = (-D')(0:M-2, :) */
@@ -356,7 +309,7 @@ static int fail(char* err, int errlen, const char* msg) {
   }
   return 0;
 }
-static double* dupd(const double* s, int n) {
+double* orpm_dupd(const double* s, int n) {
   double* d = NEW(double, n);
   if (n > 0 && s) memcpy(d, s, sizeof(double) * n);
   return d;
@@ -380,7 +333,7 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
   o->L = d->n_links;
   o->fun = fun;
   o->nconsts = d->n_consts;
-  o->consts = dupd(d->consts, d->n_consts);
+  o->consts = orpm_dupd(d->consts, d->n_consts);
   o->tol = d->fd_tol > 0 ? d->fd_tol : 1e-6;
   o->first_derive = d->first_derive;
   o->hessian_mode = d->hessian_approximation;
@@ -408,7 +361,7 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
       orpm_destroy(o);
       return NULL;
     }
-    p->mesh = dupd(pd->mesh_points, p->K + 1);
+    p->mesh = orpm_dupd(pd->mesh_points, p->K + 1);
     p->nk = NEW(int, p->K);
     for (int k = 0; k < p->K; k++) {
       p->nk[k] = pd->nodes_per_interval[k];
@@ -430,8 +383,8 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
     o->lk[i].left = ld->left_phase - 1; /* Linkage::LeftPhase(), LpOptimalProblem.hpp:264-269 */
     o->lk[i].right = ld->right_phase - 1;
     o->lk[i].nlink = ld->n_links;
-    o->lk[i].lmin = dupd(ld->link_min, ld->n_links);
-    o->lk[i].lmax = dupd(ld->link_max, ld->n_links);
+    o->lk[i].lmin = orpm_dupd(ld->link_min, ld->n_links);
+    o->lk[i].lmax = orpm_dupd(ld->link_max, ld->n_links);
   }
 
   /* ---- bounds and layout (LpBoundsChecker::GetBounds, Core/LpBoundsChecker.cpp:13-348) ---- */
@@ -710,17 +663,7 @@ void orpm_get_phase_tables(const orpm* o, int phase, double* points, double* wei
 /* ===========================================================================
  * slicing shared by every callback (e.g. Core/LpNLPWrapper.cpp:69-96)
  * ======================================================================== */
-typedef struct {
-  int N, nx, nu, nq, nc, ne;
-  double t0, tf, tspan;
-  double* t_radau;      /* N */
-  double* state_matrix; /* (N+1) x nx */
-  double* state_radau;  /* N x nx */
-  double* control;      /* N x nu */
-  double *x0, *xf;      /* nx */
-} pslice;
-
-static void slice_phase(const orpm* o, int i, const double* x, pslice* s) {
+void orpm_slice_phase(const orpm* o, int i, const double* x, pslice* s) {
   const ophase* p = &o->ph[i];
   int N = p->N;
   s->N = N;
@@ -734,7 +677,7 @@ static void slice_phase(const orpm* o, int i, const double* x, pslice* s) {
   s->tspan = s->tf - s->t0;
   s->t_radau = NEW(double, N);
   for (int k = 0; k < N; k++) s->t_radau[k] = (p->points[k] + 1) * (s->tspan / 2.0) + s->t0;
-  s->state_matrix = dupd(x + p->state0, (N + 1) * p->nx);
+  s->state_matrix = orpm_dupd(x + p->state0, (N + 1) * p->nx);
   s->state_radau = NEW(double, (size_t)N * p->nx);
   s->x0 = NEW(double, p->nx);
   s->xf = NEW(double, p->nx);
@@ -743,9 +686,9 @@ static void slice_phase(const orpm* o, int i, const double* x, pslice* s) {
     s->x0[j] = s->state_matrix[(size_t)j * (N + 1)];
     s->xf[j] = s->state_matrix[(size_t)j * (N + 1) + N];
   }
-  s->control = dupd(x + p->control0, N * p->nu);
+  s->control = orpm_dupd(x + p->control0, N * p->nu);
 }
-static void free_slice(pslice* s) {
+void orpm_free_slice(pslice* s) {
   free(s->t_radau);
   free(s->state_matrix);
   free(s->state_radau);
@@ -753,7 +696,7 @@ static void free_slice(pslice* s) {
   free(s->x0);
   free(s->xf);
 }
-static void mk_soldae(const pslice* s, int phase_num, orpm_soldae* d) {
+void orpm_mk_soldae(const pslice* s, int phase_num, orpm_soldae* d) {
   d->phase_num = phase_num;
   d->N = s->N;
   d->nx = s->nx;
@@ -765,7 +708,7 @@ static void mk_soldae(const pslice* s, int phase_num, orpm_soldae* d) {
   d->control = s->control;
   d->parameter = NULL;
 }
-static void mk_solcost(const pslice* s, int phase_num, orpm_solcost* c) {
+void orpm_mk_solcost(const pslice* s, int phase_num, orpm_solcost* c) {
   c->phase_num = phase_num;
   c->initial_time = s->t0;
   c->initial_state = s->x0;
@@ -780,7 +723,7 @@ static void mk_solcost(const pslice* s, int phase_num, orpm_solcost* c) {
   c->control = s->control;
   c->parameter = NULL;
 }
-static void mk_solevent(const pslice* s, int phase_num, orpm_solevent* e) {
+void orpm_mk_solevent(const pslice* s, int phase_num, orpm_solevent* e) {
   e->phase_num = phase_num;
   e->initial_time = s->t0;
   e->terminal_time = s->tf;
@@ -802,10 +745,10 @@ void orpm_eval_g(orpm* o, const double* x, double* g) {
   for (int i = 0; i < o->P; i++) {
     const ophase* p = &o->ph[i];
     pslice s;
-    slice_phase(o, i, x, &s);
+    orpm_slice_phase(o, i, x, &s);
     int N = s.N;
     orpm_soldae sd;
-    mk_soldae(&s, i + 1, &sd);
+    orpm_mk_soldae(&s, i + 1, &sd);
     double* stateout = NEW(double, (size_t)N * p->nx);
     double* pathout = NEW(double, (size_t)N * (p->nc > 0 ? p->nc : 1));
     o->fun->dae(&sd, o->consts, stateout, pathout);                                /* :110 */
@@ -817,19 +760,19 @@ void orpm_eval_g(orpm* o, const double* x, double* g) {
     row += N * p->nc;
     if (p->ne > 0) {                                                               /* :125-136 */
       orpm_solevent se;
-      mk_solevent(&s, i + 1, &se);
+      orpm_mk_solevent(&s, i + 1, &se);
       double* ev = NEW(double, p->ne);
       o->fun->event(&se, o->consts, ev);
       for (int q = 0; q < p->ne; q++) g[row + q] = ev[q];
       row += p->ne;
       free(ev);
     }
-    x0s[i] = dupd(s.x0, p->nx);
-    xfs[i] = dupd(s.xf, p->nx);
+    x0s[i] = orpm_dupd(s.x0, p->nx);
+    xfs[i] = orpm_dupd(s.xf, p->nx);
     free(stateout);
     free(pathout);
     free(odeleft);
-    free_slice(&s);
+    orpm_free_slice(&s);
   }
   for (int ip = 0; ip < o->L; ip++) { /* :180-211 */
     const olink* l = &o->lk[ip];
@@ -892,8 +835,8 @@ static void fd_deriv_dae(orpm* o, const orpm_soldae* base, double* dstate, doubl
   }
   double* pso = NEW(double, (size_t)N * nx);
   double* ppo = NEW(double, (size_t)N * (nc > 0 ? nc : 1));
-  double* work_state = dupd(base->state, N * nx);
-  double* work_control = dupd(base->control, N * nu);
+  double* work_state = orpm_dupd(base->state, N * nx);
+  double* work_control = orpm_dupd(base->control, N * nu);
   orpm_soldae sd = *base;
   /* one column of the stacked result: rows [i*N,(i+1)*N) = d out_i / d var at the N nodes */
 #define STORE(col, denom)                                                                          \
@@ -952,8 +895,8 @@ static void fd_deriv_event(orpm* o, const orpm_solevent* base, double* d) {
   double pertf = tol * (1 + fabs(base->terminal_time));
   double* ev = NEW(double, ne);
   double* pe = NEW(double, ne);
-  double* x0 = dupd(base->initial_state, nx);
-  double* xf = dupd(base->terminal_state, nx);
+  double* x0 = orpm_dupd(base->initial_state, nx);
+  double* xf = orpm_dupd(base->terminal_state, nx);
   orpm_solevent se = *base;
   se.initial_state = x0;
   se.terminal_state = xf;
@@ -990,8 +933,8 @@ static void fd_deriv_link(orpm* o, const orpm_sollink* base, double* d) {
   double tol = o->tol;
   double* lo = NEW(double, nl);
   double* pl = NEW(double, nl);
-  double* xl = dupd(base->left_state, nxl);
-  double* xr = dupd(base->right_state, nxr);
+  double* xl = orpm_dupd(base->left_state, nxl);
+  double* xr = orpm_dupd(base->right_state, nxr);
   orpm_sollink sl = *base;
   sl.left_state = xl;
   sl.right_state = xr;
@@ -1022,8 +965,8 @@ static void fd_deriv_mayer(orpm* o, const orpm_solcost* base, double* d) {
   double tol = o->tol;
   double pert0 = tol * (1 + fabs(base->initial_time));
   double pertf = tol * (1 + fabs(base->terminal_time));
-  double* x0 = dupd(base->initial_state, nx);
-  double* xf = dupd(base->terminal_state, nx);
+  double* x0 = orpm_dupd(base->initial_state, nx);
+  double* xf = orpm_dupd(base->terminal_state, nx);
   orpm_solcost sc = *base;
   sc.initial_state = x0;
   sc.terminal_state = xf;
@@ -1059,9 +1002,9 @@ static void fd_deriv_lagrange(orpm* o, const orpm_solcost* base, double* d) {
   double tol = o->tol;
   double* L0 = NEW(double, N);
   double* Lp = NEW(double, N);
-  double* ws = dupd(base->state, N * nx);
-  double* wc = dupd(base->control, N * nu);
-  double* wt = dupd(base->time, N);
+  double* ws = orpm_dupd(base->state, N * nx);
+  double* wc = orpm_dupd(base->control, N * nu);
+  double* wt = orpm_dupd(base->time, N);
   orpm_solcost sc = *base;
   o->fun->lagrange(&sc, o->consts, L0);
   for (int k = 0; k < N; k++) wt[k] = base->time[k] + tol * (1 + fabs(base->time[k]));
@@ -1104,7 +1047,7 @@ static void fd_deriv_lagrange(orpm* o, const orpm_solcost* base, double* d) {
 
 /* derive_->Deriv*: finite differences or the user's analytic callbacks
  * (Core/LpAnalyticDerive.hpp:24-48) */
-static void deriv_dae(orpm* o, const orpm_soldae* sd, double* dstate, double* dpath) {
+void orpm_deriv_dae(orpm* o, const orpm_soldae* sd, double* dstate, double* dpath) {
   if (o->first_derive == RPM_DERIVE_ANALYTIC && o->fun->deriv_dae)
     o->fun->deriv_dae(sd, o->consts, dstate, dpath);
   else
@@ -1128,7 +1071,7 @@ static void deriv_mayer(orpm* o, const orpm_solcost* sc, double* d) {
   else
     fd_deriv_mayer(o, sc, d);
 }
-static void deriv_lagrange(orpm* o, const orpm_solcost* sc, double* d) {
+void orpm_deriv_lagrange(orpm* o, const orpm_solcost* sc, double* d) {
   if (o->first_derive == RPM_DERIVE_ANALYTIC && o->fun->deriv_lagrange)
     o->fun->deriv_lagrange(sc, o->consts, d);
   else
@@ -1142,15 +1085,15 @@ static void deriv_lagrange(orpm* o, const orpm_solcost* sc, double* d) {
 static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* SC) {
   const ophase* p = &o->ph[iphase];
   pslice s;
-  slice_phase(o, iphase, x, &s);
+  orpm_slice_phase(o, iphase, x, &s);
   int N = s.N, nx = p->nx, nu = p->nu, nc = p->nc, ne = p->ne;
   int ncolD = nx + nu + 1;
   double t0 = s.t0, tf = s.tf;
   orpm_soldae sd;
-  mk_soldae(&s, iphase + 1, &sd);
+  orpm_mk_soldae(&s, iphase + 1, &sd);
   double* dDaeOut = NEW(double, (size_t)N * nx * ncolD);
   double* dPathOut = NEW(double, (size_t)N * (nc > 0 ? nc : 1) * ncolD);
-  deriv_dae(o, &sd, dDaeOut, dPathOut);                        /* :569 */
+  orpm_deriv_dae(o, &sd, dDaeOut, dPathOut);                        /* :569 */
   double* daeOut = NEW(double, (size_t)N * nx);
   double* pathOut = NEW(double, (size_t)N * (nc > 0 ? nc : 1));
   o->fun->dae(&sd, o->consts, daeOut, pathOut);                /* :572 */
@@ -1160,7 +1103,7 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
   double* dEventOut = NULL;
   if (ne > 0) { /* :638-669 */
     orpm_solevent se;
-    mk_solevent(&s, iphase + 1, &se);
+    orpm_mk_solevent(&s, iphase + 1, &se);
     dEventOut = NEW(double, (size_t)ne * (2 * nx + 2));
     deriv_event(o, &se, dEventOut);
   }
@@ -1230,7 +1173,7 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
   free(fi);
   free(fj);
   free(fv);
-  free_slice(&s);
+  orpm_free_slice(&s);
   return sh;
 }
 
@@ -1387,19 +1330,19 @@ double orpm_eval_f(orpm* o, const double* x) {
   for (int i = 0; i < o->P; i++) {
     const ophase* p = &o->ph[i];
     pslice s;
-    slice_phase(o, i, x, &s);
+    orpm_slice_phase(o, i, x, &s);
     orpm_solcost sc;
-    mk_solcost(&s, i + 1, &sc);
+    orpm_mk_solcost(&s, i + 1, &sc);
     double mayer = 0.0;
     double* L = NEW(double, p->N);
     o->fun->mayer(&sc, o->consts, &mayer);
     cost += mayer;
     o->fun->lagrange(&sc, o->consts, L);
     /* trans(Weights)*L*(tspan/2): dot (Armadillo direct_dot order) then the scalar, :931 */
-    double integrand = arma_dot(p->weights, L, p->N) * (s.tspan / 2.0);
+    double integrand = orpm_arma_dot(p->weights, L, p->N) * (s.tspan / 2.0);
     cost += integrand;
     free(L);
-    free_slice(&s);
+    orpm_free_slice(&s);
   }
   return cost;
 }
@@ -1417,17 +1360,17 @@ void orpm_eval_grad_f(orpm* o, const double* x, double* grad_f) {
   for (int ip = 0; ip < o->P; ip++) {
     const ophase* p = &o->ph[ip];
     pslice s;
-    slice_phase(o, ip, x, &s);
+    orpm_slice_phase(o, ip, x, &s);
     int N = p->N, nx = p->nx, nu = p->nu;
     double tspan = s.tspan;
     orpm_solcost sc;
-    mk_solcost(&s, ip + 1, &sc);
+    orpm_mk_solcost(&s, ip + 1, &sc);
     double* Lout = NEW(double, N);
     double* dM = NEW(double, 2 * nx + 2);
     double* dL = NEW(double, (size_t)N * (nx + nu + 1));
     o->fun->lagrange(&sc, o->consts, Lout);  /* :989 */
     deriv_mayer(o, &sc, dM);                 /* :990 */
-    deriv_lagrange(o, &sc, dL);              /* :991 */
+    orpm_deriv_lagrange(o, &sc, dL);              /* :991 */
     double dMayer_t0 = dM[nx], dMayer_tf = dM[2 * nx + 1];
     const double* dLt = dL + (size_t)(nx + nu) * N; /* last column, :1025 */
     double* J = grad_f + gs;
@@ -1451,11 +1394,11 @@ void orpm_eval_grad_f(orpm* o, const double* x, double* grad_f) {
       r2[k] = (p->weights[k] * (tspan / 2.0)) * dLt[k];
       r3[k] = p->points[k] * (-0.5) + 0.5;
     }
-    double ret = arma_dot(a, Lout, N);
-    J[cs] = (arma_dot(r2, r3, N) + dMayer_t0) + ret;
+    double ret = orpm_arma_dot(a, Lout, N);
+    J[cs] = (orpm_arma_dot(r2, r3, N) + dMayer_t0) + ret;
     /* d/dtf, :1081-1087 */
     for (int k = 0; k < N; k++) a[k] = p->weights[k] * (0.5);
-    ret = arma_dot(a, Lout, N);
+    ret = orpm_arma_dot(a, Lout, N);
     double ret3_00 = (p->points[0] * (0.5) + 0.5) * r2[0];
     J[cs + 1] = dMayer_tf + ret + ret3_00;
     free(a);
@@ -1465,33 +1408,7 @@ void orpm_eval_grad_f(orpm* o, const double* x, double* grad_f) {
     free(dM);
     free(dL);
     gs += p->nvar;
-    free_slice(&s);
+    orpm_free_slice(&s);
   }
 }
 
-/* accessors used by orpm_hess.c */
-int orpm__P(const orpm* o) { return o->P; }
-int orpm__L(const orpm* o) { return o->L; }
-void orpm__phase_dims(const orpm* o, int i, int* N, int* nx, int* nu, int* nc, int* ne, int* var0,
-                      int* con0) {
-  const ophase* p = &o->ph[i];
-  *N = p->N;
-  *nx = p->nx;
-  *nu = p->nu;
-  *nc = p->nc;
-  *ne = p->ne;
-  *var0 = p->var0;
-  *con0 = p->con0;
-}
-const double* orpm__points(const orpm* o, int i) { return o->ph[i].points; }
-const double* orpm__weights(const orpm* o, int i) { return o->ph[i].weights; }
-const orpm_functions* orpm__fun(const orpm* o) { return o->fun; }
-const double* orpm__consts(const orpm* o) { return o->consts; }
-double orpm__tol(const orpm* o) { return o->tol; }
-int orpm__n(const orpm* o) { return o->n; }
-int orpm__mnl(const orpm* o) { return o->m_nl; }
-void orpm__link(const orpm* o, int i, int* left, int* right, int* nlink) {
-  *left = o->lk[i].left;
-  *right = o->lk[i].right;
-  *nlink = o->lk[i].nlink;
-}

@@ -235,3 +235,71 @@ def test_mfma_dx_mode(built, name, make, mode, tile):
     eng.set_option("fuse_pair", 0)
     assert np.array_equal(eng.eval_g(x), g1)
     eng.close()
+
+
+# ---- exact Hessian (hessian-approximation=exact): forward second differences, LpHessian.cpp ------------------
+def _exact():
+    o = Options()
+    o.SetStringValue("hessian-approximation", "exact")
+    return o
+
+
+HESS_CASES = [
+    # (name, problem, relative tolerance).  Second differences divide rounding noise by h_i*h_j ~ 1e-12, so a 1-ulp
+    # libm difference (exp/pow/sqrt/acos/sin/cos) between the CPU oracle and the GPU shows up at ~1e-4 of the
+    # function's scale; polynomial dynamics have no libm call and must agree to rounding of the final combination.
+    ("bryson_denham", lambda: problems.bryson_denham(3, 5), 1e-9),
+    ("hypersensitive", lambda: problems.hypersensitive([-1, -0.5, 0.4, 1], [4, 6, 3], tf=50.0), 1e-9),
+    ("brachistochrone", lambda: problems.brachistochrone(2, 6), 5e-3),
+    ("quadrotor", lambda: problems.quadrotor(2, 4), 5e-3),
+    ("climb", lambda: problems.min_time_climb(2, 6), 5e-3),
+    ("launch", lambda: problems.launch(2, 5), 5e-3),
+]
+
+
+@pytest.mark.parametrize("name,make,tol", HESS_CASES, ids=[c[0] for c in HESS_CASES])
+def test_exact_hessian(built, name, make, tol):
+    import scipy.sparse as sp
+    prob = make()
+    eng = NLPEngine(prob, _exact(), device=0)
+    orc = oracle_for(prob, _exact())
+    assert eng.nnz_h == orc.nnz_h and eng.nnz_h > 0
+    hi, hj = eng.eval_h_structure()
+    oi, oj = orc.hess_structure()
+    assert np.array_equal(hi, oi) and np.array_equal(hj, oj)
+    assert np.all(hi >= hj)                                        # lower triangle
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 5)
+    rng = np.random.RandomState(1)
+    lam, sigma = rng.uniform(-1, 1, eng.m), 0.7
+    hv, hr = eng.eval_h(x, sigma, lam), orc.eval_h(x, sigma, lam)
+    scale = max(1.0, float(np.max(np.abs(hr))))
+    assert np.max(np.abs(hv - hr)) <= tol * scale
+    # the assembled matrix acts like the derivative of the Lagrangian gradient (oracle-free consistency check;
+    # loose because of the reference's pertxf(i)-for-pertxf(j) denominators, LpHessian.cpp:1588,1612)
+    if name in ("bryson_denham", "hypersensitive", "quadrotor"):
+        H = sp.coo_matrix((hv, (hi, hj)), shape=(eng.n, eng.n)).tocsr()
+        H = H + sp.tril(H, -1).T
+        ji, jj = eng.eval_jac_g_structure()
+
+        def grad_l(xx):
+            J = sp.coo_matrix((eng.eval_jac_g(xx), (ji, jj)), shape=(eng.m, eng.n)).tocsr()
+            return sigma * eng.eval_grad_f(xx) + J.T @ lam
+        dx = rng.uniform(-1, 1, eng.n)
+        e = 1e-5
+        fd = (grad_l(x + e * dx) - grad_l(x - e * dx)) / (2 * e)
+        assert np.max(np.abs(H @ dx - fd)) <= 2e-3 * max(1.0, np.max(np.abs(fd)))
+    eng.close()
+
+
+def test_exact_hessian_analytic_first_derivatives(built):
+    opts = _exact()
+    opts.SetStringValue("first-derive", "analytic")
+    prob = problems.hypersensitive([-1, 0, 1], [5, 4], tf=30.0)
+    eng, orc = NLPEngine(prob, opts, device=0), oracle_for(prob, opts)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 2, "uniform")
+    lam = np.linspace(-1, 1, eng.m)
+    hv, hr = eng.eval_h(x, 1.3, lam), orc.eval_h(x, 1.3, lam)
+    assert np.max(np.abs(hv - hr)) <= 1e-9 * max(1.0, np.max(np.abs(hr)))
+    eng.close()

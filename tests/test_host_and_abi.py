@@ -105,7 +105,7 @@ def test_error_reporting_matches_reference_checkers(built):
     with pytest.raises(RpmError) as ei:
         NLPEngine(problems.launch(2, 4), o)
     assert ei.value.code == 2
-    # exact Hessian is a later row: reported, never silently ignored
+    # eval_h on an engine created with limited-memory Hessian (the reference default): reported, never ignored
     e = NLPEngine(problems.brachistochrone())
     with pytest.raises(RpmError) as ei:
         e.eval_h(e.get_starting_point(), 1.0, np.zeros(e.m))
