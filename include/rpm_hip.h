@@ -179,7 +179,12 @@ int rpm_synchronize(rpm_engine* e);
  *                    rpm_eval_jac_g(new_x=0) on the same x returns the cached values; 0: separate kernels
  * "dx_mode"          0: scalar ascending-column D.X (bit-identical to the reference's COO loop,
  *                    SparseMatrix/LpSparseMatrix.cpp:142-153); 1: v_mfma_f64_16x16x4 tiles
- * "tile_nodes"       16 | 32 | 64: collocation nodes per workgroup (0 = choose from grid size)
+ * "tile_nodes"       16 | 32 | 64: collocation nodes per workgroup (0 = default 16)
+ * "check_finite"     1 (default): NaN/Inf in a result -> RPM_E_NONFINITE (checked on the device); 0: lpopc's behaviour
+ * "pin_host"         1 (default): the host-pointer entry points page-lock (hipHostRegister) the caller's x / g /
+ *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —
+ *                    so copies run at PCIe rate; the registrations are released by rpm_destroy.  Set 0 if the
+ *                    caller frees and re-allocates these buffers between calls.
  */
 int rpm_set_option(rpm_engine* e, const char* key, int value);
 int rpm_get_option(rpm_engine* e, const char* key, int* value);

@@ -133,6 +133,7 @@ static int stage_x(Engine& e, int n, const double* x, int new_x) {
   }
   if (new_x) {
     rpm::dev_cache_valid(e) = false;
+    rpm::dev_pin_host(e, x, size_t(e.n_instances) * e.n * sizeof(double));
     return rpm::dev_upload_x(e, x);
   }
   return RPM_OK;
@@ -165,9 +166,10 @@ int rpm_eval_grad_f(rpm_engine* h, int n, const double* x, int new_x, double* gr
   if (rc) return rc;
   rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), rpm::dev_buf(e, 3), rpm::dev_stream(e));
   if (rc) return rc;
+  rpm::dev_pin_host(e, grad_f, size_t(e.n_instances) * e.n * sizeof(double));
   rc = rpm::dev_download(e, grad_f, rpm::dev_buf(e, 3), size_t(e.n_instances) * e.n);
   if (rc) return rc;
-  if (e.opt_check_finite && !all_finite(grad_f, size_t(e.n_instances) * e.n)) return fail(e, RPM_E_NONFINITE, "eval_grad_f: non-finite gradient");
+  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 3), size_t(e.n_instances) * e.n) != 0) return fail(e, RPM_E_NONFINITE, "eval_grad_f: non-finite gradient");
   return RPM_OK;
   RPM_GUARD_END(e)
 }
@@ -185,10 +187,11 @@ int rpm_eval_g(rpm_engine* h, int n, const double* x, int new_x, int m, double* 
   const int flags = e.opt_fuse_pair ? 3 : 1;  // fused: the Jacobian of the same x is produced by the same launch
   rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), flags, rpm::dev_stream(e));
   if (rc) return rc;
+  rpm::dev_pin_host(e, g, size_t(e.n_instances) * e.m * sizeof(double));
   rc = rpm::dev_download(e, g, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m);
   if (rc) return rc;
   rpm::dev_cache_valid(e) = (flags == 3);
-  if (e.opt_check_finite && !all_finite(g, size_t(e.n_instances) * e.m)) return fail(e, RPM_E_NONFINITE, "eval_g: non-finite constraint value");
+  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m) != 0) return fail(e, RPM_E_NONFINITE, "eval_g: non-finite constraint value");
   return RPM_OK;
   RPM_GUARD_END(e)
 }
@@ -214,9 +217,10 @@ int rpm_eval_jac_g(rpm_engine* h, int n, const double* x, int new_x, int m, int 
     rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), 2, rpm::dev_stream(e));
     if (rc) return rc;
   }
+  rpm::dev_pin_host(e, values, size_t(e.n_instances) * e.nnz_jac * sizeof(double));
   rc = rpm::dev_download(e, values, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac);
   if (rc) return rc;
-  if (e.opt_check_finite && !all_finite(values, size_t(e.n_instances) * e.nnz_jac)) return fail(e, RPM_E_NONFINITE, "eval_jac_g: non-finite Jacobian value");
+  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac) != 0) return fail(e, RPM_E_NONFINITE, "eval_jac_g: non-finite Jacobian value");
   return RPM_OK;
   RPM_GUARD_END(e)
 }
@@ -247,9 +251,10 @@ int rpm_eval_h(rpm_engine* h, int n, const double* x, int new_x, double obj_fact
   if (rc) return rc;
   rc = rpm::dev_eval_h(e, rpm::dev_buf(e, 0), obj_factor, rpm::dev_buf(e, 5), rpm::dev_buf(e, 6), rpm::dev_stream(e));
   if (rc) return rc;
+  rpm::dev_pin_host(e, values, size_t(e.n_instances) * e.nnz_h * sizeof(double));
   rc = rpm::dev_download(e, values, rpm::dev_buf(e, 6), size_t(e.n_instances) * e.nnz_h);
   if (rc) return rc;
-  if (e.opt_check_finite && !all_finite(values, size_t(e.n_instances) * e.nnz_h)) return fail(e, RPM_E_NONFINITE, "eval_h: non-finite Hessian value");
+  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 6), size_t(e.n_instances) * e.nnz_h) != 0) return fail(e, RPM_E_NONFINITE, "eval_h: non-finite Hessian value");
   return RPM_OK;
   RPM_GUARD_END(e)
 }
@@ -335,6 +340,7 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   const std::string k(key);
   if (k == "fuse_pair") e.opt_fuse_pair = value ? 1 : 0;
   else if (k == "check_finite") e.opt_check_finite = value ? 1 : 0;
+  else if (k == "pin_host") e.opt_pin_host = value ? 1 : 0;
   else if (k == "dx_mode") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "dx_mode must be 0 (scalar, reference order) or 1 (MFMA)");
     if (value == 1 && e.first_derive == RPM_DERIVE_ANALYTIC)

@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "problems/problems.hpp"
 #include "rpm_engine.hpp"
@@ -80,6 +82,8 @@ struct Device {
   double *d_x = nullptr, *d_g = nullptr, *d_values = nullptr, *d_grad = nullptr, *d_obj = nullptr,
          *d_lambda = nullptr, *d_hess = nullptr;
   double* d_partial = nullptr;  // objective partial sums
+  int* d_flag = nullptr;        // non-finite flag of the host-pointer path
+  std::vector<std::pair<const void*, size_t>> pinned;   // caller buffers registered with hipHostRegister
   bool cache_valid = false;     // d_g / d_values hold the pair of the x last uploaded
   size_t lds_bytes = 0;
   // exact-Hessian tables
@@ -974,6 +978,9 @@ void device_destroy(Engine& e) {
                   d->d_hends, d->d_hlinks, d->d_htiles, d->d_htmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (d->d_flag) (void)hipFree(d->d_flag);
+  for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.first));
+  (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
   for (auto& row : d->segtab)
     for (auto& t : row)
       if (t.ptr) (void)hipFree(t.ptr);
@@ -1177,6 +1184,51 @@ int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, vo
     return RPM_E_DEVICE;
   }
   return RPM_OK;
+}
+
+// ---- non-finite detection on the device (the host-pointer path reports NaN/Inf to Ipopt) ---------
+__global__ void rpm_finite_kernel(const double* __restrict__ v, size_t n, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+    bad |= !isfinite(v[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// 1 if dev[0..count) contains a NaN/Inf (checked on the device, 4 bytes cross PCIe), 0 if not, <0 on error
+int dev_nonfinite(Engine& e, const double* dev, size_t count) {
+  Device& d = *e.dev;
+  if (!d.d_flag) {
+    if (hipMalloc(reinterpret_cast<void**>(&d.d_flag), sizeof(int)) != hipSuccess) return -1;
+  }
+  if (hipMemsetAsync(d.d_flag, 0, sizeof(int), d.stream) != hipSuccess) return -1;
+  unsigned blocks = unsigned((count + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(rpm_finite_kernel, dim3(blocks), dim3(256), 0, d.stream, dev, count, d.d_flag);
+  int h = 0;
+  if (hipMemcpyAsync(&h, d.d_flag, sizeof(int), hipMemcpyDeviceToHost, d.stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(d.stream) != hipSuccess) return -1;
+  return h;
+}
+
+// Page-lock the caller's buffer once (Ipopt hands the same x / g / values arrays every iteration) so that
+// the copies are direct DMA at PCIe rate instead of staged pageable copies.  Best effort: failures are ignored.
+void dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
+  if (!e.opt_pin_host || !ptr || bytes < (64u << 10)) return;
+  Device& d = *e.dev;
+  for (auto& p : d.pinned)
+    if (p.first == ptr && p.second >= bytes) return;
+  for (auto it = d.pinned.begin(); it != d.pinned.end(); ++it)
+    if (it->first == ptr) {   // same address, grew: re-register
+      (void)hipHostUnregister(const_cast<void*>(it->first));
+      (void)hipGetLastError();
+      d.pinned.erase(it);
+      break;
+    }
+  if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
+    d.pinned.emplace_back(ptr, bytes);
+  else
+    (void)hipGetLastError();
 }
 
 // ---- small helpers used by the C ABI (rpm_abi.cpp) ---------------------------------------------

@@ -140,6 +140,7 @@ struct Engine {
   int max_span = 0, max_drow = 0;
   // options
   int opt_fuse_pair = 1, opt_dx_mode = 0, opt_tile_nodes = 0, opt_check_finite = 1, opt_const_once = 0;
+  int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
   std::vector<double> sol_x, sol_lambda;
   double sol_obj = 0.0;
@@ -182,6 +183,8 @@ int dev_download(Engine& e, double* host, const double* dev, size_t count);
 int dev_sync(Engine& e);
 double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 lambda, 6 hess
 bool& dev_cache_valid(Engine& e);
-void* dev_stream(Engine& e);            // the engine's own stream (host-pointer TNLP path)
+void* dev_stream(Engine& e);
+int dev_nonfinite(Engine& e, const double* dev, size_t count);   // 1 if a NaN/Inf is present, checked on the device
+void dev_pin_host(Engine& e, const void* ptr, size_t bytes);       // page-lock a caller buffer once (best effort)            // the engine's own stream (host-pointer TNLP path)
 
 }  // namespace rpm

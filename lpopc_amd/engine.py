@@ -119,6 +119,9 @@ class NLPEngine:
         self._h = h
         if tile_nodes:
             self.set_option("tile_nodes", tile_nodes)
+        # this wrapper returns freshly allocated numpy arrays, so page-locking the caller's buffers (the C ABI's
+        # default, meant for Ipopt's long-lived arrays) would register a new buffer per call: off unless `out=` reuse
+        self.set_option("pin_host", 0)
         n, m, nj, nh, st = (C.c_int() for _ in range(5))
         self._check(self._L.rpm_get_nlp_info(h, C.byref(n), C.byref(m), C.byref(nj), C.byref(nh), C.byref(st)))
         self.n, self.m, self.nnz_jac, self.nnz_h, self.index_style = n.value, m.value, nj.value, nh.value, st.value
@@ -182,9 +185,9 @@ class NLPEngine:
         self._check(self._L.rpm_eval_grad_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
         return out
 
-    def eval_g(self, x, new_x=True):
+    def eval_g(self, x, new_x=True, out=None):
         x = self._x(x)
-        out = np.zeros(self.m * self.n_instances)
+        out = np.zeros(self.m * self.n_instances) if out is None else out
         self._check(self._L.rpm_eval_g(self._h, self.n, _dp(x), int(new_x), self.m, _dp(out)))
         return out
 
@@ -193,9 +196,9 @@ class NLPEngine:
         self._check(self._L.rpm_eval_jac_g(self._h, self.n, None, 0, self.m, self.nnz_jac, _ip(i), _ip(j), None))
         return i, j
 
-    def eval_jac_g(self, x, new_x=True):
+    def eval_jac_g(self, x, new_x=True, out=None):
         x = self._x(x)
-        out = np.zeros(self.nnz_jac * self.n_instances)
+        out = np.zeros(self.nnz_jac * self.n_instances) if out is None else out
         self._check(self._L.rpm_eval_jac_g(self._h, self.n, _dp(x), int(new_x), self.m, self.nnz_jac, None, None, _dp(out)))
         return out
 

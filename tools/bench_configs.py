@@ -1,0 +1,114 @@
+"""All five BASELINE.json configs on one MI355X: parity against the CPU oracle and eval_g+eval_jac_g throughput
+(x resident in HBM, hipGraph replay), next to the single-core CPU oracle; plus the PCIe-inclusive rate of the
+host-pointer (Ipopt) path for the metric config.  Writes one JSON object per config to stdout.
+Run on the GPU box:  python tools/bench_configs.py > gpurun_out/r01_configs.jsonl
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from lpopc_amd import problems
+from lpopc_amd.engine import NLPEngine
+from oracle.oracle import Oracle
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def gpu_rate(eng, xs, B, steps=300):
+    R = xs.shape[0]
+    d_x = torch.from_numpy(xs).cuda()
+    d_g = torch.empty((R, eng.m), dtype=torch.float64, device="cuda")
+    d_v = torch.empty((R, eng.nnz_jac), dtype=torch.float64, device="cuda")
+
+    def step(k):
+        r = (k * B) % R
+        eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
+    for k in range(20):
+        step(k)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(steps):
+            step(k)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    return B * 1e6 / us, us
+
+
+def cpu_rate(orc, x, budget=3.0):
+    orc.eval_g(x); orc.eval_jac_g(x)
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < budget or n < 5:
+        orc.eval_g(x); orc.eval_jac_g(x); n += 1
+    return n / (time.perf_counter() - t0)
+
+
+CONFIGS = [
+    ("1 brachistochrone 1x10 (plumbing)", lambda: problems.brachistochrone(1, 10), 1, "perturb"),
+    ("2 min-time-to-climb 16x16", lambda: problems.min_time_climb(16, 16), 1, "perturb"),
+    ("3 Delta-III 4 phases x 64x16 (metric), 1 iterate/launch", lambda: problems.launch(64, 16), 1, "perturb"),
+    ("3 Delta-III 4 phases x 64x16 (metric), 16 iterates/launch", lambda: problems.launch(64, 16), 16, "perturb"),
+    ("4 hypersensitive hp mesh 4096 nodes", lambda: problems.config("hypersensitive"), 1, "uniform"),
+    ("4 hypersensitive hp mesh 4096 nodes, 16 iterates/launch", lambda: problems.config("hypersensitive"), 16, "uniform"),
+    ("5 quadrotor MPC sweep, 1024 instances x (8x8)", lambda: problems.quadrotor(8, 8), 1024, "perturb"),
+]
+
+
+def main():
+    for name, make, B, mode in CONFIGS:
+        prob = make()
+        one = NLPEngine(prob, device=0)
+        eng = one if B == 1 else NLPEngine(prob, n_instances=B, device=0)
+        orc = Oracle(prob)
+        xl, xu, _, _ = one.get_bounds_info()
+        x0 = one.get_starting_point()
+        R = max(2 * B, 32)
+        while R * (one.nnz_jac + one.m) * 8 < 300e6 and R < 4096 * max(B, 1):
+            R *= 2
+        R -= R % B
+        xs = np.stack([problems.seeded_iterate(x0, xl, xu, 5 + r, mode) for r in range(min(R, 2048))])
+        if xs.shape[0] < R:
+            xs = np.concatenate([xs] * (R // xs.shape[0] + 1))[:R]
+        g, v = one.eval_g(xs[0]), one.eval_jac_g(xs[0], False)
+        rate, us = gpu_rate(eng, xs, B)
+        crate = cpu_rate(orc, xs[0])
+        bytes_pair = 8 * (2 * one.n + one.m + one.nnz_jac) + 8 * sum(one.phase_tables(p)["d_vals"].size for p in range(one.n_phases))
+        out = {"config": name, "n": one.n, "m": one.m, "nnz_jac": one.nnz_jac, "instances_per_launch": B,
+               "gpu_pairs_per_s": rate, "launch_us": us, "cpu_port_pairs_per_s_1core": crate, "speedup": rate / crate,
+               "algorithmic_bytes_per_pair": bytes_pair, "hbm_frac": bytes_pair * rate / 8e12,
+               "parity_eval_g": rel(g, orc.eval_g(xs[0])), "parity_eval_jac_g": rel(v, orc.eval_jac_g(xs[0]))}
+        if name.startswith("3") and B == 1:
+            # host-pointer (Ipopt) path: x up, g down, values down through PCIe every pair
+            # (Ipopt reuses its x / g / values arrays, so they are page-locked once: pin_host = 1)
+            for pin in (0, 1):
+                one.set_option("pin_host", pin)
+                xh = np.ascontiguousarray(xs[:8].copy())
+                gh, vh = np.zeros(one.m), np.zeros(one.nnz_jac)
+                for n in range(8):
+                    one.eval_g(xh[n % 8], True, out=gh); one.eval_jac_g(xh[n % 8], False, out=vh)
+                t0 = time.perf_counter(); n = 0
+                while time.perf_counter() - t0 < 2.0:
+                    one.eval_g(xh[n % 8], True, out=gh); one.eval_jac_g(xh[n % 8], False, out=vh); n += 1
+                out["host_pointer_pairs_per_s_pcie_inclusive" + ("_pinned" if pin else "_pageable")] = n / (time.perf_counter() - t0)
+            one.set_option("pin_host", 0)
+        print(json.dumps(out), flush=True)
+        one.close()
+        if eng is not one:
+            eng.close()
+
+
+if __name__ == "__main__":
+    main()
