@@ -93,7 +93,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # under torch.distributed.run: always go through the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -229,6 +229,7 @@ def main():
                         "fused: one rpm_tile_kernel launch writes g and all Jacobian values of x_k",
                 "launch": "hipGraph replay of the K steps" if graph is not None else "eager launches",
                 "tile_nodes": eng.get_option("tile_nodes"),
+                "thread_layout": "64 nodes x 4 role groups (roles looped)" if eng.get_option("role_loop") else "16 nodes x (nx+nu+2) roles",
                 "dx_mode": "mfma_f64_16x16x4" if args.dx_mode else "scalar, reference summation order",
                 "parallelism": ("intervals sharded x%d + RCCL all-gather" % world) if sharded else
                                ("independent instances x%d" % world),

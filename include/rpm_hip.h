@@ -180,6 +180,8 @@ int rpm_synchronize(rpm_engine* e);
  * "dx_mode"          0: scalar ascending-column D.X (bit-identical to the reference's COO loop,
  *                    SparseMatrix/LpSparseMatrix.cpp:142-153); 1: v_mfma_f64_16x16x4 tiles
  * "tile_nodes"       16 | 32 | 64: collocation nodes per workgroup (0 = default 16)
+ * "role_loop"        -1 (default): automatic, 0: never, 1: always — the throughput thread layout (64 nodes x 4 role
+ *                    groups per workgroup, roles walked sequentially) chosen automatically for large grids
  * "check_finite"     1 (default): NaN/Inf in a result -> RPM_E_NONFINITE (checked on the device); 0: lpopc's behaviour
  * "pin_host"         1 (default): the host-pointer entry points page-lock (hipHostRegister) the caller's x / g /
  *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —

@@ -350,7 +350,21 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
     if (value != 0 && value != 16 && value != 32 && value != 64) return fail(e, RPM_E_INVALID, "tile_nodes must be 0, 16, 32 or 64");
     if (e.dev) return fail(e, RPM_E_INVALID, "tile_nodes must be set before the device is initialised");
     e.opt_tile_nodes = value;
-    if (value) rpm::build_tiles(e, value);
+    if (value) {
+      e.role_looped = false;
+      rpm::build_tiles(e, value);
+    }
+  } else if (k == "role_loop") {
+    if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "role_loop must be -1 (auto), 0 or 1");
+    if (e.dev) return fail(e, RPM_E_INVALID, "role_loop must be set before the device is initialised");
+    e.opt_role_loop = value;
+    if (e.opt_tile_nodes == 0) {   // re-tile with the new policy
+      long long total = 0;
+      for (int i = 0; i < e.P; ++i) total += e.ph[i].N;
+      total *= e.n_instances;
+      e.role_looped = value == 1 || (value == -1 && total / 64 >= 1024);
+      rpm::build_tiles(e, e.role_looped ? 64 : 16);
+    }
   } else
     return fail(e, RPM_E_INVALID, "unknown option");
   return RPM_OK;
@@ -364,6 +378,7 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "dx_mode") *value = e.opt_dx_mode;
   else if (k == "tile_nodes") *value = e.tile_nodes;
   else if (k == "n_tiles") *value = int(e.tiles.size());
+  else if (k == "role_loop") *value = e.role_looped ? 1 : 0;
   else return fail(e, RPM_E_INVALID, "unknown option");
   return RPM_OK;
 }

@@ -509,6 +509,162 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// rpm_tile_rl_kernel ("role-looped"): the throughput variant for large grids (many instances per launch).
+// Same arithmetic and the same output order as rpm_tile_kernel, different thread layout: a workgroup is T nodes x RG
+// role GROUPS, and each thread walks the roles g, g+RG, g+2RG, ... of its node one after another.  With T = 64,
+// RG = 4 a wave is 64 consecutive nodes of ONE role, so every Jacobian store instruction writes 512 contiguous bytes
+// (instead of 4 x 128 B), a launch has 4x fewer workgroups of 4 waves each (one residency round on 256 CUs at 16
+// instances of the metric problem), and each workgroup pays its load chain once for 3 dynamics evaluations per thread.
+template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
+__global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, const double* __restrict__ xall,
+                                                            double* __restrict__ gall, double* __restrict__ vall) {
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
+  constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
+  constexpr int R = WJ ? NV + 1 : (NX > 0 ? NX : 1);
+  constexpr int NCs = NC > 0 ? NC : 1;
+  constexpr int NTHR = T * RG;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const double* __restrict__ x = xall + size_t(blockIdx.y) * K.n;
+  double* __restrict__ g = gall + size_t(blockIdx.y) * K.m;
+  double* __restrict__ vals = vall + size_t(blockIdx.y) * K.nnz;
+  if (int(blockIdx.x) >= K.n_my_tiles) {
+    endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
+    return;
+  }
+  const int nt = K.n_my_tiles, per = nt >> 3, rem = nt & 7, xcd = int(blockIdx.x) & 7, slot = int(blockIdx.x) >> 3;
+  const TileDev tl = K.tiles[xcd * per + (xcd < rem ? xcd : rem) + slot];
+  const TileDev& ph = tl;
+  const double* __restrict__ c = K.consts;
+  double* Xs = lds;
+  double* Us = Xs + NX * K.max_span;
+  double* Ds = Us + NU * T;
+  double* Fb = Ds + K.max_drow;
+  const int kk = tid % T, grp = tid / T;
+  const int kc = kk < tl.cnt ? kk : tl.cnt - 1;
+  const int k = tl.k0 + kc;
+  const int nidx = ph.node0 + k;
+  const double tau = K.points[nidx];
+  const NodeDev nd = K.nodes[nidx];
+  const double ddiag = WJ ? K.diag[nidx] : 0.0;
+  for (int q = tid; q < NX * tl.span_len; q += NTHR) {
+    const int i = q / tl.span_len, r = q - i * tl.span_len;
+    Xs[i * K.max_span + r] = x[ph.x_state0 + i * (ph.N + 1) + tl.span0 + r];
+  }
+  for (int q = tid; q < NU * tl.cnt; q += NTHR) {
+    const int j = q / tl.cnt, r = q - j * tl.cnt;
+    Us[j * T + r] = x[ph.x_control0 + j * ph.N + tl.k0 + r];
+  }
+  if (WG)
+    for (int q = tid; q < tl.drow_len; q += NTHR) Ds[q] = K.dvals[tl.drow0 + q];
+  const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+  __syncthreads();
+
+  const bool node_ok = kk < tl.cnt;
+  const double tspan = tf - t0;
+  const double tk0 = (tau + 1) * (tspan / 2.0) + t0;      // LpNLPWrapper.cpp:80
+  const int N = ph.N;
+  bool first = true;
+  for (int role = grp; role < R || first; role += RG) {
+    const bool act = node_ok && role < R;
+    double xs[NX > 0 ? NX : 1], us[NU > 0 ? NU : 1];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - tl.span0)];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) us[j] = Us[j * T + kc];
+    double tk = tk0;
+    const int sv = WJ ? role - 1 : role;
+    double dx = 0.0;
+    if (WG && sv >= 0 && sv < NX) {   // D.X in the reference's ascending-column order (LpSparseMatrix.cpp:142-153)
+      const double* drow = Ds + (nd.drow_off - tl.drow0);
+      const double* xcol = Xs + sv * K.max_span + (nd.dcol0 - tl.span0);
+      for (int j = 0; j < nd.dlen; ++j) dx += drow[j] * xcol[j];
+    }
+    double h = 1.0;
+    const int v = role - 1;
+    if (WJ && !AN && role >= 1) {     // h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214)
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (v == i) { h = K.tol * (1 + fabs(xs[i])); xs[i] += h; }
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        if (v == NX + j) { h = K.tol * (1 + fabs(us[j])); us[j] += h; }
+      if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
+    }
+    double f[NX > 0 ? NX : 1], cp[NCs];
+    if (!AN || role == 0) {
+      Prob::dae(ph.phase_num, tk, xs, us, c, f, cp);
+    } else if constexpr (AN) {
+      Prob::dae_jac_col(ph.phase_num, v, tk, xs, us, c, f, cp);
+    }
+    if (first) {   // wave-uniform: the first pass publishes the unperturbed outputs before anyone forms a difference
+      if (role == 0 && act) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Fb[i * T + kk] = f[i];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          Fb[(NX + j) * T + kk] = cp[j];
+          if (WG) g[ph.g0 + (NX + j) * N + k] = cp[j];           // path rows, :138-164
+        }
+      }
+      __syncthreads();
+      first = false;
+    }
+    if (act) {
+      if (WG && sv >= 0 && sv < NX) g[ph.g0 + sv * N + k] = dx - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
+      if (WJ && role >= 1) {
+        double J[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          const double pert = o < NX ? f[o < NX ? o : 0] : cp[o >= NX ? o - NX : 0];
+          J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
+        }
+        double* vb = vals + ph.v_nl0 + k;
+        if (v < NX + NU) {            // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
+#pragma unroll
+          for (int o = 0; o < NO; ++o) {
+            double val;
+            if (o < NX) {
+              const double ret = J[o] * (tf - t0) / 2.0;
+              val = (o == v) ? ddiag - ret : -ret;
+            } else {
+              val = J[o];
+            }
+            vb[size_t(o * NB + v) * N] = val;
+          }
+        } else {                       // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign kept
+          const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
+#pragma unroll
+          for (int o = 0; o < NO; ++o) {
+            double v0, vf;
+            if (o < NX) {
+              const double fb = Fb[o * T + kk];
+              const double dt = J[o] * (tf - t0) / 2.0;
+              v0 = fb * (0.5) - a0 * dt;
+              vf = -fb * (0.5) + af * dt;
+            } else {
+              v0 = a0 * J[o];
+              vf = af * J[o];
+            }
+            vb[size_t(o * NB + NX + NU) * N] = v0;
+            vb[size_t(o * NB + NX + NU + 1) * N] = vf;
+          }
+        }
+      }
+    }
+  }
+  if (WJ) {   // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718)
+    const double* __restrict__ src = K.doff_vals + tl.c_src0;
+    double* __restrict__ dst = vals + tl.c_dst0;
+    for (int q = tid; q < tl.c_cnt; q += NTHR) {
+      const double dv = src[q];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = dv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Objective and gradient.  One workgroup per phase; thread = node (strided).  Sums use a fixed
 // binary tree over the workgroup so the result is deterministic (independent of timing).
 template <class Prob, bool GRAD, bool AN>
@@ -1102,9 +1258,35 @@ static hipError_t launch_tile_inst(const Engine& e, const double* dx, double* dg
   return hipGetLastError();
 }
 
+template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
+static hipError_t launch_tile_rl(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
+  const Device& d = *e.dev;
+  auto kern = rpm_tile_rl_kernel<Prob, T, RG, WG, WJ, AN>;
+  if (d.lds_bytes > 64 * 1024) {
+    hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(d.lds_bytes));
+    if (s != hipSuccess) return s;
+  }
+  dim3 grid(unsigned(d.kp.n_my_tiles + d.kp.n_tasks), unsigned(e.n_instances));
+  hipLaunchKernelGGL(kern, grid, dim3(T * RG), d.lds_bytes, st, d.kp, dx, dg, dv);
+  return hipGetLastError();
+}
+
 template <class Prob, int T>
 static hipError_t launch_tile_T(const Engine& e, bool wg, bool wj, const double* dx, double* dg, double* dv,
                                 hipStream_t st) {
+  if (e.role_looped && T == 64 && e.opt_dx_mode == 0) {   // throughput layout (see rpm_tile_rl_kernel)
+    const bool an_rl = e.first_derive == RPM_DERIVE_ANALYTIC;
+    if constexpr (Prob::HAS_ANALYTIC) {
+      if (an_rl) {
+        if (wg && wj) return launch_tile_rl<Prob, 64, 4, true, true, true>(e, dx, dg, dv, st);
+        if (wj) return launch_tile_rl<Prob, 64, 4, false, true, true>(e, dx, dg, dv, st);
+      }
+    }
+    if (wg && wj) return launch_tile_rl<Prob, 64, 4, true, true, false>(e, dx, dg, dv, st);
+    if (wj) return launch_tile_rl<Prob, 64, 4, false, true, false>(e, dx, dg, dv, st);
+    return launch_tile_rl<Prob, 64, 4, true, false, false>(e, dx, dg, dv, st);
+  }
   const bool an = e.first_derive == RPM_DERIVE_ANALYTIC;
   if constexpr (Prob::HAS_ANALYTIC) {
     if (an) {

@@ -137,9 +137,11 @@ struct Engine {
   std::vector<NodeDev> nodes;                      // all phases concatenated
   std::vector<double> points, weights, diag, dvals, doff_vals;
   int tile_nodes = 16;
+  bool role_looped = false;   // T = 64 nodes x 4 role groups, roles walked sequentially (large grids)
   int max_span = 0, max_drow = 0;
   // options
   int opt_fuse_pair = 1, opt_dx_mode = 0, opt_tile_nodes = 0, opt_check_finite = 1, opt_const_once = 0;
+  int opt_role_loop = -1;        // -1 automatic, 0 never, 1 always (when tile_nodes is automatic)
   int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
   std::vector<double> sol_x, sol_lambda;

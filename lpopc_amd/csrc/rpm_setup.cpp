@@ -187,7 +187,7 @@ static int bad(Engine& e, int code, const std::string& msg) {
 void build_tiles(Engine& e, int T) {
   // a workgroup is T nodes x (nx+nu+2) roles and may not exceed 1024 threads
   ProblemDims dims;
-  if (problem_dims(e.problem_id, &dims))
+  if (!e.role_looped && problem_dims(e.problem_id, &dims))   // the role-looped layout is always T x 4 threads
     while (T > 16 && T * (dims.nx + dims.nu + 2) > 1024) T /= 2;
   e.tile_nodes = T;
   e.tiles.clear();
@@ -571,10 +571,22 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     e.dvals.insert(e.dvals.end(), p.drows.begin(), p.drows.end());
     e.doff_vals.insert(e.doff_vals.end(), p.off_v.begin(), p.off_v.end());
   }
-  // tiling: nodes per workgroup.  16 measured best at every batch size on MI355X:
-  // small workgroups keep five of them resident per CU, which hides each one's load->compute->store chain.
+  // tiling.  Small grids (one iterate per launch): 16 nodes x (nx+nu+2) roles per workgroup, every role its own
+  // thread — shortest critical path.  Large grids (>= 4 workgroups per CU even with 64-node tiles): the role-looped
+  // layout, 64 nodes x 4 role groups (rpm_tile_rl_kernel) — 512-byte store runs, one residency round.
   int T = e.opt_tile_nodes;
-  if (T != 16 && T != 32 && T != 64) T = 16;
+  e.role_looped = false;
+  if (T != 16 && T != 32 && T != 64) {
+    long long total = 0;
+    for (int i = 0; i < e.P; ++i) total += e.ph[i].N;
+    total *= e.n_instances;
+    if (e.opt_role_loop != 0 && (e.opt_role_loop == 1 || total / 64 >= 1024)) {
+      T = 64;
+      e.role_looped = true;
+    } else {
+      T = 16;
+    }
+  }
   build_tiles(e, T);
   return RPM_OK;
 }

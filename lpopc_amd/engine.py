@@ -109,7 +109,7 @@ class NLPEngine:
     tensors (used only as HBM handles)."""
 
     def __init__(self, problem, options=None, n_instances=1, shard_mode=0, shard_rank=0, shard_world=1,
-                 tile_nodes=0, device=None):
+                 tile_nodes=0, device=None, role_loop=None):
         self._L = lib()
         self._desc, self._keep = _abi.lower(problem, options, n_instances, shard_mode, shard_rank, shard_world)
         h = C.c_void_p()
@@ -119,6 +119,8 @@ class NLPEngine:
         self._h = h
         if tile_nodes:
             self.set_option("tile_nodes", tile_nodes)
+        if role_loop is not None:
+            self.set_option("role_loop", role_loop)
         # this wrapper returns freshly allocated numpy arrays, so page-locking the caller's buffers (the C ABI's
         # default, meant for Ipopt's long-lived arrays) would register a new buffer per call: off unless `out=` reuse
         self.set_option("pin_host", 0)

@@ -303,3 +303,38 @@ def test_exact_hessian_analytic_first_derivatives(built):
     hv, hr = eng.eval_h(x, 1.3, lam), orc.eval_h(x, 1.3, lam)
     assert np.max(np.abs(hv - hr)) <= 1e-9 * max(1.0, np.max(np.abs(hr)))
     eng.close()
+
+
+@pytest.mark.parametrize("name,make,mode", [CASES[3], CASES[5], CASES[6], CASES[7]], ids=[CASES[i][0] for i in (3, 5, 6, 7)])
+def test_role_looped_layout_is_bit_identical(built, name, make, mode):
+    """The throughput thread layout (64 nodes x 4 role groups, rpm_tile_rl_kernel) computes exactly the same numbers
+    as the one-role-per-thread layout, for g, the Jacobian, batched instances and the analytic mode."""
+    import torch
+    prob = make()
+    a = NLPEngine(prob, device=0, role_loop=0)
+    b = NLPEngine(prob, device=0, role_loop=1)
+    assert b.get_option("role_loop") == 1 and b.get_option("tile_nodes") == 64 and a.get_option("tile_nodes") == 16
+    xl, xu, _, _ = a.get_bounds_info()
+    x = problems.seeded_iterate(a.get_starting_point(), xl, xu, 23, mode)
+    assert np.array_equal(a.eval_g(x), b.eval_g(x))
+    assert np.array_equal(a.eval_jac_g(x, False), b.eval_jac_g(x, False))
+    b.set_option("fuse_pair", 0)
+    assert np.array_equal(a.eval_g(x), b.eval_g(x)) and np.array_equal(a.eval_jac_g(x), b.eval_jac_g(x))
+    B = 5
+    many = NLPEngine(prob, n_instances=B, device=0, role_loop=1)
+    xs = np.stack([problems.seeded_iterate(a.get_starting_point(), xl, xu, 40 + i, mode) for i in range(B)])
+    dg = torch.empty((B, a.m), dtype=torch.float64, device="cuda")
+    dv = torch.empty((B, a.nnz_jac), dtype=torch.float64, device="cuda")
+    many.eval_pair_dev(torch.from_numpy(xs).cuda(), dg, dv)
+    torch.cuda.synchronize()
+    for i in (0, B - 1):
+        assert np.array_equal(dg[i].cpu().numpy(), a.eval_g(xs[i])) and np.array_equal(dv[i].cpu().numpy(), a.eval_jac_g(xs[i], False))
+    for e_ in (a, b, many):
+        e_.close()
+    if name == "hypersensitive_hp":
+        opts = Options()
+        opts.SetStringValue("first-derive", "analytic")
+        a2, b2 = NLPEngine(prob, opts, device=0, role_loop=0), NLPEngine(prob, opts, device=0, role_loop=1)
+        assert np.array_equal(a2.eval_g(x), b2.eval_g(x)) and np.array_equal(a2.eval_jac_g(x), b2.eval_jac_g(x))
+        a2.close()
+        b2.close()
