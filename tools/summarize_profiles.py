@@ -16,17 +16,18 @@ os.makedirs(out, exist_ok=True)
 
 
 def one(pattern):
-    fs = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
-    return fs[0] if fs else None
+    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)), key=os.path.getmtime)
+    return fs[-1] if fs else None
 
 
 stats = one("%s_stats/*/*kernel_stats.csv" % tag)
 shutil.copy(stats, os.path.join(out, "%s_kernel_stats.csv" % tag))
 summary = {"tag": tag, "command": "python3 bench.py --profile --steps 200 --warmup 20 (default workload: batch 16, tile 16)"}
 for r in csv.DictReader(open(stats)):
-    if "rpm_tile_kernel" in r["Name"]:
-        summary["rpm_tile_kernel_calls"] = int(r["Calls"])
-        summary["rpm_tile_kernel_avg_us"] = float(r["AverageNs"]) / 1e3
+    if "rpm_tile" in r["Name"]:   # rpm_tile_kernel or its role-looped layout rpm_tile_rl_kernel
+        summary["dominant_kernel"] = r["Name"].split("<")[0].split("::")[-1]
+        summary["dominant_kernel_calls"] = int(r["Calls"])
+        summary["dominant_kernel_avg_us"] = float(r["AverageNs"]) / 1e3
 pmc = {}
 for sub in ("fetch", "write", "sq"):
     f = one("%s_%s/*/*counter_collection.csv" % (tag, sub))
@@ -34,7 +35,7 @@ for sub in ("fetch", "write", "sq"):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "rpm_tile_kernel" in r["Kernel_Name"]:
+        if "rpm_tile" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         pmc[k] = sum(v) / len(v)
