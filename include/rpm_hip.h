@@ -157,6 +157,19 @@ int rpm_finalize_solution(rpm_engine* e, int status, int n, const double* x, con
                           double obj_value);
 int rpm_get_solution(rpm_engine* e, int n, double* x, int m, double* lambda, double* obj_value);
 
+/* ---- solution extraction (the step after the NLP solve) -----------------------
+ * Nlp2OpConverter::Nlp2OpControl, Core/Nlp2OPConverter.cpp:13-196, for one phase: time, states, controls (with the
+ * spline-extrapolated value at tau=+1 appended), costates -W^-1 lambda (and -D(:,N)' lambda at the end point), path
+ * multipliers, Hamiltonian, Mayer and Lagrange cost.  Outputs are host arrays with N+1 rows, column-major; any may
+ * be NULL.  x / lambda are host arrays; NULL = the solution stored by rpm_finalize_solution.  The time/state/
+ * control arrays are also what the reference installs as the next mesh's guess (:149-193). */
+int rpm_nlp2op_control(rpm_engine* e, int phase, const double* x, const double* lambda, double* time, double* state,
+                       double* control, double* costate, double* pathmult, double* hamiltonian, double* mayer_cost,
+                       double* lagrange_cost);
+/* Nlp2OpConverter::FinalResultSave, Core/Nlp2OPConverter.cpp:198-223: writes time<k>, state<k>, control<k>, parameter<k>,
+ * costate<k>, Hamiltonian<k> (Armadillo raw_ascii: one row per line) for every phase k into `dir`. */
+int rpm_final_result_save(rpm_engine* e, const char* dir);
+
 /* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
  *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
  *      engine's device; `stream` is a hipStream_t with HIP's own meaning (NULL = the legacy

@@ -2,7 +2,9 @@
 // the TNLP value/structure protocol (Core/LpopcIpopt.cpp:11-246), host<->device staging for
 // the host-pointer path, and error capture (no exception leaves this file).
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -281,6 +283,56 @@ int rpm_get_solution(rpm_engine* h, int n, double* x, int m, double* lambda, dou
   if (lambda) std::memcpy(lambda, e.sol_lambda.data(), sizeof(double) * m);
   if (obj_value) *obj_value = e.sol_obj;
   return RPM_OK;
+}
+
+// ---- solution extraction --------------------------------------------------
+int rpm_nlp2op_control(rpm_engine* h, int phase, const double* x, const double* lambda, double* time, double* state,
+                       double* control, double* costate, double* pathmult, double* hamiltonian, double* mayer_cost,
+                       double* lagrange_cost) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (phase < 0 || phase >= e.P) return fail(e, RPM_E_INVALID, "The phase index is out of rang");
+  if (e.n_instances != 1) return fail(e, RPM_E_UNSUPPORTED, "nlp2op_control: one instance per engine");
+  if (!x || !lambda) {   // Data_->nlpreturn_x / nlpreturn_lambda, stored by finalize_solution
+    if (!e.has_solution) return fail(e, RPM_E_INVALID, "nlp2op_control: no x/lambda given and no solution stored");
+    x = e.sol_x.data();
+    lambda = e.sol_lambda.data();
+  }
+  return rpm::dev_nlp2op(e, phase, x, lambda, time, state, control, costate, pathmult, hamiltonian, mayer_cost, lagrange_cost);
+  RPM_GUARD_END(e)
+}
+
+int rpm_final_result_save(rpm_engine* h, const char* dir) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (!e.has_solution) return fail(e, RPM_E_INVALID, "final_result_save: no solution stored (call rpm_finalize_solution first)");
+  const std::string base = (dir && *dir) ? std::string(dir) + "/" : std::string();
+  for (int ip = 0; ip < e.P; ++ip) {
+    const rpm::PhaseHost& p = e.ph[ip];
+    const int M = p.N + 1;
+    std::vector<double> t(M), st(size_t(M) * p.nx), ct(size_t(M) * (p.nu ? p.nu : 1)), cs(size_t(M) * p.nx), ham(M);
+    int rc = rpm::dev_nlp2op(e, ip, e.sol_x.data(), e.sol_lambda.data(), t.data(), st.data(), ct.data(), cs.data(), nullptr,
+                             ham.data(), nullptr, nullptr);
+    if (rc) return rc;
+    // Armadillo raw_ascii: one row per line, scientific notation (arma::diskio::save_raw_ascii)
+    auto save = [&](const char* stem, const double* a, int rows, int cols) -> bool {
+      FILE* f = std::fopen((base + stem + std::to_string(ip + 1)).c_str(), "w");
+      if (!f) return false;
+      for (int r = 0; r < rows; ++r) {
+        for (int c = 0; c < cols; ++c) std::fprintf(f, " %24.16e", a[r + size_t(c) * rows]);
+        std::fputc('\n', f);
+      }
+      std::fclose(f);
+      return true;
+    };
+    if (!save("time", t.data(), M, 1) || !save("state", st.data(), M, p.nx) || !save("control", ct.data(), M, p.nu) ||
+        !save("parameter", nullptr, 0, 0) || !save("costate", cs.data(), M, p.nx) || !save("Hamiltonian", ham.data(), M, 1))
+      return fail(e, RPM_E_INVALID, "final_result_save: cannot write the result files");
+  }
+  return RPM_OK;
+  RPM_GUARD_END(e)
 }
 
 // ---- device-resident variants ----------------------------------------------------------------

@@ -1094,6 +1094,121 @@ __global__ void rpm_hess_end_kernel(const KParams K, const HParams Hp, const dou
 }
 
 // ------------------------------------------------------------------------------------------
+// Solution extraction: Nlp2OpConverter::Nlp2OpControl, Core/Nlp2OPConverter.cpp:13-196.
+// Runs once per mesh after the NLP solve, not per iteration.
+// rpm_post_spline_kernel: value at tau = +1 of the natural cubic spline through (tau_k, y_k), one thread per column
+// (LpGuessChecker::spline_interpolation, Core/LpGuessChecker.cpp:208-270, specialised to the last interval: only the
+// forward recurrence's final z is needed because c[n-1] = 0).
+__global__ void rpm_post_spline_kernel(int N, const double* __restrict__ tau, const double* __restrict__ cols, int ncols,
+                                       double scale_num, double scale_den, const double* __restrict__ w,
+                                       double* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  const double* y = cols + size_t(col) * N;
+  // optional scaling y_k -> scale_num * (1/w_k) * y_k / scale_den  (path multipliers, Nlp2OPConverter.cpp:92)
+  auto Y = [&](int k) -> double { return w ? scale_num * ((1 / w[k]) * y[k]) / scale_den : y[k]; };
+  double mu = 0.0, z = 0.0;
+  for (int i = 1; i < N - 1; ++i) {
+    const double him1 = tau[i] - tau[i - 1], hi = tau[i + 1] - tau[i];
+    const double alpha = 3.0 / hi * (Y(i + 1) - Y(i)) - 3.0 / him1 * (Y(i) - Y(i - 1));
+    const double li = 2 * (tau[i + 1] - tau[i - 1]) - him1 * mu;
+    mu = hi / li;
+    z = (alpha - him1 * z) / li;
+  }
+  const double d2l = (N - 2 >= 1) ? 2 * z : 0.0;   // c[n-2] = z[n-2] - mu[n-2]*c[n-1], doubled for interior knots
+  const double h = tau[N - 1] - tau[N - 2];
+  const double A = (tau[N - 1] - 1.0) / h, B = (1.0 - tau[N - 2]) / h;
+  const double Cc = (pow(A, 3.0) - A) * (h * h) / 6.0, Dd = (pow(B, 3.0) - B) * (h * h) / 6.0;
+  out[col] = A * Y(N - 2) + B * Y(N - 1) + Cc * d2l + Dd * 0.0;
+}
+
+template <class Prob>
+__global__ void rpm_post_kernel(const KParams K, int phase, const double* __restrict__ x, const double* __restrict__ lam,
+                                const double* __restrict__ u_end, const double* __restrict__ pm_end,
+                                double* __restrict__ o_time, double* __restrict__ o_state, double* __restrict__ o_control,
+                                double* __restrict__ o_costate, double* __restrict__ o_pathmult,
+                                double* __restrict__ o_ham, double* __restrict__ o_lag, double* __restrict__ o_mayer) {
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
+  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1, NCs = NC > 0 ? NC : 1;
+  const PhaseDev ph = K.phases[phase];
+  const int N = ph.N, M = N + 1;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+  const double tau = k < N ? K.points[ph.node0 + k] : 1.0;
+  const double t = (tf - t0) * (tau + 1) / 2 + t0;                       // :49
+  o_time[k] = t;
+  double xs[NXs], us[NUs], cst[NXs];
+#pragma unroll
+  for (int s = 0; s < NX; ++s) {
+    xs[s] = x[ph.x_state0 + s * M + k];
+    o_state[s * M + k] = xs[s];
+  }
+#pragma unroll
+  for (int j = 0; j < NU; ++j) {
+    us[j] = k < N ? x[ph.x_control0 + j * N + k] : u_end[j];             // :53-64
+    o_control[j * M + k] = us[j];
+  }
+  const double* lp = lam + ph.g0;                                       // this phase's multipliers, :73
+#pragma unroll
+  for (int s = 0; s < NX; ++s) {
+    if (k < N) {
+      cst[s] = -((1 / K.weights[ph.node0 + k]) * lp[s * N + k]);         // -(W^-1 lambda), :75-79
+    } else {
+      // -trans(D(:,N)) * lambda: only the rows of the last mesh interval reach the last column
+      const NodeDev last = K.nodes[ph.node0 + N - 1];
+      double acc = 0.0;
+      for (int r = last.dcol0; r < N; ++r) {
+        const NodeDev nr = K.nodes[ph.node0 + r];
+        acc += K.dvals[nr.drow_off + nr.dlen - 1] * lp[s * N + r];
+      }
+      cst[s] = -acc;
+    }
+    o_costate[s * M + k] = cst[s];
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j)   // lambda WITHOUT the phase offset, exactly as Nlp2OPConverter.cpp:88 reads it
+    o_pathmult[j * M + k] = k < N ? 2 * ((1 / K.weights[ph.node0 + k]) * lam[N * NX + j * N + k]) / (tf - t0) : pm_end[j];
+  double f[NXs], cp[NCs];
+  Prob::dae(ph.phase_num, t, xs, us, K.consts, f, cp);
+  const double L = Prob::lagrange(ph.phase_num, t, xs, us, K.consts);
+  double sum = 0.0;
+#pragma unroll
+  for (int s = 0; s < NX; ++s) {
+    const double term = cst[s] * f[s];
+    sum = (s == 0) ? term : sum + term;
+  }
+  o_ham[k] = L + sum;                                                    // :146
+  o_lag[k] = L;
+  if (k == 0) {
+    double x0[NXs], xf[NXs];
+#pragma unroll
+    for (int s = 0; s < NX; ++s) {
+      x0[s] = x[ph.x_state0 + s * M];
+      xf[s] = x[ph.x_state0 + s * M + N];
+    }
+    o_mayer[0] = Prob::mayer(ph.phase_num, t0, x0, tf, xf, K.consts);
+  }
+}
+
+// lagrange_cost = (tf-t0) * (w . L[0..N-1]) / 2  (:134), fixed-tree sum
+__global__ void rpm_post_cost_kernel(const KParams K, int phase, const double* __restrict__ x,
+                                     const double* __restrict__ lag, double* __restrict__ out) {
+  __shared__ double red[256];
+  const PhaseDev ph = K.phases[phase];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  for (int k = tid; k < ph.N; k += 256) s += K.weights[ph.node0 + k] * lag[k];
+  red[tid] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = (x[ph.x_t0 + 1] - x[ph.x_t0]) * red[0] / 2.0;
+}
+
+// ------------------------------------------------------------------------------------------
 // problem registry
 template <class F>
 static bool with_problem(int id, F&& fn) {
@@ -1609,6 +1724,72 @@ int dev_eval_h(Engine& e, const double* d_x, double obj_factor, const double* d_
   });
   if (s != hipSuccess) {
     e.err = std::string("rpm_hess_kernel launch: ") + hipGetErrorString(s);
+    return RPM_E_DEVICE;
+  }
+  return RPM_OK;
+}
+
+// Nlp2OpControl for one phase: host x / lambda in, (N+1)-row column-major host arrays out (any may be NULL)
+int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, double* time, double* state, double* control,
+               double* costate, double* pathmult, double* hamiltonian, double* mayer_cost, double* lagrange_cost) {
+  if (!e.dev) {
+    int rc = device_init(e, 0);
+    if (rc) return rc;
+  }
+  Device& d = *e.dev;
+  HIP_TRY(e, hipSetDevice(d.device_id));
+  const PhaseHost& p = e.ph[phase];
+  const int N = p.N, M = N + 1, nx = p.nx, nu = p.nu, nc = p.nc;
+  const size_t out_doubles = size_t(M) * (3 + 2 * nx + nu + nc) + 8 + nu + nc;
+  double* buf = nullptr;
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&buf), out_doubles * sizeof(double)));
+  double* o_time = buf;
+  double* o_state = o_time + M;
+  double* o_control = o_state + size_t(M) * nx;
+  double* o_costate = o_control + size_t(M) * nu;
+  double* o_pathmult = o_costate + size_t(M) * nx;
+  double* o_ham = o_pathmult + size_t(M) * nc;
+  double* o_lag = o_ham + M;
+  double* o_scal = o_lag + M;          // [0] mayer, [1] lagrange cost
+  double* u_end = o_scal + 8;
+  double* pm_end = u_end + nu;
+  int rc = dev_upload(e, d.d_x, x, size_t(e.n));
+  if (rc == RPM_OK) rc = dev_upload(e, d.d_lambda, lambda, size_t(e.m));
+  hipError_t s = hipSuccess;
+  if (rc == RPM_OK) {
+    hipStream_t st = d.stream;
+    const PhaseDev& q = e.phd[phase];
+    const double tspan = x[q.x_t0 + 1] - x[q.x_t0];
+    if (nu > 0)
+      hipLaunchKernelGGL(rpm_post_spline_kernel, dim3(1), dim3(64), 0, st, N, d.d_points + q.node0, d.d_x + q.x_control0, nu,
+                         1.0, 1.0, static_cast<const double*>(nullptr), u_end);
+    if (nc > 0)
+      hipLaunchKernelGGL(rpm_post_spline_kernel, dim3(1), dim3(64), 0, st, N, d.d_points + q.node0,
+                         d.d_lambda + size_t(N) * nx, nc, 2.0, tspan, d.d_weights + q.node0, pm_end);
+    with_problem(e.problem_id, [&](auto prob) {
+      using P = decltype(prob);
+      hipLaunchKernelGGL((rpm_post_kernel<P>), dim3(unsigned((M + 255) / 256)), dim3(256), 0, st, d.kp, phase, d.d_x, d.d_lambda,
+                         u_end, pm_end, o_time, o_state, o_control, o_costate, o_pathmult, o_ham, o_lag, o_scal);
+    });
+    hipLaunchKernelGGL(rpm_post_cost_kernel, dim3(1), dim3(256), 0, st, d.kp, phase, d.d_x, o_lag, o_scal + 1);
+    s = hipGetLastError();
+    if (s == hipSuccess) s = hipStreamSynchronize(st);
+    auto get = [&](double* host, const double* dev, size_t cnt) {
+      if (host && cnt && s == hipSuccess) s = hipMemcpy(host, dev, cnt * sizeof(double), hipMemcpyDeviceToHost);
+    };
+    get(time, o_time, M);
+    get(state, o_state, size_t(M) * nx);
+    get(control, o_control, size_t(M) * nu);
+    get(costate, o_costate, size_t(M) * nx);
+    get(pathmult, o_pathmult, size_t(M) * nc);
+    get(hamiltonian, o_ham, M);
+    get(mayer_cost, o_scal, 1);
+    get(lagrange_cost, o_scal + 1, 1);
+  }
+  (void)hipFree(buf);
+  if (rc) return rc;
+  if (s != hipSuccess) {
+    e.err = std::string("nlp2op: ") + hipGetErrorString(s);
     return RPM_E_DEVICE;
   }
   return RPM_OK;

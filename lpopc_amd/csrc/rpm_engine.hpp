@@ -164,6 +164,9 @@ void build_hessian_tables(Engine& e);
 int ensure_hessian(Engine& e);
 int dev_eval_h(Engine& e, const double* d_x, double obj_factor, const double* d_lambda, double* d_values, void* stream);
 
+int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, double* time, double* state, double* control,
+               double* costate, double* pathmult, double* hamiltonian, double* mayer_cost, double* lagrange_cost);
+
 // rpm_shard.cpp: rank's contiguous runs of g (which=0) or of the Jacobian values (which=1)
 std::vector<rpm_segment> shard_segments(const Engine& e, int which, int rank, int* packed_len);
 int dev_shard_copy(Engine& e, int which, bool pack, const double* src, int stride, double* dst, void* stream);

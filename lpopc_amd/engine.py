@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "rpm_eval_jac_g", "rpm_eval_h", "rpm_finalize_solution", "rpm_get_solution", "rpm_eval_g_dev",
     "rpm_eval_jac_g_dev", "rpm_eval_pair_dev", "rpm_eval_f_dev", "rpm_eval_grad_f_dev", "rpm_eval_h_dev",
     "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_get_phase_sizes", "rpm_get_phase_tables",
-    "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev",
+    "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
 ]
 
 
@@ -82,6 +82,8 @@ def lib():
     L.rpm_get_option.argtypes = [vp, C.c_char_p, ip]
     L.rpm_get_phase_sizes.argtypes = [vp, C.c_int, ip, ip, ip]
     L.rpm_get_phase_tables.argtypes = [vp, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
+    L.rpm_nlp2op_control.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.rpm_final_result_save.argtypes = [vp, C.c_char_p]
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
     L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -262,6 +264,27 @@ class NLPEngine:
 
     def synchronize(self):
         self._check(self._L.rpm_synchronize(self._h))
+
+    # ---- solution extraction (Nlp2OpConverter) ----------------------------------------
+    def nlp2op_control(self, phase, x=None, lam=None):
+        d = self._desc.phases[phase]
+        M = self.phase_tables(phase)["points"].size + 1
+        out = dict(time=np.zeros(M), state=np.zeros(M * d.nx), control=np.zeros(M * max(d.nu, 1)),
+                   costate=np.zeros(M * d.nx), pathmult=np.zeros(M * max(d.nc, 1)), hamiltonian=np.zeros(M))
+        mc, lc = C.c_double(), C.c_double()
+        xp = _dp(self._x(x)) if x is not None else None
+        lp = _dp(np.ascontiguousarray(lam, dtype=np.float64)) if lam is not None else None
+        self._check(self._L.rpm_nlp2op_control(self._h, phase, xp, lp, _dp(out["time"]), _dp(out["state"]),
+                                               _dp(out["control"]), _dp(out["costate"]), _dp(out["pathmult"]),
+                                               _dp(out["hamiltonian"]), C.cast(C.byref(mc), C.POINTER(C.c_double)),
+                                               C.cast(C.byref(lc), C.POINTER(C.c_double))))
+        out["control"] = out["control"][:M * d.nu]
+        out["pathmult"] = out["pathmult"][:M * d.nc]
+        out["mayer_cost"], out["lagrange_cost"] = mc.value, lc.value
+        return out
+
+    def final_result_save(self, directory):
+        self._check(self._L.rpm_final_result_save(self._h, str(directory).encode()))
 
     # ---- tables and sharding ---------------------------------------------------------------
     def phase_tables(self, phase):

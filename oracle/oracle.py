@@ -17,7 +17,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liborpm.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm_post.c", "orpm.h", "orpm_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "rpm_hip.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborpm.so"], stdout=subprocess.DEVNULL)
@@ -48,6 +48,7 @@ def lib():
         L.orpm_eval_h.argtypes = [C.c_void_p, dp, C.c_double, dp, dp]
         L.orpm_get_phase_sizes.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.orpm_get_phase_tables.argtypes = [C.c_void_p, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
+        L.orpm_nlp2op.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orpm_lgr_points.argtypes = [C.c_int, dp, dp]
         L.orpm_colloc_d.argtypes = [C.c_int, dp, dp]
         _LIB = L
@@ -145,6 +146,23 @@ class Oracle:
         v = np.zeros(self.nnz_h)
         lib().orpm_eval_h(self._h, _dp(x), float(obj_factor), _dp(lam), _dp(v))
         return v
+
+    def nlp2op(self, phase, x, lam):
+        """Nlp2OpConverter::Nlp2OpControl for one phase -> dict of (N+1)-row column-major arrays."""
+        d = self._desc.phases[phase]
+        N = self.phase_tables(phase)["points"].size
+        M = N + 1
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        out = dict(time=np.zeros(M), state=np.zeros(M * d.nx), control=np.zeros(M * max(d.nu, 1)),
+                   costate=np.zeros(M * d.nx), pathmult=np.zeros(M * max(d.nc, 1)), hamiltonian=np.zeros(M))
+        mc, lc = C.c_double(), C.c_double()
+        lib().orpm_nlp2op(self._h, phase, _dp(x), _dp(lam), _dp(out["time"]), _dp(out["state"]), _dp(out["control"]),
+                          _dp(out["costate"]), _dp(out["pathmult"]), _dp(out["hamiltonian"]), C.byref(mc), C.byref(lc))
+        out["control"] = out["control"][:M * d.nu]
+        out["pathmult"] = out["pathmult"][:M * d.nc]
+        out["mayer_cost"], out["lagrange_cost"] = mc.value, lc.value
+        return out
 
     def phase_tables(self, phase):
         N, dn, on = C.c_int(), C.c_int(), C.c_int()

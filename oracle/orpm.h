@@ -104,6 +104,12 @@ void orpm_get_phase_tables(const orpm* o, int phase, double* points, double* wei
                            int* d_cols, double* d_vals, double* diag_vals, int* doff_rows,
                            int* doff_cols, double* doff_vals);
 
+/* Solution extraction, Nlp2OpConverter::Nlp2OpControl (Core/Nlp2OPConverter.cpp:13-196): per phase N+1 rows.
+ * Any output may be NULL.  control/pathmult have the spline-extrapolated row at tau = +1 appended. */
+void orpm_nlp2op(orpm* o, int phase, const double* x, const double* lambda, double* time, double* state,
+                 double* control, double* costate, double* pathmult, double* hamiltonian, double* mayer_cost,
+                 double* lagrange_cost);
+
 /* stand-alone table helpers (exposed for the invariant tests) */
 void orpm_lgr_points(int n, double* x, double* w);                    /* RPMGenerator.cpp:253-291 */
 void orpm_colloc_d(int M, const double* x, double* D /*(M-1) x M col-major*/); /* :107-130 */

@@ -280,7 +280,7 @@ static void spline_second_derivative(const double* x, const double* y, int n, do
   free(mu);
   free(z);
 }
-static double spline_interp(double x, const double* xdata, const double* ydata, int n) {
+double orpm_spline_interp(double x, const double* xdata, const double* ydata, int n) {
   int kleft = 1, kright = n, k;
   double* d2y = NEW(double, n);
   spline_second_derivative(xdata, ydata, n, d2y);
@@ -552,11 +552,11 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
     double* g = o->guess + p->var0;
     int r = 0;
     for (int j = 0; j < p->nx; j++) {
-      for (int k = 0; k < p->N; k++) g[r++] = spline_interp(p->points[k], tauG, pd->state_guess + (size_t)j * ng, ng);
-      g[r++] = spline_interp(1.0, tauG, pd->state_guess + (size_t)j * ng, ng);
+      for (int k = 0; k < p->N; k++) g[r++] = orpm_spline_interp(p->points[k], tauG, pd->state_guess + (size_t)j * ng, ng);
+      g[r++] = orpm_spline_interp(1.0, tauG, pd->state_guess + (size_t)j * ng, ng);
     }
     for (int j = 0; j < p->nu; j++)
-      for (int k = 0; k < p->N; k++) g[r++] = spline_interp(p->points[k], tauG, pd->control_guess + (size_t)j * ng, ng);
+      for (int k = 0; k < p->N; k++) g[r++] = orpm_spline_interp(p->points[k], tauG, pd->control_guess + (size_t)j * ng, ng);
     g[r++] = t0G;
     g[r++] = tfG;
     free(tauG);

@@ -77,4 +77,5 @@ void orpm_mk_solcost(const pslice* s, int phase_num, orpm_solcost* c);
 void orpm_mk_solevent(const pslice* s, int phase_num, orpm_solevent* e);
 void orpm_deriv_dae(orpm* o, const orpm_soldae* sd, double* dstate, double* dpath);
 void orpm_deriv_lagrange(orpm* o, const orpm_solcost* sc, double* d);
+double orpm_spline_interp(double x, const double* xdata, const double* ydata, int n);
 #endif

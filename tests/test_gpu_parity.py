@@ -338,3 +338,29 @@ def test_role_looped_layout_is_bit_identical(built, name, make, mode):
         assert np.array_equal(a2.eval_g(x), b2.eval_g(x)) and np.array_equal(a2.eval_jac_g(x), b2.eval_jac_g(x))
         a2.close()
         b2.close()
+
+
+# ---- solution extraction (Nlp2OpConverter::Nlp2OpControl) --------------------------------
+@pytest.mark.parametrize("name,make", [("launch", lambda: problems.launch(3, 6)), ("quadrotor", lambda: problems.quadrotor(4, 5)),
+                                       ("hypersensitive", lambda: problems.config("hypersensitive")),
+                                       ("bryson_denham", lambda: problems.bryson_denham())])
+def test_solution_extraction(built, name, make, tmp_path):
+    prob = make()
+    eng, orc = NLPEngine(prob, device=0), oracle_for(prob)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 31)
+    lam = np.random.RandomState(3).uniform(-1, 1, eng.m)
+    eng.finalize_solution(0, x, lam, 0.0)
+    for ph in range(eng.n_phases):
+        a, b = eng.nlp2op_control(ph), orc.nlp2op(ph, x, lam)      # a: from the stored solution
+        for k in ("time", "state", "costate", "control", "pathmult"):
+            assert np.array_equal(a[k], b[k]), (ph, k)               # copies, W^-1 lambda, spline extrapolation: bit-exact
+        assert rel_err(a["hamiltonian"], b["hamiltonian"]) <= 1e-12  # dynamics (libm) inside
+        assert a["mayer_cost"] == b["mayer_cost"]
+        assert abs(a["lagrange_cost"] - b["lagrange_cost"]) <= 1e-13 * max(1.0, abs(b["lagrange_cost"]))
+    eng.final_result_save(tmp_path)
+    M = eng.phase_tables(0)["points"].size + 1
+    st = np.loadtxt(tmp_path / "state1").reshape(M, -1)
+    assert np.array_equal(st[:, 0], eng.nlp2op_control(0)["state"][:M])
+    assert (tmp_path / ("Hamiltonian%d" % eng.n_phases)).exists() and (tmp_path / "costate1").exists()
+    eng.close()
