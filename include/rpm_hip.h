@@ -170,6 +170,29 @@ int rpm_nlp2op_control(rpm_engine* e, int phase, const double* x, const double* 
  * costate<k>, Hamiltonian<k> (Armadillo raw_ascii: one row per line) for every phase k into `dir`. */
 int rpm_final_result_save(rpm_engine* e, const char* dir);
 
+/* ---- mesh-error estimate and ph mesh refinement (after extraction) ------------
+ * SolutionErrorChecker::CheckSolutionDiffError, Core/LpSolutionError.cpp:112-169, for one phase: the solution is
+ * interpolated onto a mesh with one more LGR point per interval (:46-108), the dynamics are integrated there with
+ * inv(D(:,1:)) (Core/RPMGenerator.cpp:85), and rel_err = |integrated - interpolated| / (1 + max of the state's column).
+ * rel_err is a host array, (N + K + 1) rows x nx, column-major (K = mesh intervals); *rows receives the row count
+ * (rel_err may be NULL to query it).  x is a host array; NULL = the solution stored by rpm_finalize_solution. */
+int rpm_solution_error(rpm_engine* e, int phase, const double* x, double* rel_err, int* rows);
+/* PhMeshRefineAlg::RefineMesh + ModifySegment, Core/LpPhMeshRefineAlg.cpp:12-100, for one phase: an interval whose
+ * largest relative error is <= tol is kept; otherwise it gets Pq = int(log(emax/tol)/log(n)) more nodes, or, when
+ * that exceeds nmax, is split into max(ceil((n+Pq)/nmin), 2) intervals of nmin nodes.  Outputs (any may be NULL):
+ * new_mesh_points (new_n_intervals + 1), new_nodes_per_interval (new_n_intervals; both need `capacity` >= that
+ * count, query it first with NULL arrays), interval_error (K, the per-interval maxima), no_more_refine (1 when
+ * every interval met tol: the reference's NoMoreRefine).  The caller installs the new mesh with a new rpm_create,
+ * as the reference re-runs GetSizes/GetBounds/GetGuess per mesh (Algorithm/LpLpopcAlgorithm.cpp:147-169). */
+int rpm_ph_refine_mesh(rpm_engine* e, int phase, const double* x, double tol, int nmin, int nmax, int capacity,
+                       double* new_mesh_points, int* new_nodes_per_interval, int* new_n_intervals,
+                       double* interval_error, int* no_more_refine);
+
+/* The refinement decision alone, from a relative_error matrix the caller already holds (host only, no device work). */
+int rpm_ph_refine_from_error(rpm_engine* e, int phase, const double* rel_err, double tol, int nmin, int nmax,
+                             int capacity, double* new_mesh_points, int* new_nodes_per_interval,
+                             int* new_n_intervals, double* interval_error, int* no_more_refine);
+
 /* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
  *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
  *      engine's device; `stream` is a hipStream_t with HIP's own meaning (NULL = the legacy

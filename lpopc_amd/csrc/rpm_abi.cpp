@@ -303,6 +303,76 @@ int rpm_nlp2op_control(rpm_engine* h, int phase, const double* x, const double* 
   RPM_GUARD_END(e)
 }
 
+// ---- mesh-error estimate and ph refinement ----------------------------------
+int rpm_solution_error(rpm_engine* h, int phase, const double* x, double* rel_err, int* rows) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (phase < 0 || phase >= e.P) return fail(e, RPM_E_INVALID, "The phase index is out of rang");
+  if (e.n_instances != 1) return fail(e, RPM_E_UNSUPPORTED, "solution_error: one instance per engine");
+  if (!x) {
+    if (!e.has_solution) return fail(e, RPM_E_INVALID, "solution_error: no x given and no solution stored");
+    x = e.sol_x.data();
+  }
+  if (rows) *rows = e.ph[phase].N + e.ph[phase].K + 1;
+  if (!rel_err) return RPM_OK;
+  return rpm::dev_solution_error(e, phase, x, rel_err);
+  RPM_GUARD_END(e)
+}
+
+static int refine_from(Engine& e, int phase, const double* rel, double tol, int nmin, int nmax, int capacity,
+                       double* new_mesh_points, int* new_nodes_per_interval, int* new_n_intervals, double* interval_error,
+                       int* no_more_refine) {
+  std::vector<double> mesh, emax;
+  std::vector<int> nodes;
+  const bool done = rpm::ph_refine(e.ph[phase], rel, tol, nmin, nmax, mesh, nodes, emax);
+  if (new_n_intervals) *new_n_intervals = int(nodes.size());
+  if (no_more_refine) *no_more_refine = done ? 1 : 0;
+  if (interval_error) std::memcpy(interval_error, emax.data(), sizeof(double) * emax.size());
+  if (new_mesh_points || new_nodes_per_interval) {
+    if (capacity < int(nodes.size())) return fail(e, RPM_E_INVALID, "ph_refine_mesh: capacity is smaller than the new interval count");
+    if (new_mesh_points) std::memcpy(new_mesh_points, mesh.data(), sizeof(double) * mesh.size());
+    if (new_nodes_per_interval) std::memcpy(new_nodes_per_interval, nodes.data(), sizeof(int) * nodes.size());
+  }
+  return RPM_OK;
+}
+
+int rpm_ph_refine_from_error(rpm_engine* h, int phase, const double* rel_err, double tol, int nmin, int nmax, int capacity,
+                             double* new_mesh_points, int* new_nodes_per_interval, int* new_n_intervals,
+                             double* interval_error, int* no_more_refine) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (phase < 0 || phase >= e.P) return fail(e, RPM_E_INVALID, "The phase index is out of rang");
+  if (!rel_err) return fail(e, RPM_E_INVALID, "ph_refine_from_error: rel_err is NULL");
+  if (!(tol > 0) || nmin < 2 || nmax < nmin) return fail(e, RPM_E_INVALID, "ph_refine_mesh: need tol > 0 and 2 <= Nmin <= Nmax");
+  return refine_from(e, phase, rel_err, tol, nmin, nmax, capacity, new_mesh_points, new_nodes_per_interval, new_n_intervals,
+                     interval_error, no_more_refine);
+  RPM_GUARD_END(e)
+}
+
+int rpm_ph_refine_mesh(rpm_engine* h, int phase, const double* x, double tol, int nmin, int nmax, int capacity,
+                       double* new_mesh_points, int* new_nodes_per_interval, int* new_n_intervals,
+                       double* interval_error, int* no_more_refine) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (phase < 0 || phase >= e.P) return fail(e, RPM_E_INVALID, "The phase index is out of rang");
+  if (e.n_instances != 1) return fail(e, RPM_E_UNSUPPORTED, "ph_refine_mesh: one instance per engine");
+  if (!(tol > 0) || nmin < 2 || nmax < nmin) return fail(e, RPM_E_INVALID, "ph_refine_mesh: need tol > 0 and 2 <= Nmin <= Nmax");
+  if (!x) {
+    if (!e.has_solution) return fail(e, RPM_E_INVALID, "ph_refine_mesh: no x given and no solution stored");
+    x = e.sol_x.data();
+  }
+  const rpm::PhaseHost& p = e.ph[phase];
+  std::vector<double> rel(size_t(p.N + p.K + 1) * p.nx);
+  int rc = rpm::dev_solution_error(e, phase, x, rel.data());
+  if (rc) return rc;
+  return refine_from(e, phase, rel.data(), tol, nmin, nmax, capacity, new_mesh_points, new_nodes_per_interval,
+                     new_n_intervals, interval_error, no_more_refine);
+  RPM_GUARD_END(e)
+}
+
 int rpm_final_result_save(rpm_engine* h, const char* dir) {
   if (!h) return RPM_E_INVALID;
   Engine& e = h->e;

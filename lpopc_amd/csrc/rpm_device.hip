@@ -1094,6 +1094,105 @@ __global__ void rpm_hess_end_kernel(const KParams K, const HParams Hp, const dou
 }
 
 // ------------------------------------------------------------------------------------------
+// Mesh-error estimate: SolutionErrorChecker::CheckSolutionDiffError, Core/LpSolutionError.cpp:112-169.
+// One workgroup per mesh interval.  Phase A interpolates the interval's states / controls onto its (n+1)-point LGR
+// mesh (SolutionInterpolation, :46-108, rows of the tables built in rpm_mesh.cpp), phase B evaluates the dynamics
+// there, phase C integrates them with the interval's integration matrix: X(start) + A f (:147).
+template <class Prob>
+__global__ void rpm_mesh_err_kernel(const KParams K, int phase, const double* __restrict__ x,
+                                    const MeshIvDev* __restrict__ ivs, int n_iv, const double* __restrict__ Hs,
+                                    const double* __restrict__ Ss, const int* __restrict__ hit_s,
+                                    const double* __restrict__ Hc, const double* __restrict__ Sc,
+                                    const int* __restrict__ hit_c, const double* __restrict__ A,
+                                    const double* __restrict__ ttem, int rows, double* __restrict__ fine_state,
+                                    double* __restrict__ integ) {
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
+  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1, NCs = NC > 0 ? NC : 1;
+  extern __shared__ double mesh_sm[];
+  const MeshIvDev v = ivs[blockIdx.x];
+  const int n = v.n, n1 = n + 1;
+  double* Xs = mesh_sm;            // [q * NX + s]
+  double* Us = Xs + n1 * NX;       // [q * NU + j]
+  double* Fs = Us + n1 * NU;       // [q * NX + s]
+  const PhaseDev ph = K.phases[phase];
+  const int N = ph.N, M = N + 1;
+  const double t0 = x[ph.x_t0];
+  const double tf = (x[ph.x_t0 + 1] - t0) * (1.0 + 1) / 2 + t0;   // result->time's last entry, Nlp2OPConverter.cpp:58
+  for (int idx = threadIdx.x; idx < n1 * NX; idx += blockDim.x) {
+    const int q = idx % n1, s = idx / n1;
+    const double* col = x + ph.x_state0 + s * M + v.istart;
+    const int hit = hit_s[v.q0 + q];
+    double val;
+    if (hit >= 0) {
+      val = col[hit];
+    } else {
+      double acc = 0.0;
+      for (int j = 0; j < n1; ++j) acc += Hs[v.hs + q + j * n1] * col[j];
+      val = acc / Ss[v.q0 + q];
+    }
+    Xs[q * NX + s] = val;
+    fine_state[(v.r0 + q) + size_t(s) * rows] = val;
+  }
+  for (int idx = threadIdx.x; idx < n1 * NU; idx += blockDim.x) {
+    const int q = idx % n1, j = idx / n1;
+    const double* col = x + ph.x_control0 + j * N + v.istart;
+    const int hit = hit_c[v.q0 + q];
+    double val;
+    if (hit >= 0) {
+      val = col[hit];
+    } else {
+      double acc = 0.0;
+      for (int c = 0; c < n; ++c) acc += Hc[v.hc + q + c * n1] * col[c];
+      val = acc / Sc[v.q0 + q];
+    }
+    Us[q * NU + j] = val;
+  }
+  __syncthreads();
+  const double half = (tf - t0) / 2;
+  for (int q = threadIdx.x; q < n1; q += blockDim.x) {
+    double xs[NXs], us[NUs], f[NXs], cp[NCs];
+#pragma unroll
+    for (int s = 0; s < NX; ++s) xs[s] = Xs[q * NX + s];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) us[j] = Us[q * NU + j];
+    const double t = half * ttem[v.q0 + q] + half;   // t0 is not added, LpSolutionError.cpp:124
+    Prob::dae(ph.phase_num, t, xs, us, K.consts, f, cp);
+#pragma unroll
+    for (int s = 0; s < NX; ++s) Fs[q * NX + s] = f[s] * ((tf - t0) / 2.0);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n1 * NX; idx += blockDim.x) {
+    const int r = idx % n1, s = idx / n1;
+    double acc = 0.0;
+    for (int c = 0; c < n1; ++c) acc += A[v.a + r + c * n1] * Fs[c * NX + s];
+    integ[(1 + v.r0 + r) + size_t(s) * rows] = (0.0 + 1.0 * Xs[s]) + acc;
+  }
+  if (blockIdx.x == 0)
+    for (int s = threadIdx.x; s < NX; s += blockDim.x) integ[size_t(s) * rows] = Xs[s];
+  if (blockIdx.x == n_iv - 1)
+    for (int s = threadIdx.x; s < NX; s += blockDim.x)
+      fine_state[(rows - 1) + size_t(s) * rows] = x[ph.x_state0 + s * M + N];
+}
+
+// relative_error(:, s) = |integrated - interpolated| / (1 + max(interpolated(:, s))), one workgroup per state (:148-157)
+__global__ void rpm_mesh_rel_kernel(int rows, const double* __restrict__ fine_state, const double* __restrict__ integ,
+                                    double* __restrict__ rel) {
+  __shared__ double red[256];
+  const double* col = fine_state + size_t(blockIdx.x) * rows;
+  double mx = col[0];
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) mx = fmax(mx, col[r]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+    __syncthreads();
+  }
+  const double den = 1 + red[0];
+  for (int r = threadIdx.x; r < rows; r += blockDim.x)
+    rel[r + size_t(blockIdx.x) * rows] = fabs(integ[r + size_t(blockIdx.x) * rows] - col[r]) / den;
+}
+
+// ------------------------------------------------------------------------------------------
 // Solution extraction: Nlp2OpConverter::Nlp2OpControl, Core/Nlp2OPConverter.cpp:13-196.
 // Runs once per mesh after the NLP solve, not per iteration.
 // rpm_post_spline_kernel: value at tau = +1 of the natural cubic spline through (tau_k, y_k), one thread per column
@@ -1790,6 +1889,80 @@ int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, doub
   if (rc) return rc;
   if (s != hipSuccess) {
     e.err = std::string("nlp2op: ") + hipGetErrorString(s);
+    return RPM_E_DEVICE;
+  }
+  return RPM_OK;
+}
+
+// CheckSolutionDiffError for one phase: host x in, relative_error ((N + K + 1) x nx, column-major) out
+int dev_solution_error(Engine& e, int phase, const double* x, double* rel_err) {
+  if (!e.dev) {
+    int rc = device_init(e, 0);
+    if (rc) return rc;
+  }
+  Device& d = *e.dev;
+  HIP_TRY(e, hipSetDevice(d.device_id));
+  const PhaseHost& p = e.ph[phase];
+  if (e.mesh_err.size() != e.ph.size()) e.mesh_err.assign(e.ph.size(), MeshErrTables());
+  MeshErrTables& t = e.mesh_err[phase];
+  if (t.iv.empty()) build_mesh_err_tables(p, t);
+  const int rows = t.rows, nx = p.nx, nu = p.nu, K = int(t.iv.size());
+  int nmax = 0;
+  for (const MeshIvDev& iv : t.iv) nmax = std::max(nmax, iv.n + 1);
+  const size_t lds = sizeof(double) * size_t(nmax) * (2 * nx + nu);
+  if (lds > 60 * 1024) {
+    e.err = "solution_error: a mesh interval has too many nodes for the estimator's LDS tile";
+    return RPM_E_UNSUPPORTED;
+  }
+  // one device block: doubles first, then the ints
+  const size_t nd = t.ttem.size() + t.Hs.size() + t.Ss.size() + t.Hc.size() + t.Sc.size() + t.A.size() + 3 * size_t(rows) * nx;
+  const size_t ni = t.hit_s.size() + t.hit_c.size();
+  const size_t bytes = nd * sizeof(double) + ni * sizeof(int) + K * sizeof(MeshIvDev);
+  char* buf = nullptr;
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&buf), bytes));
+  double* dd = reinterpret_cast<double*>(buf);
+  double* d_ttem = dd; dd += t.ttem.size();
+  double* d_Hs = dd; dd += t.Hs.size();
+  double* d_Ss = dd; dd += t.Ss.size();
+  double* d_Hc = dd; dd += t.Hc.size();
+  double* d_Sc = dd; dd += t.Sc.size();
+  double* d_A = dd; dd += t.A.size();
+  double* d_fine = dd; dd += size_t(rows) * nx;
+  double* d_integ = dd; dd += size_t(rows) * nx;
+  double* d_rel = dd; dd += size_t(rows) * nx;
+  int* d_hit_s = reinterpret_cast<int*>(dd);
+  int* d_hit_c = d_hit_s + t.hit_s.size();
+  MeshIvDev* d_iv = reinterpret_cast<MeshIvDev*>(d_hit_c + t.hit_c.size());
+  hipError_t s = hipSuccess;
+  auto put = [&](void* dev, const void* host, size_t cnt) {
+    if (cnt && s == hipSuccess) s = hipMemcpy(dev, host, cnt, hipMemcpyHostToDevice);
+  };
+  put(d_ttem, t.ttem.data(), t.ttem.size() * sizeof(double));
+  put(d_Hs, t.Hs.data(), t.Hs.size() * sizeof(double));
+  put(d_Ss, t.Ss.data(), t.Ss.size() * sizeof(double));
+  put(d_Hc, t.Hc.data(), t.Hc.size() * sizeof(double));
+  put(d_Sc, t.Sc.data(), t.Sc.size() * sizeof(double));
+  put(d_A, t.A.data(), t.A.size() * sizeof(double));
+  put(d_hit_s, t.hit_s.data(), t.hit_s.size() * sizeof(int));
+  put(d_hit_c, t.hit_c.data(), t.hit_c.size() * sizeof(int));
+  put(d_iv, t.iv.data(), K * sizeof(MeshIvDev));
+  int rc = (s == hipSuccess) ? dev_upload(e, d.d_x, x, size_t(e.n)) : RPM_OK;
+  if (rc == RPM_OK && s == hipSuccess) {
+    hipStream_t st = d.stream;
+    with_problem(e.problem_id, [&](auto prob) {
+      using P = decltype(prob);
+      hipLaunchKernelGGL((rpm_mesh_err_kernel<P>), dim3(unsigned(K)), dim3(128), lds, st, d.kp, phase, d.d_x, d_iv, K, d_Hs,
+                         d_Ss, d_hit_s, d_Hc, d_Sc, d_hit_c, d_A, d_ttem, rows, d_fine, d_integ);
+    });
+    hipLaunchKernelGGL(rpm_mesh_rel_kernel, dim3(unsigned(nx)), dim3(256), 0, st, rows, d_fine, d_integ, d_rel);
+    s = hipGetLastError();
+    if (s == hipSuccess) s = hipStreamSynchronize(st);
+    if (s == hipSuccess) s = hipMemcpy(rel_err, d_rel, size_t(rows) * nx * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(buf);
+  if (rc) return rc;
+  if (s != hipSuccess) {
+    e.err = std::string("solution_error: ") + hipGetErrorString(s);
     return RPM_E_DEVICE;
   }
   return RPM_OK;

@@ -85,6 +85,22 @@ struct LinkDev {
   int v0;            // offset of the pair's entries in `values`
 };
 
+// ---- mesh-error estimate (row f-3): per mesh interval, offsets into the phase's interpolation / integration tables
+struct MeshIvDev {
+  int n;        // collocation nodes of the interval on the current mesh (the finer mesh has n + 1)
+  int istart;   // first node of the interval on the current mesh
+  int r0;       // first row of the interval on the finer mesh
+  int q0;       // offset of its n + 1 rows in ttem / Ss / Sc / hit_s / hit_c
+  int hs, hc;   // offsets of its state ((n+1) x (n+1)) and control ((n+1) x n) interpolation rows, column-major
+  int a;        // offset of its (n+1) x (n+1) integration matrix, column-major
+};
+struct MeshErrTables {
+  std::vector<MeshIvDev> iv;
+  std::vector<double> ttem, Hs, Ss, Hc, Sc, A;
+  std::vector<int> hit_s, hit_c;
+  int fine_nodes = 0, rows = 0;   // sum(n_k + 1) and that + 1
+};
+
 // ---- host-side phase tables ----------------------------------------------------------
 struct PhaseHost {
   int nx = 0, nu = 0, nq = 0, nc = 0, ne = 0, K = 0, N = 0;
@@ -147,6 +163,7 @@ struct Engine {
   std::vector<double> sol_x, sol_lambda;
   double sol_obj = 0.0;
   bool has_solution = false;
+  std::vector<MeshErrTables> mesh_err;            // built on first use, per phase
   // state
   std::string err;
   Device* dev = nullptr;
@@ -166,6 +183,12 @@ int dev_eval_h(Engine& e, const double* d_x, double obj_factor, const double* d_
 
 int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, double* time, double* state, double* control,
                double* costate, double* pathmult, double* hamiltonian, double* mayer_cost, double* lagrange_cost);
+
+// rpm_mesh.cpp: tables of the mesh-error estimate and the ph refinement decision (host); rpm_device.hip: the estimate
+void build_mesh_err_tables(const PhaseHost& p, MeshErrTables& t);
+bool ph_refine(const PhaseHost& p, const double* rel, double tol, int nmin, int nmax, std::vector<double>& mesh,
+               std::vector<int>& nodes, std::vector<double>& interval_error);
+int dev_solution_error(Engine& e, int phase, const double* x, double* rel_err);
 
 // rpm_shard.cpp: rank's contiguous runs of g (which=0) or of the Jacobian values (which=1)
 std::vector<rpm_segment> shard_segments(const Engine& e, int which, int rank, int* packed_len);

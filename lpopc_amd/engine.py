@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "rpm_eval_jac_g_dev", "rpm_eval_pair_dev", "rpm_eval_f_dev", "rpm_eval_grad_f_dev", "rpm_eval_h_dev",
     "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_get_phase_sizes", "rpm_get_phase_tables",
     "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
+    "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
 ]
 
 
@@ -84,6 +85,9 @@ def lib():
     L.rpm_get_phase_tables.argtypes = [vp, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
     L.rpm_nlp2op_control.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
     L.rpm_final_result_save.argtypes = [vp, C.c_char_p]
+    L.rpm_solution_error.argtypes = [vp, C.c_int, dp, dp, ip]
+    L.rpm_ph_refine_mesh.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, ip]
+    L.rpm_ph_refine_from_error.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, ip]
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
     L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -285,6 +289,36 @@ class NLPEngine:
 
     def final_result_save(self, directory):
         self._check(self._L.rpm_final_result_save(self._h, str(directory).encode()))
+
+    # ---- mesh-error estimate and ph refinement ---------------------------------------
+    def solution_error(self, phase, x=None):
+        """SolutionErrorChecker::CheckSolutionDiffError -> relative_error, (N + K + 1) x nx."""
+        rows = C.c_int()
+        self._check(self._L.rpm_solution_error(self._h, phase, None, None, C.byref(rows)))
+        nx = self._desc.phases[phase].nx
+        rel = np.zeros(rows.value * nx)
+        xp = _dp(self._x(x)) if x is not None else None
+        self._check(self._L.rpm_solution_error(self._h, phase, xp, _dp(rel), C.byref(rows)))
+        return rel.reshape((rows.value, nx), order="F")
+
+    def _refine(self, fn, phase, arg, tol, nmin, nmax):
+        K = self._desc.phases[phase].n_intervals
+        nk, done, emax = C.c_int(), C.c_int(), np.zeros(K)
+        self._check(fn(self._h, phase, arg, float(tol), int(nmin), int(nmax), 0, None, None, C.byref(nk), _dp(emax),
+                       C.byref(done)))
+        mesh, nodes = np.zeros(nk.value + 1), np.zeros(nk.value, dtype=np.int32)
+        self._check(fn(self._h, phase, arg, float(tol), int(nmin), int(nmax), nk.value, _dp(mesh), _ip(nodes),
+                       C.byref(nk), None, None))
+        return bool(done.value), mesh, nodes, emax
+
+    def ph_refine_mesh(self, phase, tol, nmin, nmax, x=None):
+        """PhMeshRefineAlg::RefineMesh for one phase -> (no_more_refine, mesh_points, nodes_per_interval, emax)."""
+        xp = _dp(self._x(x)) if x is not None else None
+        return self._refine(self._L.rpm_ph_refine_mesh, phase, xp, tol, nmin, nmax)
+
+    def ph_refine_from_error(self, phase, rel_err, tol, nmin, nmax):
+        rel = np.asfortranarray(rel_err, dtype=np.float64).ravel(order="F").copy()
+        return self._refine(self._L.rpm_ph_refine_from_error, phase, _dp(rel), tol, nmin, nmax)
 
     # ---- tables and sharding ---------------------------------------------------------------
     def phase_tables(self, phase):

@@ -1,0 +1,70 @@
+"""Mesh refinement driver: the host-side mirror of lpopc's MeshRefiner.
+
+Reference: Core/LpMeshRefiner.h:36-92 and Core/LpMeshRefiner.cpp:62-90 (grid counter, mesh history, method choice
+from the option list), Core/LpPhMeshRefineAlg.cpp (the ph method), Core/Nlp2OPConverter.cpp:149-193 (the extracted
+solution becomes the next mesh's guess).  The per-node work runs on the device behind rpm_solution_error /
+rpm_ph_refine_mesh; this class only keeps the reference's bookkeeping and error behaviour.
+"""
+from .problem import LpopcException
+
+
+class LpMesh:
+    """Core/LpMeshRefineImpletation.hpp: the mesh of one phase."""
+
+    def __init__(self, meshpoints, nodesPerInterval):
+        self.meshpoints = list(meshpoints)
+        self.nodesPerInterval = list(nodesPerInterval)
+
+
+class MeshRefiner:
+    def __init__(self, options):
+        self.tol_ = options.GetNumericValue("desired-relative-error")
+        self.method_ = options.GetStringValue("mesh-refine-methods")
+        self.gridmaxnum_ = options.GetIntegerValue("max-grid-num")
+        self.Nmax_ = options.GetIntegerValue("Nmax")
+        self.Nmin_ = options.GetIntegerValue("Nmin")
+        if self.method_ != "ph":
+            # hp-Liu (Core/LpLiuHpMeshRefineAlg.cpp) is not built yet: say so instead of silently running ph
+            raise LpopcException("mesh-refine-methods=%s is not supported by this build (only ph)" % self.method_)
+        self.grid_ = 0
+        self.meshhistory = []
+
+    def CurrentGrid(self):
+        return self.grid_
+
+    def RefineMesh(self, engine, optpro, x=None):
+        """One refinement pass on the solution x (default: the one stored by finalize_solution).  Installs the new
+        mesh in `optpro` and returns NoMoreRefine; the caller builds a new engine for the new mesh."""
+        if self.grid_ > self.gridmaxnum_:
+            raise LpopcException("The problem reach the max number of refine grid,but hasn't reach the derized error tolrance")
+        nph = optpro.GetPhaseNum()
+        if self.grid_ == 0:
+            self.meshhistory.append([LpMesh(optpro.GetPhase(i).GetMeshPoints(), optpro.GetPhase(i).GetNodesPerInterval())
+                                     for i in range(nph)])
+        no_more, newmesh = True, []
+        for i in range(nph):
+            done, mesh, nodes, _ = engine.ph_refine_mesh(i, self.tol_, self.Nmin_, self.Nmax_, x=x)
+            no_more = no_more and done
+            newmesh.append(LpMesh(mesh.tolist(), [int(v) for v in nodes]))
+        for i, mesh in enumerate(newmesh):   # the reference rewrites the mesh even when nothing changed
+            ph = optpro.GetPhase(i)
+            ph.meshpoints = list(mesh.meshpoints)
+            ph.nodesperinterval = list(mesh.nodesPerInterval)
+        if not no_more:
+            self.grid_ += 1
+            self.meshhistory.append(newmesh)
+        return no_more
+
+
+def install_guess(engine, optpro, x=None, lam=None):
+    """Nlp2OpControl's tail (Core/Nlp2OPConverter.cpp:160-193): the extracted time / state / control arrays of every
+    phase become that phase's guess for the next mesh."""
+    for i in range(optpro.GetPhaseNum()):
+        ph = optpro.GetPhase(i)
+        r = engine.nlp2op_control(i, x=x, lam=lam)
+        M = r["time"].size
+        ph.vtimeguess = [float(v) for v in r["time"]]
+        nx, nu = r["state"].size // M, r["control"].size // M
+        ph.vstateguess = [[float(v) for v in r["state"][s * M:(s + 1) * M]] for s in range(nx)]
+        ph.vcontrolguess = [[float(v) for v in r["control"][j * M:(j + 1) * M]] for j in range(nu)]
+        ph.vparameterguess = []

@@ -17,7 +17,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liborpm.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm_post.c", "orpm.h", "orpm_internal.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm_post.c", "orpm_mesh.c", "orpm.h", "orpm_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "rpm_hip.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborpm.so"], stdout=subprocess.DEVNULL)
@@ -49,6 +49,10 @@ def lib():
         L.orpm_get_phase_sizes.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.orpm_get_phase_tables.argtypes = [C.c_void_p, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
         L.orpm_nlp2op.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orpm_solution_error.argtypes = [C.c_void_p, C.c_int, dp, dp]
+        L.orpm_ph_refine.argtypes = [C.c_void_p, C.c_int, dp, C.c_double, C.c_int, C.c_int, dp, ip, ip, dp]
+        L.orpm_inverse.argtypes = [C.c_int, dp, dp]
+        L.orpm_bary_tables.argtypes = [C.c_int, dp, C.c_int, dp, dp, dp, ip]
         L.orpm_lgr_points.argtypes = [C.c_int, dp, dp]
         L.orpm_colloc_d.argtypes = [C.c_int, dp, dp]
         _LIB = L
@@ -163,6 +167,27 @@ class Oracle:
         out["pathmult"] = out["pathmult"][:M * d.nc]
         out["mayer_cost"], out["lagrange_cost"] = mc.value, lc.value
         return out
+
+    def solution_error(self, phase, x):
+        """SolutionErrorChecker::CheckSolutionDiffError -> relative_error, (N+K+1) x nx."""
+        d = self._desc.phases[phase]
+        N = self.phase_tables(phase)["points"].size
+        rows = N + d.n_intervals + 1
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        rel = np.zeros(rows * d.nx)
+        lib().orpm_solution_error(self._h, phase, _dp(x), _dp(rel))
+        return rel.reshape((rows, d.nx), order="F")
+
+    def ph_refine(self, phase, x, tol, nmin, nmax):
+        """PhMeshRefineAlg::RefineMesh for one phase -> (no_more_refine, mesh_points, nodes_per_interval, emax)."""
+        d = self._desc.phases[phase]
+        K = d.n_intervals
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        cap = K * 64 + 2
+        mesh, nodes, nk, emax = np.zeros(cap * 8), np.zeros(cap * 8, dtype=np.int32), C.c_int(), np.zeros(K)
+        done = lib().orpm_ph_refine(self._h, phase, _dp(x), float(tol), int(nmin), int(nmax), _dp(mesh), _ip(nodes),
+                                    C.byref(nk), _dp(emax))
+        return bool(done), mesh[:nk.value + 1].copy(), nodes[:nk.value].copy(), emax
 
     def phase_tables(self, phase):
         N, dn, on = C.c_int(), C.c_int(), C.c_int()

@@ -110,6 +110,14 @@ void orpm_nlp2op(orpm* o, int phase, const double* x, const double* lambda, doub
                  double* control, double* costate, double* pathmult, double* hamiltonian, double* mayer_cost,
                  double* lagrange_cost);
 
+/* Mesh-error estimate and ph refinement: SolutionErrorChecker::CheckSolutionDiffError
+ * (Core/LpSolutionError.cpp:112-169) and PhMeshRefineAlg::RefineMesh (Core/LpPhMeshRefineAlg.cpp:12-100). */
+int orpm_solution_error(orpm* o, int phase, const double* x, double* rel_err /* (N+K+1) x nx, column-major */);
+int orpm_ph_refine(orpm* o, int phase, const double* x, double tol, int Nmin, int Nmax, double* new_mesh,
+                   int* new_nodes, int* new_K, double* max_err_per_interval);
+void orpm_bary_tables(int M, const double* data_x, int Nq, const double* xq, double* H, double* S, int* fix);
+void orpm_inverse(int n, const double* A, double* inv);
+
 /* stand-alone table helpers (exposed for the invariant tests) */
 void orpm_lgr_points(int n, double* x, double* w);                    /* RPMGenerator.cpp:253-291 */
 void orpm_colloc_d(int M, const double* x, double* D /*(M-1) x M col-major*/); /* :107-130 */

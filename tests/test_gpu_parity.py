@@ -364,3 +364,53 @@ def test_solution_extraction(built, name, make, tmp_path):
     assert np.array_equal(st[:, 0], eng.nlp2op_control(0)["state"][:M])
     assert (tmp_path / ("Hamiltonian%d" % eng.n_phases)).exists() and (tmp_path / "costate1").exists()
     eng.close()
+
+
+# ---- mesh-error estimate and ph refinement (SolutionErrorChecker / PhMeshRefineAlg) -----------
+MESH_CASES = [("launch", lambda: problems.launch(3, 6)), ("launch_ragged", _launch_ragged),
+              ("quadrotor", lambda: problems.quadrotor(4, 5)), ("hypersensitive", lambda: problems.config("hypersensitive")),
+              ("bryson_denham", lambda: problems.bryson_denham()), ("brachistochrone", lambda: problems.config("brachistochrone")),
+              ("climb", lambda: problems.config("climb"))]
+
+
+@pytest.mark.parametrize("name,make", MESH_CASES, ids=[c[0] for c in MESH_CASES])
+def test_solution_error_and_ph_refine(built, name, make):
+    prob = make()
+    eng, orc = NLPEngine(prob, device=0), oracle_for(prob)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 77)
+    eng.finalize_solution(0, x, np.zeros(eng.m), 0.0)
+    for ph in range(eng.n_phases):
+        a, b = eng.solution_error(ph), orc.solution_error(ph, x)     # a: from the stored solution
+        assert a.shape == b.shape
+        # interpolation, integration and the error quotient follow the oracle's operation order; the dynamics call
+        # libm on both sides, so allow the same slack as the Hamiltonian of the extraction row
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), (ph, np.abs(a - b).max())
+        for tol, nmin, nmax in [(1e-6, 4, 16), (1e-3, 3, 8), (1e-9, 2, 5)]:
+            d1, m1, n1, e1 = eng.ph_refine_mesh(ph, tol, nmin, nmax, x=x)
+            d2, m2, n2, e2 = orc.ph_refine(ph, x, tol, nmin, nmax)
+            assert d1 == d2 and np.array_equal(m1, m2) and np.array_equal(n1, n2), (ph, tol)
+            assert np.abs(e1 - e2).max() <= 1e-12 * max(1.0, e2.max())
+    eng.close()
+
+
+def test_refinement_pass_builds_the_next_mesh(built):
+    """One trip round the reference's outer loop without the NLP solve: estimate -> new mesh -> guess -> new engine."""
+    from lpopc_amd.mesh import MeshRefiner, install_guess
+    from lpopc_amd.problem import Options
+    prob = problems.launch(3, 6)
+    eng = NLPEngine(prob, device=0)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 5)
+    eng.finalize_solution(0, x, np.zeros(eng.m), 0.0)
+    refiner = MeshRefiner(Options())
+    assert refiner.RefineMesh(eng, prob) is False and refiner.CurrentGrid() == 1
+    install_guess(eng, prob)
+    old_n = eng.n
+    eng.close()
+    eng2, orc2 = NLPEngine(prob, device=0), oracle_for(prob)
+    assert eng2.n != old_n and eng2.n == orc2.n
+    x2 = eng2.get_starting_point()
+    assert np.array_equal(x2, orc2.starting_point())               # the extracted solution, re-interpolated as the guess
+    assert np.array_equal(eng2.eval_g(x2), orc2.eval_g(x2)) or rel_err(eng2.eval_g(x2), orc2.eval_g(x2)) <= 1e-12
+    eng2.close()
