@@ -54,6 +54,7 @@ struct KParams {
   int P, L, n, m, m_nl, nnz, nnz_nl, nnz_lin, nnz_const;
   int max_span, max_drow;
   int diag_mask;                        // ablation mask, only honoured by the -DRPM_DIAG diagnostic build
+  unsigned long long* trace;            // per-workgroup timestamps (diagnostic build with RPM_DIAG_TRACE set), else NULL
 };
 
 struct HParams {
@@ -67,6 +68,7 @@ struct HParams {
 
 struct Device {
   int device_id = -1;
+  size_t trace_words = 0;
   hipStream_t stream = nullptr;
   KParams kp{};
   // tables
@@ -515,8 +517,20 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
 // RG = 4 a wave is 64 consecutive nodes of ONE role, so every Jacobian store instruction writes 512 contiguous bytes
 // (instead of 4 x 128 B), a launch has 4x fewer workgroups of 4 waves each (one residency round on 256 CUs at 16
 // instances of the metric problem), and each workgroup pays its load chain once for 3 dynamics evaluations per thread.
+#ifdef RPM_DIAG
+#define RPM_TRC(i)                                                                                            \
+  if (K.trace && threadIdx.x == 0)                                                                            \
+  K.trace[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64()
+#else
+#define RPM_TRC(i)
+#endif
+#ifdef RPM_EXP_RL_WAVES
+#define RPM_RL_ATTR __attribute__((amdgpu_waves_per_eu(RPM_EXP_RL_WAVES, 8)))
+#else
+#define RPM_RL_ATTR
+#endif
 template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
-__global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, const double* __restrict__ xall,
+__global__ __launch_bounds__(T* RG) RPM_RL_ATTR void rpm_tile_rl_kernel(const KParams K, const double* __restrict__ xall,
                                                             double* __restrict__ gall, double* __restrict__ vall) {
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
   constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
@@ -528,6 +542,7 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
   const double* __restrict__ x = xall + size_t(blockIdx.y) * K.n;
   double* __restrict__ g = gall + size_t(blockIdx.y) * K.m;
   double* __restrict__ vals = vall + size_t(blockIdx.y) * K.nnz;
+  RPM_TRC(0);
   if (int(blockIdx.x) >= K.n_my_tiles) {
     endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
     return;
@@ -547,18 +562,25 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
   const double tau = K.points[nidx];
   const NodeDev nd = K.nodes[nidx];
   const double ddiag = WJ ? K.diag[nidx] : 0.0;
+#ifdef RPM_DIAG
+  const bool diag_noload = K.diag_mask & 2;
+#else
+  constexpr bool diag_noload = false;
+#endif
   for (int q = tid; q < NX * tl.span_len; q += NTHR) {
     const int i = q / tl.span_len, r = q - i * tl.span_len;
-    Xs[i * K.max_span + r] = x[ph.x_state0 + i * (ph.N + 1) + tl.span0 + r];
+    Xs[i * K.max_span + r] = diag_noload ? 1.0e6 + q : x[ph.x_state0 + i * (ph.N + 1) + tl.span0 + r];
   }
   for (int q = tid; q < NU * tl.cnt; q += NTHR) {
     const int j = q / tl.cnt, r = q - j * tl.cnt;
-    Us[j * T + r] = x[ph.x_control0 + j * ph.N + tl.k0 + r];
+    Us[j * T + r] = diag_noload ? 0.5 : x[ph.x_control0 + j * ph.N + tl.k0 + r];
   }
   if (WG)
-    for (int q = tid; q < tl.drow_len; q += NTHR) Ds[q] = K.dvals[tl.drow0 + q];
-  const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
+    for (int q = tid; q < tl.drow_len; q += NTHR) Ds[q] = diag_noload ? 0.25 : K.dvals[tl.drow0 + q];
+  const double t0 = diag_noload ? 0.0 : x[ph.x_t0], tf = diag_noload ? 100.0 : x[ph.x_t0 + 1];
+  RPM_TRC(1);
   __syncthreads();
+  RPM_TRC(2);
 
   const bool node_ok = kk < tl.cnt;
   const double tspan = tf - t0;
@@ -592,6 +614,14 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
       if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
     }
     double f[NX > 0 ? NX : 1], cp[NCs];
+#ifdef RPM_DIAG
+    if ((K.diag_mask & 1) && role >= 4) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) f[i] = Fb[i * T + kk] + h;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) cp[j] = Fb[(NX + j) * T + kk] + h;
+    } else
+#endif
     if (!AN || role == 0) {
       Prob::dae(ph.phase_num, tk, xs, us, c, f, cp);
     } else if constexpr (AN) {
@@ -608,11 +638,16 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
         }
       }
       __syncthreads();
+      RPM_TRC(3);
       first = false;
     }
     if (act) {
       if (WG && sv >= 0 && sv < NX) g[ph.g0 + sv * N + k] = dx - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
+#ifdef RPM_DIAG
+      if (WJ && role >= 1 && !(K.diag_mask & 8)) {
+#else
       if (WJ && role >= 1) {
+#endif
         double J[NO];
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
@@ -653,7 +688,13 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
       }
     }
   }
-  if (WJ) {   // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718)
+  RPM_TRC(4);
+#ifdef RPM_DIAG
+  if (WJ && !(K.diag_mask & 4)) {
+#else
+  if (WJ) {
+#endif
+    // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718)
     const double* __restrict__ src = K.doff_vals + tl.c_src0;
     double* __restrict__ dst = vals + tl.c_dst0;
     for (int q = tid; q < tl.c_cnt; q += NTHR) {
@@ -662,6 +703,20 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
       for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = dv;
     }
   }
+#ifdef RPM_DIAG
+  RPM_TRC(5);
+  if (K.trace) {
+    __builtin_amdgcn_s_waitcnt(0);
+    RPM_TRC(6);
+    if (threadIdx.x == 0) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      K.trace[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 7] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1342,6 +1397,18 @@ void device_destroy(Engine& e) {
   Device* d = e.dev;
   if (!d) return;
   (void)hipSetDevice(d->device_id);
+#ifdef RPM_DIAG
+  if (d->kp.trace) {   // dump the last launch's per-workgroup timestamps
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(d->trace_words);
+    (void)hipMemcpy(h.data(), d->kp.trace, d->trace_words * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = std::fopen(getenv("RPM_DIAG_TRACE"), "wb")) {
+      std::fwrite(h.data(), 8, h.size(), f);
+      std::fclose(f);
+    }
+    (void)hipFree(d->kp.trace);
+  }
+#endif
   void* ptrs[] = {d->d_phases, d->d_tiles, d->d_tasks, d->d_nodes, d->d_points, d->d_weights, d->d_diag,
                   d->d_dvals, d->d_doff, d->d_consts, d->d_alin_v, d->d_links, d->d_alin_j, d->d_x, d->d_g,
                   d->d_values, d->d_grad, d->d_obj, d->d_lambda, d->d_hess, d->d_partial, d->d_hpairs, d->d_hphases,
@@ -1440,7 +1507,13 @@ int device_init(Engine& e, int device_id) {
   k.tasks = d->d_tasks;
   k.n_tasks = (!sharded || e.shard_rank == 0) ? int(e.tasks.size()) : 0;  // rank 0 owns the endpoint rows
   k.diag_mask = 0;
+  k.trace = nullptr;
 #ifdef RPM_DIAG
+  if (getenv("RPM_DIAG_TRACE")) {
+    const size_t words = size_t(e.tiles.size() * 2 + e.tasks.size() + 64) * size_t(e.n_instances) * 8;
+    if (hipMalloc(reinterpret_cast<void**>(&k.trace), words * 8) == hipSuccess) (void)hipMemset(k.trace, 0, words * 8);
+    d->trace_words = words;
+  }
   if (const char* dm = getenv("RPM_DIAG_MASK")) k.diag_mask = atoi(dm);
 #endif
   ProblemDims pd;
