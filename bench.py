@@ -75,6 +75,7 @@ def main():
                          "rocprofv3 --stats averages exactly the launches bench.py times")
     ap.add_argument("--dx-mode", type=int, default=0, help="0: scalar D.X in the reference's order, 1: FP64 MFMA tiles")
     ap.add_argument("--tile-nodes", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 role-looped kernel only, 1 force the pipelined kernel")
     ap.add_argument("--batch", type=int, default=16,
                     help="NLP iterates evaluated per launch (independent instances of the same problem)")
     ap.add_argument("--intervals", type=int, default=64)
@@ -109,6 +110,8 @@ def main():
                     shard_world=world if sharded else 1, tile_nodes=args.tile_nodes, device=local_rank)
     if args.dx_mode:
         eng.set_option("dx_mode", args.dx_mode)
+    if args.pipeline != -1:
+        eng.set_option("pipeline", args.pipeline)
     xl, xu, _, _ = eng.get_bounds_info()
     x0 = eng.get_starting_point()
     R = max(args.iterates, 2 * B)
@@ -229,7 +232,8 @@ def main():
                         "fused: one rpm_tile_kernel launch writes g and all Jacobian values of x_k",
                 "launch": "hipGraph replay of the K steps" if graph is not None else "eager launches",
                 "tile_nodes": eng.get_option("tile_nodes"),
-                "thread_layout": "64 nodes x 4 role groups (roles looped)" if eng.get_option("role_loop") else "16 nodes x (nx+nu+2) roles",
+                "thread_layout": ("persistent workgroups, 4 compute waves + 1 DMA wave (rpm_tile_pl_kernel)" if eng.get_option("pipeline_active")
+                                  else "64 nodes x 4 role groups (roles looped)" if eng.get_option("role_loop") else "16 nodes x (nx+nu+2) roles"),
                 "dx_mode": "mfma_f64_16x16x4" if args.dx_mode else "scalar, reference summation order",
                 "parallelism": ("intervals sharded x%d + RCCL all-gather" % world) if sharded else
                                ("independent instances x%d" % world),
@@ -238,7 +242,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "rpm_tile_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel": ("rpm_tile_pl_kernel" if eng.get_option("pipeline_active") else
+                           "rpm_tile_rl_kernel" if eng.get_option("role_loop") else "rpm_tile_kernel"),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_pair": bytes_per_launch // B,
                 "avg_launch_us": launch_us,
             },

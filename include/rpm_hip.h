@@ -218,6 +218,10 @@ int rpm_synchronize(rpm_engine* e);
  * "tile_nodes"       16 | 32 | 64: collocation nodes per workgroup (0 = default 16)
  * "role_loop"        -1 (default): automatic, 0: never, 1: always — the throughput thread layout (64 nodes x 4 role
  *                    groups per workgroup, roles walked sequentially) chosen automatically for large grids
+ * "pipeline"         -1 (default): automatic, 0: never, 1: whenever the mesh fits — with the role-looped layout, run the
+ *                    persistent pipelined kernel (4 compute waves + 1 DMA wave per workgroup; inputs of the next tile
+ *                    prefetched, constant block written by the DMA wave); automatic = every resident workgroup has
+ *                    at least two tiles.  get-only "pipeline_active": 1 if the next launch uses it
  * "check_finite"     1 (default): NaN/Inf in a result -> RPM_E_NONFINITE (checked on the device); 0: lpopc's behaviour
  * "pin_host"         1 (default): the host-pointer entry points page-lock (hipHostRegister) the caller's x / g /
  *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —

@@ -476,6 +476,9 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
       e.role_looped = false;
       rpm::build_tiles(e, value);
     }
+  } else if (k == "pipeline") {
+    if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "pipeline must be -1 (auto), 0 or 1");
+    e.opt_pipeline = value;
   } else if (k == "role_loop") {
     if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "role_loop must be -1 (auto), 0 or 1");
     if (e.dev) return fail(e, RPM_E_INVALID, "role_loop must be set before the device is initialised");
@@ -501,6 +504,8 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "tile_nodes") *value = e.tile_nodes;
   else if (k == "n_tiles") *value = int(e.tiles.size());
   else if (k == "role_loop") *value = e.role_looped ? 1 : 0;
+  else if (k == "pipeline") *value = e.opt_pipeline;
+  else if (k == "pipeline_active") *value = rpm::dev_pipeline_active(e);
   else return fail(e, RPM_E_INVALID, "unknown option");
   return RPM_OK;
 }

@@ -53,6 +53,7 @@ struct KParams {
   double tol;
   int P, L, n, m, m_nl, nnz, nnz_nl, nnz_lin, nnz_const;
   int max_span, max_drow;
+  int max_cshare;                       // largest constant-block share of a tile (c_cnt)
   int diag_mask;                        // ablation mask, only honoured by the -DRPM_DIAG diagnostic build
   unsigned long long* trace;            // per-workgroup timestamps (diagnostic build with RPM_DIAG_TRACE set), else NULL
 };
@@ -88,6 +89,9 @@ struct Device {
   std::vector<std::pair<const void*, size_t>> pinned;   // caller buffers registered with hipHostRegister
   bool cache_valid = false;     // d_g / d_values hold the pair of the x last uploaded
   size_t lds_bytes = 0;
+  int pl_slots = 0;             // resident workgroups the pipelined kernel is launched with (2 per CU)
+  size_t pl_lds = 0;
+  bool pl_ok = false;           // the mesh fits rpm_tile_pl_kernel's register staging
   // exact-Hessian tables
   HessPairDev* d_hpairs = nullptr;
   HessPhaseDev* d_hphases = nullptr;
@@ -114,18 +118,22 @@ struct Device {
 // ------------------------------------------------------------------------------------------
 // endpoint rows: events, linkages, linear rows.  Each work item (TaskDev) is one workgroup of the same
 // launch, so the three kinds run concurrently on different CUs.
-template <class Prob, bool WG, bool WJ, bool AN>
+// WAVE = true: the work item is done by ONE wave (lanes = perturbations, the base values travel by lane shuffle, no
+// workgroup barrier), so a wave of a workgroup that is busy with something else can take it (rpm_tile_pl_kernel).
+template <class Prob, bool WG, bool WJ, bool AN, bool WAVE = false>
 __device__ void endpoint_block(const KParams& K, const TaskDev task, const double* __restrict__ x,
                                double* __restrict__ g, double* __restrict__ vals, double* lds) {
   constexpr int NX = Prob::NX;
   constexpr int NE = Prob::NE_MAX > 0 ? Prob::NE_MAX : 1;
   constexpr int NL = Prob::NLINK_MAX > 0 ? Prob::NLINK_MAX : 1;
-  const int tid = threadIdx.x;
+  static_assert(!WAVE || 2 * NX + 3 <= 64, "endpoint perturbations must fit one wave");
+  const int tid = WAVE ? int(threadIdx.x & 63) : int(threadIdx.x);
+  const int nthr = WAVE ? 64 : int(blockDim.x);
   const double* c = K.consts;
   if (task.type == 0) {
     // linear rows  A_lin * x  (LpNLPWrapper.cpp:45; COO loop order of LpSparseMatrix.cpp:142-153) and
     // their constant Jacobian entries (:242)
-    for (int r = tid; r < K.P + K.L; r += blockDim.x) {
+    for (int r = tid; r < K.P + K.L; r += nthr) {
       if (WG) {
         double acc = 0.0;
         acc += K.alin_v[2 * r] * x[K.alin_j[2 * r]];
@@ -164,15 +172,24 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 #pragma unroll
     for (int i = 0; i < NE; ++i) ev[i] = 0.0;
     if (act && (pi == 0 || !AN)) Prob::event(ph.phase_num, t0, x0, tf, xf, c, ev);
+    double base[NE];
+    if constexpr (WAVE) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) base[i] = __shfl(ev[i], 0, 64);
+    }
     if (pi == 0) {
 #pragma unroll
       for (int i = 0; i < NE; ++i)
         if (i < ph.ne) {
-          lds[i] = ev[i];
+          if (!WAVE) lds[i] = ev[i];
           if (WG) g[ph.g0 + (NX + Prob::NC) * ph.N + i] = ev[i];
         }
     }
-    __syncthreads();
+    if constexpr (!WAVE) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NE; ++i) base[i] = lds[i];
+    }
     if (WJ && act && pi >= 1) {
       const int v = pi - 1;
       double de[NE];
@@ -180,7 +197,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
         Prob::event_jac_col(ph.phase_num, v, t0, x0, tf, xf, c, de);
       } else {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) de[i] = (ev[i] - lds[i]) / h;
+        for (int i = 0; i < NE; ++i) de[i] = (ev[i] - base[i]) / h;
       }
       // position inside an event's row of entries: (x0_j, xf_j) pairs, then t0, tf (:837-853)
       int pos;
@@ -218,15 +235,24 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 #pragma unroll
     for (int i = 0; i < NL; ++i) lo[i] = 0.0;
     if (act && (pi == 0 || !AN)) Prob::link(lk.left + 1, lk.right + 1, xl, xr, c, lk.nlink, lo);
+    double base[NL];
+    if constexpr (WAVE) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) base[i] = __shfl(lo[i], 0, 64);
+    }
     if (pi == 0) {
 #pragma unroll
       for (int i = 0; i < NL; ++i)
         if (i < lk.nlink) {
-          lds[i] = lo[i];
+          if (!WAVE) lds[i] = lo[i];
           if (WG) g[lk.g0 + i] = lo[i];
         }
     }
-    __syncthreads();
+    if constexpr (!WAVE) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NL; ++i) base[i] = lds[i];
+    }
     if (WJ && act && pi >= 1) {
       const int v = pi - 1;
       double dl[NL];
@@ -234,7 +260,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
         Prob::link_jac_col(lk.left + 1, lk.right + 1, v, xl, xr, c, lk.nlink, dl);
       } else {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) dl[i] = (lo[i] - lds[i]) / (1.0 * h);
+        for (int i = 0; i < NL; ++i) dl[i] = (lo[i] - base[i]) / (1.0 * h);
       }
 #pragma unroll
       for (int i = 0; i < NL; ++i)
@@ -555,7 +581,7 @@ __global__ __launch_bounds__(T* RG) RPM_RL_ATTR void rpm_tile_rl_kernel(const KP
   double* Us = Xs + NX * K.max_span;
   double* Ds = Us + NU * T;
   double* Fb = Ds + K.max_drow;
-  const int kk = tid % T, grp = tid / T;
+  const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
   const int kc = kk < tl.cnt ? kk : tl.cnt - 1;
   const int k = tl.k0 + kc;
   const int nidx = ph.node0 + k;
@@ -717,6 +743,320 @@ __global__ __launch_bounds__(T* RG) RPM_RL_ATTR void rpm_tile_rl_kernel(const KP
     }
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// rpm_tile_pl_kernel ("pipelined"): the role-looped layout made persistent and wave-specialised.  Why: the per-
+// workgroup timeline of rpm_tile_rl_kernel is serial (input loads 4-5 us behind the store traffic, 3 dynamics passes,
+// then a 2.5 us burst of constant-block stores that blocks the issuing waves), every workgroup of a launch is in the
+// same phase at the same time, and a launch is only two residency rounds, so neither the SIMDs (busy 35 %) nor HBM
+// (busy 45 %) are kept fed (tools/trace_timeline.py).  Here a workgroup is 4 compute waves + 1 DMA wave and walks
+// tiles w, w+G, w+2G, ...:
+//   * the DMA wave loads the NEXT tile's inputs (tile record, x rows, D rows, node records) into registers while the
+//     compute waves work on the current one, parks them in the other LDS staging buffer, and writes the current
+//     tile's share of the constant Doffdiag block, so the compute waves never wait for a load or a store burst;
+//   * the compute waves run exactly the role loop of rpm_tile_rl_kernel (same arithmetic, same output order:
+//     bit-identical results, tests/test_gpu_parity.py) out of the staged buffer;
+//   * endpoint work items (events, linkages, linear rows) are taken by DMA waves once their tiles are done, one wave
+//     each (endpoint_block<..., WAVE = true>).
+// Two workgroup barriers per tile (A: staging buffer ready, F: unperturbed dynamics published), executed by all five
+// waves.  Host-checked limits of the register staging: max_span <= 128*PL_XCH, max_drow <= 128*PL_DCH, a tile's
+// constant share <= 128*PL_CCH, 2 NX + 3 <= 64.
+constexpr int PL_CCH = 5, PL_REC = 32;   // a tile's constant share: at most 2 * PL_CCH chunks of 128 doubles (16 B per lane)
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // a pair of doubles at 8-byte alignment
+#define RPM_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define RPM_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+// One wave copies `len` doubles from global memory straight into LDS (both sides 8-byte aligned).  Inlined (a call
+// would start with s_waitcnt 0 and serialise the loads) but not unrolled: the DMA wave runs this code once per tile,
+// so it should be small enough to stay in the instruction cache.
+__device__ __forceinline__ void pl_dma_run(const double* gsrc, double* ldst, int len, int lane) {
+  const int pairs = len >> 1;
+#pragma unroll 1
+  for (int ch = 0; ch * 64 < pairs; ++ch)
+    if (ch * 64 + lane < pairs)
+      __builtin_amdgcn_global_load_lds(RPM_GPTR(gsrc + ch * 128 + 2 * lane), RPM_LPTR(ldst + ch * 128), 16, 0, 0);
+  if ((len & 1) && lane < 2)   // odd tail: the last double as two dwords
+    __builtin_amdgcn_global_load_lds(RPM_GPTR(reinterpret_cast<const int*>(gsrc + len - 1) + lane),
+                                     RPM_LPTR(ldst + len - 1), 4, 0, 0);
+}
+
+constexpr int PL_HALF = 64 * 4 + 128;   // threads of one half-workgroup: 4 compute waves + 2 DMA waves
+
+template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
+__global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams K, int n_inst,
+                                                                 const double* __restrict__ xall,
+                                                                 double* __restrict__ gall,
+                                                                 double* __restrict__ vall) {
+  static_assert(T == 64 && RG == 4, "a role of a tile is one wave, four role groups per tile");
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
+  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1;
+  constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
+  constexpr int R = WJ ? NV + 1 : (NX > 0 ? NX : 1);
+  constexpr int NCs = NC > 0 ? NC : 1;
+  constexpr int NTHR = T * RG;
+  constexpr int NREC = int(sizeof(TileDev) / sizeof(int));
+  static_assert(NREC < PL_REC, "tile record plus the instance index must fit the staged record");
+  extern __shared__ double lds_all[];
+  // A workgroup is two independent halves (one CU holds exactly one workgroup: 12 waves, 3 per SIMD at the 168-VGPR
+  // budget, each SIMD 2 compute + 1 DMA wave; separate 5- or 6-wave workgroups do not pack).  The halves only share
+  // the barriers.
+  const int half = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / PL_HALF);   // wave-uniform: keeps w, the tile index and the record in SGPRs
+  const int tid = int(threadIdx.x) - half * PL_HALF;
+  const int G = 2 * int(gridDim.x), w = 2 * int(blockIdx.x) + half;
+  const int nt = K.n_my_tiles;
+  const int W = nt * n_inst;
+  const int n_iter = w < W ? (W - w + G - 1) / G : 0;                      // items w, w + G, ... of this half
+  const int n_iter_wg = (W - 2 * int(blockIdx.x) + G - 1) / G;             // of half 0: the barrier count of the workgroup
+  // one staging buffer (doubles): record, next tile's record | t0 tf | X rows | U rows | D rows | tau | diag | node
+  // records | const share
+  const int S_TT = PL_REC, S_X = S_TT + 2, S_U = S_X + NX * K.max_span, S_D = S_U + NU * T;
+  const int S_TAU = S_D + K.max_drow, S_DG = S_TAU + T, S_ND = S_DG + T, S_CV = S_ND + 2 * T;
+  const int S_SIZE = S_CV + (WJ ? K.max_cshare : 0);
+  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T);
+  double* Fb = lds + 2 * S_SIZE;
+  const double* __restrict__ c = K.consts;
+#ifdef RPM_DIAG
+#define RPM_PTRC(j, slot)                                                           \
+  if (K.trace && (threadIdx.x & 63) == 0 && (j) < 2) K.trace[size_t(w) * 64 + (j)*32 + (slot)] = wall_clock64()
+#else
+#define RPM_PTRC(j, slot)
+#endif
+  if (tid == 0) { RPM_PTRC(0, 31); }
+
+  if (tid >= NTHR) {
+    // ---------------- DMA waves (two per half: a direct-to-LDS load takes ~60 ns to issue, so the runs of a tile
+    // and the chunks of the constant block are dealt alternately to the two) ----------------
+    const int lane = (tid - NTHR) & 63;
+    const int dw = __builtin_amdgcn_readfirstlane((tid - NTHR) >> 6);
+    // The next tile's inputs go from global memory straight into the other LDS staging buffer
+    // (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip): the DMA wave only issues them.
+    auto run = [&](const double* gsrc, double* ldst, int len) { pl_dma_run(gsrc, ldst, len, lane); };
+    // The addresses of a tile's runs come from its record.  In steady state that record is already in LDS (each
+    // staging buffer also carries the record of the tile AFTER its own), so issuing the next tile's loads never waits
+    // for global memory; only the first tile of a workgroup reads its record from HBM.
+    struct TileRuns { int k0, cnt, span0, span_len, drow0, drow_len, N, x_state0, x_control0, x_t0, node0, c_src0, c_cnt; };
+    auto runs_of = [&](const int* p) {
+      TileRuns r;
+#define RPM_RF(f) r.f = __builtin_amdgcn_readfirstlane(p[offsetof(TileDev, f) / 4])
+      RPM_RF(k0); RPM_RF(cnt); RPM_RF(span0); RPM_RF(span_len); RPM_RF(drow0); RPM_RF(drow_len); RPM_RF(N);
+      RPM_RF(x_state0); RPM_RF(x_control0); RPM_RF(x_t0); RPM_RF(node0); RPM_RF(c_src0); RPM_RF(c_cnt);
+#undef RPM_RF
+      return r;
+    };
+    auto stage = [&](int item, double* buf, const TileRuns tl) {
+      const int inst = item / nt, tidx = item - inst * nt;
+      const double* __restrict__ x = xall + size_t(inst) * K.n;
+      static_assert(NREC % 2 == 0 && sizeof(TileDev) % 8 == 0, "the tile record is copied as doubles");
+      if (dw == 0) {
+        if (lane == 0) reinterpret_cast<int*>(buf)[NREC] = inst;   // before the direct loads: an LDS write after them waits for them
+        run(reinterpret_cast<const double*>(K.tiles + tidx), buf, NREC / 2);
+        if (item + G < W) {   // the record of this half's tile after this one
+          const int item2 = item + G, inst2 = item2 / nt;
+          run(reinterpret_cast<const double*>(K.tiles + (item2 - inst2 * nt)), buf + PL_REC / 2, NREC / 2);
+        }
+        run(x + tl.x_t0, buf + S_TT, 2);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if ((i & 1) == dw) run(x + tl.x_state0 + i * (tl.N + 1) + tl.span0, buf + S_X + i * K.max_span, tl.span_len);
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        if ((j & 1) != dw) run(x + tl.x_control0 + j * tl.N + tl.k0, buf + S_U + j * T, tl.cnt);
+      if (dw == 0) {
+        if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
+        run(K.points + tl.node0 + tl.k0, buf + S_TAU, tl.cnt);
+      } else {
+        if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
+        if (WJ) run(K.diag + tl.node0 + tl.k0, buf + S_DG, tl.cnt);
+        run(reinterpret_cast<const double*>(K.nodes + tl.node0 + tl.k0), buf + S_ND, 2 * tl.cnt);
+      }
+    };
+    if (n_iter > 0) stage(w, lds, runs_of(reinterpret_cast<const int*>(K.tiles + (w - (w / nt) * nt))));
+    for (int j = 0; j < n_iter_wg; ++j) {
+      const double* cur = lds + (j & 1) * S_SIZE;
+      double* nxt = lds + ((j + 1) & 1) * S_SIZE;
+      __builtin_amdgcn_s_waitcnt(0);   // the staged loads (and the constant stores before them) have landed
+      __syncthreads();                 // A: buffer `cur` is complete
+      RPM_PTRC(j, 16);
+      // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718): LDS -> registers now, so that no
+      // LDS read of this wave sits behind the direct-to-LDS loads issued next
+      d2u cv[PL_CCH];
+      int c_cnt = 0, c_stride = 0;
+      double* __restrict__ cdst = nullptr;
+      double ctail = 0.0;
+      if (WJ && j < n_iter) {
+        const int* rec = reinterpret_cast<const int*>(cur);
+        const int c_dst0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_dst0) / 4]);
+        const int inst = __builtin_amdgcn_readfirstlane(rec[NREC]);
+        c_cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_cnt) / 4]);
+        c_stride = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_stride) / 4]);
+        cdst = vall + size_t(inst) * K.nnz + c_dst0;
+#pragma unroll
+        for (int ch = 0; ch < PL_CCH; ++ch) {
+          const int q = min((2 * ch + dw) * 128 + 2 * lane, c_cnt - 2);
+          cv[ch].x = cur[S_CV + q];
+          cv[ch].y = cur[S_CV + q + 1];
+        }
+        ctail = cur[S_CV + c_cnt - 1];
+      }
+      const bool more = j + 1 < n_iter;
+      if (more) stage(w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
+      RPM_PTRC(j, 17);
+      __syncthreads();   // F (the compute waves publish the unperturbed dynamics here)
+      RPM_PTRC(j, 18);
+      if (WJ && j < n_iter) {
+#pragma unroll
+        for (int ch = 0; ch < PL_CCH; ++ch) {
+          const int q = (2 * ch + dw) * 128 + 2 * lane;   // 16 B per lane: 1 KB per store instruction
+          if (q + 1 < c_cnt) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) *reinterpret_cast<d2u*>(cdst + size_t(i) * c_stride + q) = cv[ch];
+          }
+        }
+        if ((c_cnt & 1) && dw == 0 && lane < NX) cdst[size_t(lane) * c_stride + c_cnt - 1] = ctail;
+      }
+      RPM_PTRC(j, 19);
+    }
+    // endpoint work items of this half, one wave each
+    const int n_end = K.n_tasks * n_inst;
+    for (int it = 2 * w + dw; it < n_end; it += 2 * G) {
+      const int inst = it / K.n_tasks;
+      endpoint_block<Prob, WG, WJ, AN, true>(K, K.tasks[it - inst * K.n_tasks], xall + size_t(inst) * K.n,
+                                             gall + size_t(inst) * K.m, vall + size_t(inst) * K.nnz, nullptr);
+    }
+    return;
+  }
+
+  // ---------------- compute waves: the role loop of rpm_tile_rl_kernel out of the staged buffer ----------------
+  const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
+  for (int jt = 0; jt < n_iter_wg; ++jt) {
+    const double* cur = lds + (jt & 1) * S_SIZE;
+    __syncthreads();   // A
+    if (jt >= n_iter) {   // the other half still has a tile: keep the barrier count
+      __syncthreads();   // F
+      continue;
+    }
+    RPM_PTRC(jt, grp * 4 + 0);
+    const int* rec = reinterpret_cast<const int*>(cur);
+    const int k0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, k0) / 4]);
+    const int cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, cnt) / 4]);
+    const int span0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, span0) / 4]);
+    const int drow0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, drow0) / 4]);
+    const int N = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, N) / 4]);
+    const int phase_num = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, phase_num) / 4]);
+    const int g0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, g0) / 4]);
+    const int v_nl0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, v_nl0) / 4]);
+    const int inst = __builtin_amdgcn_readfirstlane(rec[NREC]);
+    double* __restrict__ g = gall + size_t(inst) * K.m;
+    double* __restrict__ vals = vall + size_t(inst) * K.nnz;
+    const double* Xs = cur + S_X;
+    const double* Us = cur + S_U;
+    const double* Ds = cur + S_D;
+    const int kc = kk < cnt ? kk : cnt - 1;
+    const int k = k0 + kc;
+    const bool node_ok = kk < cnt;
+    bool first = true;
+    // per-pass scalars (tau, t0, tf, the node record, the diagonal of D) are re-read from LDS where they are used
+    // instead of living in registers across the dynamics call: the 10-wave workgroup has 168 VGPRs per lane
+    for (int role = grp; role < R || first; role += RG) {
+      const bool act = node_ok && role < R;
+      double xs[NXs], us[NUs];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - span0)];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) us[j] = Us[j * T + kc];
+      double tk;
+      {
+        const double tau = cur[S_TAU + kc], t0 = cur[S_TT], tf = cur[S_TT + 1];
+        tk = (tau + 1) * ((tf - t0) / 2.0) + t0;      // LpNLPWrapper.cpp:80
+      }
+      const int sv = WJ ? role - 1 : role;
+      double dx = 0.0;
+      if (WG && sv >= 0 && sv < NX) {   // D.X in the reference's ascending-column order (LpSparseMatrix.cpp:142-153)
+        const NodeDev nd = reinterpret_cast<const NodeDev*>(cur + S_ND)[kc];
+        const double* drow = Ds + (nd.drow_off - drow0);
+        const double* xcol = Xs + sv * K.max_span + (nd.dcol0 - span0);
+        for (int j = 0; j < nd.dlen; ++j) dx += drow[j] * xcol[j];
+      }
+      double h = 1.0;
+      const int v = role - 1;
+      if (WJ && !AN && role >= 1) {     // h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214)
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          if (v == i) { h = K.tol * (1 + fabs(xs[i])); xs[i] += h; }
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+          if (v == NX + j) { h = K.tol * (1 + fabs(us[j])); us[j] += h; }
+        if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
+      }
+      double f[NXs], cp[NCs];
+      if (!AN || role == 0) {
+        Prob::dae(phase_num, tk, xs, us, c, f, cp);
+      } else if constexpr (AN) {
+        Prob::dae_jac_col(phase_num, v, tk, xs, us, c, f, cp);
+      }
+      if (first) {   // wave-uniform: the first pass publishes the unperturbed outputs before anyone forms a difference
+        if (role == 0 && act) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) Fb[i * T + kk] = f[i];
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            Fb[(NX + j) * T + kk] = cp[j];
+            if (WG) g[g0 + (NX + j) * N + k] = cp[j];           // path rows, :138-164
+          }
+        }
+        RPM_PTRC(jt, grp * 4 + 1);
+        __syncthreads();   // F
+        RPM_PTRC(jt, grp * 4 + 2);
+        first = false;
+      }
+      if (act) {
+        const double tau = cur[S_TAU + kc], t0 = cur[S_TT], tf = cur[S_TT + 1];
+        const double ddiag = cur[S_DG + kc];
+        if (WG && sv >= 0 && sv < NX) g[g0 + sv * N + k] = dx - Fb[sv * T + kk] * ((tf - t0) / 2.0);   // defects, :113,122
+        if (WJ && role >= 1) {
+          double J[NO];
+#pragma unroll
+          for (int o = 0; o < NO; ++o) {
+            const double pert = o < NX ? f[o < NX ? o : 0] : cp[o >= NX ? o - NX : 0];
+            J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
+          }
+          double* vb = vals + v_nl0 + k;
+          if (v < NX + NU) {            // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+              double val;
+              if (o < NX) {
+                const double ret = J[o] * (tf - t0) / 2.0;
+                val = (o == v) ? ddiag - ret : -ret;
+              } else {
+                val = J[o];
+              }
+              vb[size_t(o * NB + v) * N] = val;
+            }
+          } else {                       // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign kept
+            const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+              double v0, vf;
+              if (o < NX) {
+                const double fb = Fb[o * T + kk];
+                const double dt = J[o] * (tf - t0) / 2.0;
+                v0 = fb * (0.5) - a0 * dt;
+                vf = -fb * (0.5) + af * dt;
+              } else {
+                v0 = a0 * J[o];
+                vf = af * J[o];
+              }
+              vb[size_t(o * NB + NX + NU) * N] = v0;
+              vb[size_t(o * NB + NX + NU + 1) * N] = vf;
+            }
+          }
+        }
+      }
+    }
+    RPM_PTRC(jt, grp * 4 + 3);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1503,6 +1843,8 @@ int device_init(Engine& e, int device_id) {
   k.nnz_const = e.nnz_const;
   k.max_span = e.max_span;
   k.max_drow = e.max_drow;
+  k.max_cshare = 0;
+  for (const TileDev& t : e.tiles) k.max_cshare = t.c_cnt > k.max_cshare ? t.c_cnt : k.max_cshare;
   const bool sharded = e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1;
   k.tasks = d->d_tasks;
   k.n_tasks = (!sharded || e.shard_rank == 0) ? int(e.tasks.size()) : 0;  // rank 0 owns the endpoint rows
@@ -1510,7 +1852,8 @@ int device_init(Engine& e, int device_id) {
   k.trace = nullptr;
 #ifdef RPM_DIAG
   if (getenv("RPM_DIAG_TRACE")) {
-    const size_t words = size_t(e.tiles.size() * 2 + e.tasks.size() + 64) * size_t(e.n_instances) * 8;
+    size_t words = size_t(e.tiles.size() * 2 + e.tasks.size() + 64) * size_t(e.n_instances) * 8;
+    if (words < size_t(4096) * 64) words = size_t(4096) * 64;   // the pipelined kernel traces 64 words per half-workgroup
     if (hipMalloc(reinterpret_cast<void**>(&k.trace), words * 8) == hipSuccess) (void)hipMemset(k.trace, 0, words * 8);
     d->trace_words = words;
   }
@@ -1522,6 +1865,15 @@ int device_init(Engine& e, int device_id) {
   if (d->lds_bytes > 160 * 1024) {
     e.err = "mesh interval too large for the LDS-staged D tile (reduce nodes per interval)";
     return RPM_E_UNSUPPORTED;
+  }
+  {   // rpm_tile_pl_kernel: one workgroup of two 5-wave halves per CU, inputs staged through registers of the DMA waves
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu <= 0) ncu = 256;
+    d->pl_slots = 2 * ncu;
+    const int max_c = d->kp.max_cshare;
+    const size_t stage = size_t(PL_REC + 2) + size_t(pd.nx) * e.max_span + size_t(pd.nu) * 64 + e.max_drow + 4 * 64 + max_c;
+    d->pl_lds = 2 * (2 * stage + size_t(pd.nx + pd.nc) * 64) * sizeof(double);
+    d->pl_ok = e.role_looped && e.tile_nodes == 64 && max_c <= 2 * 128 * PL_CCH && max_c >= 2 && 2 * pd.nx + 3 <= 64 && d->pl_lds <= 160 * 1024;
   }
   return RPM_OK;
 }
@@ -1559,9 +1911,46 @@ static hipError_t launch_tile_rl(const Engine& e, const double* dx, double* dg, 
   return hipGetLastError();
 }
 
+template <class Prob, bool WG, bool WJ, bool AN>
+static hipError_t launch_tile_pl(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
+  const Device& d = *e.dev;
+  auto kern = rpm_tile_pl_kernel<Prob, 64, 4, WG, WJ, AN>;
+  if (d.pl_lds > 64 * 1024) {
+    hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(d.pl_lds));
+    if (s != hipSuccess) return s;
+  }
+  const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
+  const long long halves = W < d.pl_slots ? W : d.pl_slots;
+  hipLaunchKernelGGL(kern, dim3(unsigned((halves + 1) / 2)), dim3(2 * PL_HALF), d.pl_lds, st, d.kp, e.n_instances, dx, dg, dv);
+  return hipGetLastError();
+}
+
+// the pipelined kernel pays off once every resident workgroup has at least two tiles to walk
+static bool use_pipeline(const Engine& e) {
+  const Device& d = *e.dev;
+  if (!d.pl_ok || e.opt_pipeline == 0 || d.kp.n_my_tiles <= 0) return false;
+  if (e.opt_pipeline == 1) return true;
+  return (long long)d.kp.n_my_tiles * e.n_instances >= 2LL * d.pl_slots;
+}
+
+int dev_pipeline_active(const Engine& e) { return e.dev && e.role_looped && e.opt_dx_mode == 0 && use_pipeline(e) ? 1 : 0; }
+
 template <class Prob, int T>
 static hipError_t launch_tile_T(const Engine& e, bool wg, bool wj, const double* dx, double* dg, double* dv,
                                 hipStream_t st) {
+  if (e.role_looped && T == 64 && e.opt_dx_mode == 0 && use_pipeline(e)) {
+    const bool an_pl = e.first_derive == RPM_DERIVE_ANALYTIC;
+    if constexpr (Prob::HAS_ANALYTIC) {
+      if (an_pl) {
+        if (wg && wj) return launch_tile_pl<Prob, true, true, true>(e, dx, dg, dv, st);
+        if (wj) return launch_tile_pl<Prob, false, true, true>(e, dx, dg, dv, st);
+      }
+    }
+    if (wg && wj) return launch_tile_pl<Prob, true, true, false>(e, dx, dg, dv, st);
+    if (wj) return launch_tile_pl<Prob, false, true, false>(e, dx, dg, dv, st);
+    return launch_tile_pl<Prob, true, false, false>(e, dx, dg, dv, st);
+  }
   if (e.role_looped && T == 64 && e.opt_dx_mode == 0) {   // throughput layout (see rpm_tile_rl_kernel)
     const bool an_rl = e.first_derive == RPM_DERIVE_ANALYTIC;
     if constexpr (Prob::HAS_ANALYTIC) {

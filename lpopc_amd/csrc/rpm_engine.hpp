@@ -158,6 +158,7 @@ struct Engine {
   // options
   int opt_fuse_pair = 1, opt_dx_mode = 0, opt_tile_nodes = 0, opt_check_finite = 1, opt_const_once = 0;
   int opt_role_loop = -1;        // -1 automatic, 0 never, 1 always (when tile_nodes is automatic)
+  int opt_pipeline = -1;         // rpm_tile_pl_kernel: -1 automatic (>= 2 tiles per resident workgroup), 0 never, 1 whenever the mesh fits
   int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
   std::vector<double> sol_x, sol_lambda;
@@ -205,6 +206,7 @@ void device_destroy(Engine& e);
 int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, int flags, void* stream);
 // objective (d_obj, one per instance) and, when d_grad != nullptr, its gradient
 int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream);
+int dev_pipeline_active(const Engine& e);   // 1 when the next constraint launch uses rpm_tile_pl_kernel
 int dev_upload_x(Engine& e, const double* x);
 int dev_upload(Engine& e, double* dev, const double* host, size_t count);
 int dev_download(Engine& e, double* host, const double* dev, size_t count);

@@ -340,6 +340,45 @@ def test_role_looped_layout_is_bit_identical(built, name, make, mode):
         b2.close()
 
 
+@pytest.mark.parametrize("name,make,mode,B", [(CASES[5][0], CASES[5][1], CASES[5][2], 20), (CASES[6][0], CASES[6][1], CASES[6][2], 7),
+                                              (CASES[7][0], CASES[7][1], CASES[7][2], 3), ("launch_metric", lambda: problems.config("launch"), "perturb", 18)],
+                         ids=[CASES[5][0], CASES[6][0], CASES[7][0], "launch_metric"])
+def test_pipelined_kernel_is_bit_identical(built, name, make, mode, B):
+    """rpm_tile_pl_kernel (persistent workgroups: 4 compute waves + 1 DMA wave, endpoint items on the DMA waves) writes
+    exactly what the role-looped kernel writes: g, Jacobian, every instance, whether a workgroup walks one tile or
+    several (B is chosen so that some workgroups get one tile more than others), and in the g-only / J-only variants."""
+    import torch
+    prob = make()
+    ref = NLPEngine(prob, n_instances=B, device=0, role_loop=1)
+    pl = NLPEngine(prob, n_instances=B, device=0, role_loop=1)
+    ref.set_option("pipeline", 0)
+    pl.set_option("pipeline", 1)
+    xl, xu, _, _ = ref.get_bounds_info()
+    one = NLPEngine(prob, device=0)
+    x0 = one.get_starting_point()
+    one.close()
+    xs = np.stack([problems.seeded_iterate(x0, xl, xu, 90 + i, mode) for i in range(B)])
+    dx = torch.from_numpy(xs).cuda()
+    out = []
+    for eng in (ref, pl):
+        dg = torch.full((B, ref.m), np.nan, dtype=torch.float64, device="cuda")
+        dv = torch.full((B, ref.nnz_jac), np.nan, dtype=torch.float64, device="cuda")
+        eng.eval_pair_dev(dx, dg, dv)
+        dg2 = torch.full((B, ref.m), np.nan, dtype=torch.float64, device="cuda")
+        dv2 = torch.full((B, ref.nnz_jac), np.nan, dtype=torch.float64, device="cuda")
+        eng.eval_g_dev(dx, dg2)
+        eng.eval_jac_g_dev(dx, dv2)
+        torch.cuda.synchronize()
+        assert eng.get_option("pipeline_active") == (1 if eng is pl else 0)
+        out.append([t.cpu().numpy() for t in (dg, dv, dg2, dv2)])
+    for a, b in zip(out[0], out[1]):
+        assert not np.isnan(b).any()
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[1][0], out[1][2]) and np.array_equal(out[1][1], out[1][3])
+    ref.close()
+    pl.close()
+
+
 # ---- solution extraction (Nlp2OpConverter::Nlp2OpControl, SURVEY §8 row f-4) --------------------------------
 @pytest.mark.parametrize("name,make", [("launch", lambda: problems.launch(3, 6)), ("quadrotor", lambda: problems.quadrotor(4, 5)),
                                        ("hypersensitive", lambda: problems.config("hypersensitive")),

@@ -1,0 +1,55 @@
+"""Timeline of rpm_tile_pl_kernel's first two tiles per workgroup (diagnostic build, perf exploration only).
+Run on the GPU box:  python tools/trace_pipeline.py [instances]"""
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+os.environ["RPM_HIP_LIB"] = os.path.join(root, "lpopc_amd", "csrc", "librpm_hip_diag.so")
+os.environ["RPM_DIAG_TRACE"] = out = os.path.join(root, "gpurun_out", "trace_pl.bin")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+import numpy as np
+import torch
+
+from lpopc_amd import problems
+from lpopc_amd.engine import NLPEngine
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+prob = problems.config("launch")
+eng = NLPEngine(prob, n_instances=B, device=0)
+eng.set_option("pipeline", 1)
+xl, xu, _, _ = eng.get_bounds_info()
+x0 = eng.get_starting_point()
+R = 4
+xs = np.stack([problems.seeded_iterate(x0, xl, xu, s) for s in range(R * B)]).reshape(R, B * eng.n)
+d_x = torch.from_numpy(xs).cuda()
+d_g = torch.empty((R, B * eng.m), dtype=torch.float64, device="cuda")
+d_v = torch.empty((R, B * eng.nnz_jac), dtype=torch.float64, device="cuda")
+for k in range(12):
+    eng.eval_pair_dev(d_x[k % R], d_g[k % R], d_v[k % R])
+torch.cuda.synchronize()
+assert eng.get_option("pipeline_active") == 1
+eng.close()
+t = np.fromfile(out, dtype=np.uint64)
+G = 512
+t = t[:G * 64].reshape(G, 2, 32).astype(np.float64) * 0.01
+t00 = t[:, 0, 31].min()
+
+
+def stat(name, a):
+    print("  %-52s mean %6.2f  p10 %6.2f  p90 %6.2f" % (name, a.mean(), np.percentile(a, 10), np.percentile(a, 90)))
+
+
+stat("kernel start (rel. first)", t[:, 0, 31] - t00)
+for j in (0, 1):
+    print("tile", j, " A passed at %.2f" % (t[:, j, 0] - t00).mean())
+    for wv in range(4):
+        b = wv * 4
+        stat("wave %d: first pass (A -> arrive F)" % wv, t[:, j, b + 1] - t[:, j, b])
+        stat("wave %d: wait at F" % wv, t[:, j, b + 2] - t[:, j, b + 1])
+        stat("wave %d: later passes (F -> end)" % wv, t[:, j, b + 3] - t[:, j, b + 2])
+    stat("dma: A -> loads issued", t[:, j, 17] - t[:, j, 16])
+    stat("dma: wait at F", t[:, j, 18] - t[:, j, 17])
+    stat("dma: const stores issued", t[:, j, 19] - t[:, j, 18])
+    print("  tile end (slowest wave, abs): mean %.2f" % (t[:, j, [3, 7, 11, 15]].max(axis=1) - t00).mean())
+print("kernel end: %.2f" % (t[:, 1, [3, 7, 11, 15]].max() - t00))
