@@ -25,6 +25,16 @@ namespace rpm {
 // Delta-III launch vehicle ascent — example/launch/Launch.cpp:636-765
 // consts: [0..8] omega_matrix (column-major), 9 mu, 10 cd, 11 sa, 12 rho0, 13 H, 14 Re, 15 g0,
 //         16 thrust_srb, 17 thrust_first, 18 thrust_second, 19 ISP_srb, 20 ISP_first, 21 ISP_second
+// x^3 rounded once: the square and the product are formed exactly (FMA residuals) and summed, so the result is the
+// correctly rounded cube except in near-tie cases.  Stands for std::pow(x, 3.0), which is what the reference's
+// arma::pow(rad, 3) calls (example/launch/Launch.cpp:685): it equals glibc's pow in 99.9 % of inputs and is within
+// 1 ulp otherwise (tools/ubench/cube_vs_pow.c), at 6 flops instead of a ~180-instruction generic pow.
+RPM_DEV double cube_rn(double x) {
+  const double p = x * x, ep = fma(x, x, -p);
+  const double q = p * x, eq = fma(p, x, -q);
+  return q + (eq + ep * x);
+}
+
 struct LaunchProblem {
   static constexpr int ID = RPM_PROBLEM_LAUNCH;
   static constexpr int NX = 7, NU = 3, NC = 1, NE_MAX = 5, NLINK_MAX = 7, NCONST = 22;
@@ -53,7 +63,7 @@ struct LaunchProblem {
 #ifdef RPM_EXP_CUBE
     const double mu3 = (1.0 * c[9]) / (rad * rad * rad);
 #else
-    const double mu3 = (1.0 * c[9]) / pow(rad, 3.0);                   // :683-684
+    const double mu3 = (1.0 * c[9]) / cube_rn(rad);                    // mu / pow(rad, 3), :683-684
 #endif
     double T_tot, mdot;
     if (ph == 1 || ph == 2) {                                          // :688-711

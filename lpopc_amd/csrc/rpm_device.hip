@@ -927,6 +927,11 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
     return;
   }
 
+#ifdef RPM_DIAG
+#define RPM_JSTORE(dst, val) if (!(K.diag_mask & 8) || (val) == 1e300) dst = (val)
+#else
+#define RPM_JSTORE(dst, val) dst = (val)
+#endif
   // ---------------- compute waves: the role loop of rpm_tile_rl_kernel out of the staged buffer ----------------
   const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
   for (int jt = 0; jt < n_iter_wg; ++jt) {
@@ -960,6 +965,10 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
     // instead of living in registers across the dynamics call: the 10-wave workgroup has 168 VGPRs per lane
     for (int role = grp; role < R || first; role += RG) {
       const bool act = node_ok && role < R;
+#ifdef RPM_DIAG
+      const bool trc = role == 1 + RG;
+      if (trc) { RPM_PTRC(jt, 24); }
+#endif
       double xs[NXs], us[NUs];
 #pragma unroll
       for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - span0)];
@@ -976,8 +985,21 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
         const NodeDev nd = reinterpret_cast<const NodeDev*>(cur + S_ND)[kc];
         const double* drow = Ds + (nd.drow_off - drow0);
         const double* xcol = Xs + sv * K.max_span + (nd.dcol0 - span0);
-        for (int j = 0; j < nd.dlen; ++j) dx += drow[j] * xcol[j];
+        // same ascending order, operands fetched four columns at a time so that the LDS latency is paid per batch
+        int j = 0;
+        for (; j + 4 <= nd.dlen; j += 4) {
+          const double d0 = drow[j], d1 = drow[j + 1], d2 = drow[j + 2], d3 = drow[j + 3];
+          const double x0 = xcol[j], x1 = xcol[j + 1], x2 = xcol[j + 2], x3 = xcol[j + 3];
+          dx += d0 * x0;
+          dx += d1 * x1;
+          dx += d2 * x2;
+          dx += d3 * x3;
+        }
+        for (; j < nd.dlen; ++j) dx += drow[j] * xcol[j];
       }
+#ifdef RPM_DIAG
+      if (trc) { if (dx == 1e300) xs[0] = 0; RPM_PTRC(jt, 25); }
+#endif
       double h = 1.0;
       const int v = role - 1;
       if (WJ && !AN && role >= 1) {     // h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214)
@@ -995,6 +1017,9 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
       } else if constexpr (AN) {
         Prob::dae_jac_col(phase_num, v, tk, xs, us, c, f, cp);
       }
+#ifdef RPM_DIAG
+      if (trc) { if (f[0] == 1e300) cp[0] = 0; RPM_PTRC(jt, 26); }
+#endif
       if (first) {   // wave-uniform: the first pass publishes the unperturbed outputs before anyone forms a difference
         if (role == 0 && act) {
 #pragma unroll
@@ -1021,7 +1046,7 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
             const double pert = o < NX ? f[o < NX ? o : 0] : cp[o >= NX ? o - NX : 0];
             J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
           }
-          double* vb = vals + v_nl0 + k;
+          double* __restrict__ vb = vals + v_nl0;   // block bases stay scalar; the node index k is the only per-lane part
           if (v < NX + NU) {            // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
@@ -1032,7 +1057,7 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
               } else {
                 val = J[o];
               }
-              vb[size_t(o * NB + v) * N] = val;
+              RPM_JSTORE((vb + size_t(o * NB + v) * N)[k], val);
             }
           } else {                       // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign kept
             const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
@@ -1048,12 +1073,15 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
                 v0 = a0 * J[o];
                 vf = af * J[o];
               }
-              vb[size_t(o * NB + NX + NU) * N] = v0;
-              vb[size_t(o * NB + NX + NU + 1) * N] = vf;
+              RPM_JSTORE((vb + size_t(o * NB + NX + NU) * N)[k], v0);
+              RPM_JSTORE((vb + size_t(o * NB + NX + NU + 1) * N)[k], vf);
             }
           }
         }
       }
+#ifdef RPM_DIAG
+      if (trc) { RPM_PTRC(jt, 27); }
+#endif
     }
     RPM_PTRC(jt, grp * 4 + 3);
   }

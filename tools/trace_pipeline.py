@@ -53,3 +53,8 @@ for j in (0, 1):
     stat("dma: const stores issued", t[:, j, 19] - t[:, j, 18])
     print("  tile end (slowest wave, abs): mean %.2f" % (t[:, j, [3, 7, 11, 15]].max(axis=1) - t00).mean())
 print("kernel end: %.2f" % (t[:, 1, [3, 7, 11, 15]].max() - t00))
+print("second pass of wave 1 (role 5: a velocity perturbation, with D.X):")
+for j in (0, 1):
+    stat("tile %d: LDS reads + D.X" % j, t[:, j, 25] - t[:, j, 24])
+    stat("tile %d: perturb + dynamics" % j, t[:, j, 26] - t[:, j, 25])
+    stat("tile %d: J, transform, g + J stores" % j, t[:, j, 27] - t[:, j, 26])
