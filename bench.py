@@ -75,6 +75,7 @@ def main():
                          "rocprofv3 --stats averages exactly the launches bench.py times")
     ap.add_argument("--dx-mode", type=int, default=0, help="0: scalar D.X in the reference's order, 1: FP64 MFMA tiles")
     ap.add_argument("--tile-nodes", type=int, default=0)
+    ap.add_argument("--role-loop", type=int, default=-1, help="-1 auto, 0 one role per thread, 1 role-looped 64-node tiles")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 role-looped kernel only, 1 force the pipelined kernel")
     ap.add_argument("--batch", type=int, default=16,
                     help="NLP iterates evaluated per launch (independent instances of the same problem)")
@@ -107,7 +108,7 @@ def main():
     if sharded and B != 1:
         raise SystemExit("--shard intervals evaluates one iterate per launch")
     eng = NLPEngine(prob, n_instances=B, shard_mode=1 if sharded else 0, shard_rank=rank if sharded else 0,
-                    shard_world=world if sharded else 1, tile_nodes=args.tile_nodes, device=local_rank)
+                    shard_world=world if sharded else 1, tile_nodes=args.tile_nodes, device=local_rank, role_loop=args.role_loop)
     if args.dx_mode:
         eng.set_option("dx_mode", args.dx_mode)
     if args.pipeline != -1:

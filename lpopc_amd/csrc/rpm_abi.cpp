@@ -487,7 +487,7 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
       long long total = 0;
       for (int i = 0; i < e.P; ++i) total += e.ph[i].N;
       total *= e.n_instances;
-      e.role_looped = value == 1 || (value == -1 && total / 64 >= 1024);
+      e.role_looped = value == 1 || (value == -1 && total / 64 >= 512);
       rpm::build_tiles(e, e.role_looped ? 64 : 16);
     }
   } else

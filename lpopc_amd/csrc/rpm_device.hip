@@ -1959,7 +1959,11 @@ static bool use_pipeline(const Engine& e) {
   const Device& d = *e.dev;
   if (!d.pl_ok || e.opt_pipeline == 0 || d.kp.n_my_tiles <= 0) return false;
   if (e.opt_pipeline == 1) return true;
-  return (long long)d.kp.n_my_tiles * e.n_instances >= 2LL * d.pl_slots;
+  // measured on the metric problem: it wins when every half-workgroup walks >= 2 tiles, or when the tiles fill the
+  // resident halves exactly once (the prefetch then hides nothing, but the DMA waves still take the constant block);
+  // in between, the second pass over a partly filled chip loses to the role-looped kernel
+  const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
+  return W >= 2LL * d.pl_slots || (W <= d.pl_slots && 4 * W >= 3LL * d.pl_slots);
 }
 
 int dev_pipeline_active(const Engine& e) { return e.dev && e.role_looped && e.opt_dx_mode == 0 && use_pipeline(e) ? 1 : 0; }

@@ -572,7 +572,7 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     e.doff_vals.insert(e.doff_vals.end(), p.off_v.begin(), p.off_v.end());
   }
   // tiling.  Small grids (one iterate per launch): 16 nodes x (nx+nu+2) roles per workgroup, every role its own
-  // thread — shortest critical path.  Large grids (>= 4 workgroups per CU even with 64-node tiles): the role-looped
+  // thread — shortest critical path.  Large grids (>= 2 workgroups per CU even with 64-node tiles): the role-looped
   // layout, 64 nodes x 4 role groups (rpm_tile_rl_kernel) — 512-byte store runs, one residency round.
   int T = e.opt_tile_nodes;
   e.role_looped = false;
@@ -580,7 +580,7 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     long long total = 0;
     for (int i = 0; i < e.P; ++i) total += e.ph[i].N;
     total *= e.n_instances;
-    if (e.opt_role_loop != 0 && (e.opt_role_loop == 1 || total / 64 >= 1024)) {
+    if (e.opt_role_loop != 0 && (e.opt_role_loop == 1 || total / 64 >= 512)) {
       T = 64;
       e.role_looped = true;
     } else {
