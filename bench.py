@@ -230,10 +230,10 @@ def main():
                             "first-derive=finite-difference tol=1e-6, %d seeded iterates resident in HBM, %d iterate(s) per step"
                             % (args.intervals, args.nodes, eng.n, eng.m, eng.nnz_jac, R, B),
                 "pair": "unfused: eval_g kernel + eval_jac_g kernel" if args.unfused else
-                        "fused: one rpm_tile_kernel launch writes g and all Jacobian values of x_k",
+                        "fused: one tile-kernel launch writes g and all Jacobian values of the step's iterates",
                 "launch": "hipGraph replay of the K steps" if graph is not None else "eager launches",
                 "tile_nodes": eng.get_option("tile_nodes"),
-                "thread_layout": ("persistent workgroups, 4 compute waves + 1 DMA wave (rpm_tile_pl_kernel)" if eng.get_option("pipeline_active")
+                "thread_layout": ("persistent workgroups of two halves, each 4 compute waves + 2 DMA waves (rpm_tile_pl_kernel)" if eng.get_option("pipeline_active")
                                   else "64 nodes x 4 role groups (roles looped)" if eng.get_option("role_loop") else "16 nodes x (nx+nu+2) roles"),
                 "dx_mode": "mfma_f64_16x16x4" if args.dx_mode else "scalar, reference summation order",
                 "parallelism": ("intervals sharded x%d + RCCL all-gather" % world) if sharded else

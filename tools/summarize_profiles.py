@@ -22,7 +22,7 @@ def one(pattern):
 
 stats = one("%s_stats/*/*kernel_stats.csv" % tag)
 shutil.copy(stats, os.path.join(out, "%s_kernel_stats.csv" % tag))
-summary = {"tag": tag, "command": "python3 bench.py --profile --steps 200 --warmup 20 (default workload: batch 16, tile 16)"}
+summary = {"tag": tag, "command": "python3 bench.py --profile --steps 200 --warmup 20 (default workload: 16 iterates per launch)"}
 for r in csv.DictReader(open(stats)):
     if "rpm_tile" in r["Name"]:   # rpm_tile_kernel or its role-looped layout rpm_tile_rl_kernel
         summary["dominant_kernel"] = r["Name"].split("<")[0].split("::")[-1]
@@ -41,16 +41,17 @@ for sub in ("fetch", "write", "sq"):
         pmc[k] = sum(v) / len(v)
 summary["pmc_per_launch"] = pmc
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads 1/2 of
-    # the bytes of a WIDE (16 B/lane) streaming read and is uncalibrated for other widths; this kernel's loads are
-    # 8 B/lane, so both the raw and the doubled figure are recorded and the raw one is used (it matches the
-    # expected x + per-XCD table reads).  WRITE_SIZE reads exact.
-    fetch, write = pmc["FETCH_SIZE"] * 1024.0, pmc["WRITE_SIZE"] * 1024.0
-    summary["hbm_read_bytes_raw"] = fetch
-    summary["hbm_read_bytes_if_doubled"] = 2 * fetch
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly 1/2
+    # of the bytes of a WIDE (16 B/lane) streaming read, `global_load` and `... lds` alike, and is uncalibrated for other
+    # widths.  rpm_tile_pl_kernel reads its inputs with 16 B/lane direct-to-LDS loads -> the counter is doubled, as the
+    # guide prescribes; the older layouts read 8 B/lane -> raw figure (uncalibrated).  WRITE_SIZE reads exact.
+    wide = summary.get("dominant_kernel", "") == "rpm_tile_pl_kernel"
+    fetch, write = pmc["FETCH_SIZE"] * 1024.0 * (2.0 if wide else 1.0), pmc["WRITE_SIZE"] * 1024.0
+    summary["hbm_read_bytes"] = fetch
+    summary["hbm_read_correction"] = "x2 (16 B/lane loads, guide §HBM)" if wide else "raw (8 B/lane loads, uncalibrated)"
     summary["hbm_write_bytes"] = write
-    json.dump({"tag": tag, "hbm_bytes_per_launch": fetch + write, "fetch_bytes_raw": fetch, "write_bytes": write,
-               "note": "FETCH_SIZE raw (8 B/lane loads, see tools/summarize_profiles.py), WRITE_SIZE exact"},
+    json.dump({"tag": tag, "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+               "note": "FETCH_SIZE " + summary["hbm_read_correction"] + ", WRITE_SIZE exact"},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 bj = os.path.join(ROOT, "gpurun_out", "%s_bench.json" % tag)
 if os.path.exists(bj):
