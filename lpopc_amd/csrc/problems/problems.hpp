@@ -40,7 +40,8 @@ struct LaunchProblem {
   static constexpr int NX = 7, NU = 3, NC = 1, NE_MAX = 5, NLINK_MAX = 7, NCONST = 22;
   static constexpr bool HAS_ANALYTIC = false;
 
-  RPM_DEV static void dae(int ph, double t, const double* x, const double* u, const double* c,
+  template <class CP = const double*>
+  RPM_DEV static void dae(int ph, double t, const double* x, const double* u, CP c,
                           double* f, double* p) {
     (void)t;
     const double r0 = x[0], r1 = x[1], r2 = x[2], m = x[6];
@@ -161,11 +162,13 @@ struct HypersensitiveProblem {
   static constexpr int ID = RPM_PROBLEM_HYPERSENSITIVE;
   static constexpr int NX = 1, NU = 1, NC = 0, NE_MAX = 0, NLINK_MAX = 0, NCONST = 0;
   static constexpr bool HAS_ANALYTIC = true;
-  RPM_DEV static void dae(int, double, const double* x, const double* u, const double*, double* f, double*) {
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* u, CP, double* f, double*) {
     f[0] = ((-x[0]) * x[0]) * x[0] + u[0];                             // :131
   }
   // column v of [df/dx, df/du, df/dt] (DerivDae :134-151)
-  RPM_DEV static void dae_jac_col(int, int v, double, const double* x, const double*, const double*,
+  template <class CP = const double*>
+  RPM_DEV static void dae_jac_col(int, int v, double, const double* x, const double*, CP,
                                   double* df, double*) {
     df[0] = (v == 0) ? -3 * (x[0] * x[0]) : (v == 1 ? 1.0 : 0.0);
   }
@@ -193,7 +196,8 @@ struct BrysonDenhamProblem {
   static constexpr int ID = RPM_PROBLEM_BRYSON_DENHAM;
   static constexpr int NX = 3, NU = 1, NC = 0, NE_MAX = 5, NLINK_MAX = 0, NCONST = 0;
   static constexpr bool HAS_ANALYTIC = false;
-  RPM_DEV static void dae(int, double, const double* x, const double* u, const double*, double* f, double*) {
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* u, CP, double* f, double*) {
     f[0] = x[1];
     f[1] = u[0];
     f[2] = 0.5 * (u[0] * u[0]);                                        // :121-123
@@ -212,13 +216,15 @@ struct BrachistochroneProblem {
   static constexpr int ID = RPM_PROBLEM_BRACHISTOCHRONE;
   static constexpr int NX = 3, NU = 1, NC = 0, NE_MAX = 5, NLINK_MAX = 0, NCONST = 1;
   static constexpr bool HAS_ANALYTIC = true;
-  RPM_DEV static void dae(int, double, const double* x, const double* u, const double* c, double* f, double*) {
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* u, CP c, double* f, double*) {
     const double sn = sin(u[0]), cs = cos(u[0]);
     f[0] = x[2] * sn;
     f[1] = x[2] * cs;
     f[2] = c[0] * cs;
   }
-  RPM_DEV static void dae_jac_col(int, int v, double, const double* x, const double* u, const double* c,
+  template <class CP = const double*>
+  RPM_DEV static void dae_jac_col(int, int v, double, const double* x, const double* u, CP c,
                                   double* df, double*) {
     const double sn = sin(u[0]), cs = cos(u[0]);
     df[0] = df[1] = df[2] = 0.0;
@@ -252,7 +258,8 @@ struct MinTimeClimbProblem {
   static constexpr int ID = RPM_PROBLEM_MIN_TIME_CLIMB;
   static constexpr int NX = 4, NU = 1, NC = 0, NE_MAX = 7, NLINK_MAX = 0, NCONST = 10;
   static constexpr bool HAS_ANALYTIC = false;
-  RPM_DEV static void dae(int, double, const double* x, const double* u, const double* c, double* f, double*) {
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* u, CP c, double* f, double*) {
     const double h = x[0], v = x[1], gam = x[2], m = x[3], al = u[0];
     const double r = h + c[0];
     const double rho = c[5] * exp(-h / c[6]);
@@ -289,7 +296,8 @@ struct QuadrotorProblem {
   static constexpr int ID = RPM_PROBLEM_QUADROTOR;
   static constexpr int NX = 12, NU = 4, NC = 0, NE_MAX = 0, NLINK_MAX = 0, NCONST = 15;
   static constexpr bool HAS_ANALYTIC = false;
-  RPM_DEV static void dae(int, double, const double* x, const double* f4, const double* c, double* f, double*) {
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* f4, CP c, double* f, double*) {
     const double ph = x[6], th = x[7], ps = x[8], p = x[9], q = x[10], r = x[11];
     const double F = ((f4[0] + f4[1]) + f4[2]) + f4[3];
     const double tx = c[2] * (f4[1] - f4[3]);

@@ -933,6 +933,10 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
 #define RPM_JSTORE(dst, val) dst = (val)
 #endif
   // ---------------- compute waves: the role loop of rpm_tile_rl_kernel out of the staged buffer ----------------
+  // the problem constants through the constant address space: scalar loads (s_load, lgkmcnt).  Through a generic
+  // pointer they are vector loads here (the kernel has stored by then, so the compiler cannot use the scalar cache),
+  // and a vector load's s_waitcnt vmcnt also waits for every Jacobian store issued before it (in-order counter).
+  const auto c4 = (const __attribute__((address_space(4))) double*)K.consts;
   const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
   for (int jt = 0; jt < n_iter_wg; ++jt) {
     const double* cur = lds + (jt & 1) * S_SIZE;
@@ -1003,19 +1007,25 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
       double h = 1.0;
       const int v = role - 1;
       if (WJ && !AN && role >= 1) {     // h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214)
+        // the role is wave-uniform: fetch the one perturbed variable by its (scalar) row, form h and v+h once, and
+        // put the sum back where it belongs — instead of forming them for every variable and selecting
+        double pv;
+        if (v < NX) pv = Xs[v * K.max_span + (k - span0)];
+        else if (v < NX + NU) pv = Us[(v - NX) * T + kc];
+        else pv = tk;
+        h = K.tol * (1 + fabs(pv));
+        const double pp = pv + h;
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-          if (v == i) { h = K.tol * (1 + fabs(xs[i])); xs[i] += h; }
+        for (int i = 0; i < NX; ++i) xs[i] = (v == i) ? pp : xs[i];
 #pragma unroll
-        for (int j = 0; j < NU; ++j)
-          if (v == NX + j) { h = K.tol * (1 + fabs(us[j])); us[j] += h; }
-        if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
+        for (int j = 0; j < NU; ++j) us[j] = (v == NX + j) ? pp : us[j];
+        tk = (v == NX + NU) ? pp : tk;
       }
       double f[NXs], cp[NCs];
       if (!AN || role == 0) {
-        Prob::dae(phase_num, tk, xs, us, c, f, cp);
+        Prob::dae(phase_num, tk, xs, us, c4, f, cp);
       } else if constexpr (AN) {
-        Prob::dae_jac_col(phase_num, v, tk, xs, us, c, f, cp);
+        Prob::dae_jac_col(phase_num, v, tk, xs, us, c4, f, cp);
       }
 #ifdef RPM_DIAG
       if (trc) { if (f[0] == 1e300) cp[0] = 0; RPM_PTRC(jt, 26); }
