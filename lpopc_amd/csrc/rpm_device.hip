@@ -750,44 +750,63 @@ __global__ __launch_bounds__(T* RG) RPM_RL_ATTR void rpm_tile_rl_kernel(const KP
 // workgroup timeline of rpm_tile_rl_kernel is serial (input loads 4-5 us behind the store traffic, 3 dynamics passes,
 // then a 2.5 us burst of constant-block stores that blocks the issuing waves), every workgroup of a launch is in the
 // same phase at the same time, and a launch is only two residency rounds, so neither the SIMDs (busy 35 %) nor HBM
-// (busy 45 %) are kept fed (tools/trace_timeline.py).  Here a workgroup is 4 compute waves + 1 DMA wave and walks
-// tiles w, w+G, w+2G, ...:
-//   * the DMA wave loads the NEXT tile's inputs (tile record, x rows, D rows, node records) into registers while the
-//     compute waves work on the current one, parks them in the other LDS staging buffer, and writes the current
-//     tile's share of the constant Doffdiag block, so the compute waves never wait for a load or a store burst;
+// (busy 45 %) are kept fed (tools/trace_timeline.py).  Here a workgroup is NH independent halves of RG compute waves +
+// NDMA DMA waves (pl_shape), and a half walks tiles w, w+G, w+2G, ...:
+//   * the DMA waves copy the NEXT tile's inputs (tile record, t0 tf, X rows, U rows, D rows, node records, its slice
+//     of the constant list) from HBM straight into the other LDS staging buffer (global_load_lds_dwordx4) while the
+//     compute waves work on the current one, and write the current tile's share of the constant Doffdiag block, so
+//     the compute waves never wait for a load or a store burst; they run at raised priority (s_setprio);
 //   * the compute waves run exactly the role loop of rpm_tile_rl_kernel (same arithmetic, same output order:
 //     bit-identical results, tests/test_gpu_parity.py) out of the staged buffer;
 //   * endpoint work items (events, linkages, linear rows) are taken by DMA waves once their tiles are done, one wave
 //     each (endpoint_block<..., WAVE = true>).
-// Two workgroup barriers per tile (A: staging buffer ready, F: unperturbed dynamics published), executed by all five
-// waves.  Host-checked limits of the register staging: max_span <= 128*PL_XCH, max_drow <= 128*PL_DCH, a tile's
-// constant share <= 128*PL_CCH, 2 NX + 3 <= 64.
-constexpr int PL_CCH = 5, PL_REC = 32;   // a tile's constant share: at most 2 * PL_CCH chunks of 128 doubles (16 B per lane)
+// One workgroup barrier per tile (A: staging buffer ready; the DMA waves execute s_waitcnt vmcnt(0) before it); F
+// (unperturbed dynamics published) is a flag in LDS that only the compute waves look at, so the DMA waves spend the
+// first pass — when the compute waves store nothing — on the constant block.  Host-checked limits: a tile's constant
+// share <= PL_CMAX doubles (it passes through registers of the DMA waves), 2 NX + 3 <= 64 (endpoint perturbations
+// fit one wave).
+constexpr int PL_CMAX = 1280, PL_REC = 32;   // a tile's constant share: at most PL_CMAX doubles
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // a pair of doubles at 8-byte alignment
 #define RPM_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define RPM_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 // One wave copies `len` doubles from global memory straight into LDS (both sides 8-byte aligned).  Inlined (a call
 // would start with s_waitcnt 0 and serialise the loads) but not unrolled: the DMA wave runs this code once per tile,
 // so it should be small enough to stay in the instruction cache.
-__device__ __forceinline__ void pl_dma_run(const double* gsrc, double* ldst, int len, int lane) {
-  const int pairs = len >> 1;
+template <int NPART>
+__device__ __forceinline__ void pl_dma_run(const double* gsrc, double* ldst, int len, int lane, int part) {
+  const int pairs = len >> 1;   // chunk ch (64 pairs) is copied by the wave with part == ch % NPART
 #pragma unroll 1
-  for (int ch = 0; ch * 64 < pairs; ++ch)
+  for (int ch = part; ch * 64 < pairs; ch += NPART)
     if (ch * 64 + lane < pairs)
       __builtin_amdgcn_global_load_lds(RPM_GPTR(gsrc + ch * 128 + 2 * lane), RPM_LPTR(ldst + ch * 128), 16, 0, 0);
-  if ((len & 1) && lane < 2)   // odd tail: the last double as two dwords
+  if ((len & 1) && part == 0 && lane < 2)   // odd tail: the last double as two dwords
     __builtin_amdgcn_global_load_lds(RPM_GPTR(reinterpret_cast<const int*>(gsrc + len - 1) + lane),
                                      RPM_LPTR(ldst + len - 1), 4, 0, 0);
 }
 
-constexpr int PL_HALF = 64 * 4 + 128;   // threads of one half-workgroup: 4 compute waves + 2 DMA waves
 
-template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
-__global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams K, int n_inst,
-                                                                 const double* __restrict__ xall,
-                                                                 double* __restrict__ gall,
-                                                                 double* __restrict__ vall) {
-  static_assert(T == 64 && RG == 4, "a role of a tile is one wave, four role groups per tile");
+// role groups (= compute waves) of the pipelined kernel for a problem with R = nx + nu + 2 roles: one role per wave
+// when they fit (R <= 12; with the 2 DMA waves 14 waves = 4 per SIMD, which the launch bound turns into a 128-VGPR
+// budget), else the fewest equal passes (R = 18: two passes of 9 waves, 11 waves = 3 per SIMD, 168 VGPRs)
+constexpr int pl_role_groups(int R) { return (R + (R + 11) / 12 - 1) / ((R + 11) / 12); }
+
+// Shape of the pipelined kernel's workgroup for a problem with R = nx + nu + 2 roles: NH independent halves, each RG
+// compute waves (roles g, g + RG, ...) + NDMA DMA waves.  R <= 12: two halves of 4 + 2 waves = 12 waves, 3 per SIMD
+// (2 compute + 1 DMA, 168-VGPR budget), three passes per tile — measured best on the metric problem (33.2 us per
+// 16-iterate launch) against 2 x (6 + 2) at 128 VGPRs (35.0), one role per wave 12 + 4 (36.3) and 3 x (4 + 1) (38.6).
+// Larger problems: one half, the fewest equal passes (R = 18: 9 + 2 waves, 3 per SIMD).
+struct PlShape { int NH, RG, NDMA; };
+constexpr PlShape pl_shape(int R) {
+  return R <= 12 ? PlShape{2, 4, 2} : PlShape{1, pl_role_groups(R), 2};
+}
+
+template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN>
+__global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
+    const KParams K, int n_inst, const double* __restrict__ xall, double* __restrict__ gall,
+    double* __restrict__ vall) {
+  constexpr int T = 64;   // a role of a tile is one wave
+  constexpr int HT = 64 * (RG + NDMA);   // threads of one half
+  constexpr int CCH = (PL_CMAX / 128 + NDMA - 1) / NDMA;   // 128-double chunks of the constant share per DMA wave
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
   constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1;
   constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
@@ -797,24 +816,22 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
   constexpr int NREC = int(sizeof(TileDev) / sizeof(int));
   static_assert(NREC < PL_REC, "tile record plus the instance index must fit the staged record");
   extern __shared__ double lds_all[];
-  // A workgroup is two independent halves (one CU holds exactly one workgroup: 12 waves, 3 per SIMD at the 168-VGPR
-  // budget, each SIMD 2 compute + 1 DMA wave; separate 5- or 6-wave workgroups do not pack).  The halves only share
-  // the barriers.
-  const int half = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / PL_HALF);   // wave-uniform: keeps w, the tile index and the record in SGPRs
-  const int tid = int(threadIdx.x) - half * PL_HALF;
-  const int G = 2 * int(gridDim.x), w = 2 * int(blockIdx.x) + half;
+  // the halves of a workgroup are independent (own tiles, own LDS); they only share the barriers
+  const int half = NH > 1 ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) / HT) : 0;   // wave-uniform
+  const int tid = int(threadIdx.x) - half * HT;
+  const int G = NH * int(gridDim.x), w = NH * int(blockIdx.x) + half;
   const int nt = K.n_my_tiles;
   const int W = nt * n_inst;
-  const int n_iter = w < W ? (W - w + G - 1) / G : 0;                      // items w, w + G, ... of this half
-  const int n_iter_wg = (W - 2 * int(blockIdx.x) + G - 1) / G;             // of half 0: the barrier count of the workgroup
+  const int n_iter = w < W ? (W - w + G - 1) / G : 0;                 // tiles w, w + G, ... of this half
+  const int n_iter_wg = (W - NH * int(blockIdx.x) + G - 1) / G;       // of half 0: the barrier count of the workgroup
   // one staging buffer (doubles): record, next tile's record | t0 tf | X rows | U rows | D rows | tau | diag | node
   // records | const share
   const int S_TT = PL_REC, S_X = S_TT + 2, S_U = S_X + NX * K.max_span, S_D = S_U + NU * T;
   const int S_TAU = S_D + K.max_drow, S_DG = S_TAU + T, S_ND = S_DG + T, S_CV = S_ND + 2 * T;
   const int S_SIZE = S_CV + (WJ ? K.max_cshare : 0);
-  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T);
+  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T + 2);
   double* Fb = lds + 2 * S_SIZE;
-  const double* __restrict__ c = K.consts;
+  int* fb_ready = reinterpret_cast<int*>(Fb + (NX + NC) * T);   // tile count for which Fb holds the unperturbed dynamics
 #ifdef RPM_DIAG
 #define RPM_PTRC(j, slot)                                                           \
   if (K.trace && (threadIdx.x & 63) == 0 && (j) < 2) K.trace[size_t(w) * 64 + (j)*32 + (slot)] = wall_clock64()
@@ -824,13 +841,20 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
   if (tid == 0) { RPM_PTRC(0, 31); }
 
   if (tid >= NTHR) {
-    // ---------------- DMA waves (two per half: a direct-to-LDS load takes ~60 ns to issue, so the runs of a tile
-    // and the chunks of the constant block are dealt alternately to the two) ----------------
+    // ---------------- DMA waves (two: a direct-to-LDS load takes ~60 ns to issue, so the runs of a tile and the
+    // chunks of the constant block are dealt alternately to them) ----------------
     const int lane = (tid - NTHR) & 63;
     const int dw = __builtin_amdgcn_readfirstlane((tid - NTHR) >> 6);
+    // The DMA waves' instruction stream is long and scalar; sharing a SIMD with three busy compute waves it would get
+    // a quarter of the issue slots (4 us to issue one tile's loads).  They run at raised priority instead.
+    __builtin_amdgcn_s_setprio(3);
     // The next tile's inputs go from global memory straight into the other LDS staging buffer
     // (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip): the DMA wave only issues them.
-    auto run = [&](const double* gsrc, double* ldst, int len) { pl_dma_run(gsrc, ldst, len, lane); };
+    // every run is dealt chunk-wise to the NDMA waves, the first chunk of successive runs to successive waves
+    int rot = 0;
+    auto run = [&](const double* gsrc, double* ldst, int len) {
+      pl_dma_run<NDMA>(gsrc, ldst, len, lane, (dw + NDMA - (rot++ & (NDMA - 1))) & (NDMA - 1));
+    };
     // The addresses of a tile's runs come from its record.  In steady state that record is already in LDS (each
     // staging buffer also carries the record of the tile AFTER its own), so issuing the next tile's loads never waits
     // for global memory; only the first tile of a workgroup reads its record from HBM.
@@ -847,30 +871,25 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
       const int inst = item / nt, tidx = item - inst * nt;
       const double* __restrict__ x = xall + size_t(inst) * K.n;
       static_assert(NREC % 2 == 0 && sizeof(TileDev) % 8 == 0, "the tile record is copied as doubles");
-      if (dw == 0) {
-        if (lane == 0) reinterpret_cast<int*>(buf)[NREC] = inst;   // before the direct loads: an LDS write after them waits for them
-        run(reinterpret_cast<const double*>(K.tiles + tidx), buf, NREC / 2);
-        if (item + G < W) {   // the record of this half's tile after this one
-          const int item2 = item + G, inst2 = item2 / nt;
-          run(reinterpret_cast<const double*>(K.tiles + (item2 - inst2 * nt)), buf + PL_REC / 2, NREC / 2);
-        }
-        run(x + tl.x_t0, buf + S_TT, 2);
+      rot = 0;
+      if (dw == 0 && lane == 0) reinterpret_cast<int*>(buf)[NREC] = inst;   // before the direct loads: an LDS write after them waits for them
+      run(reinterpret_cast<const double*>(K.tiles + tidx), buf, NREC / 2);
+      if (item + G < W) {   // the record of this workgroup's tile after this one
+        const int item2 = item + G, inst2 = item2 / nt;
+        run(reinterpret_cast<const double*>(K.tiles + (item2 - inst2 * nt)), buf + PL_REC / 2, NREC / 2);
       }
+      run(x + tl.x_t0, buf + S_TT, 2);
 #pragma unroll
-      for (int i = 0; i < NX; ++i)
-        if ((i & 1) == dw) run(x + tl.x_state0 + i * (tl.N + 1) + tl.span0, buf + S_X + i * K.max_span, tl.span_len);
+      for (int i = 0; i < NX; ++i) run(x + tl.x_state0 + i * (tl.N + 1) + tl.span0, buf + S_X + i * K.max_span, tl.span_len);
 #pragma unroll
-      for (int j = 0; j < NU; ++j)
-        if ((j & 1) != dw) run(x + tl.x_control0 + j * tl.N + tl.k0, buf + S_U + j * T, tl.cnt);
-      if (dw == 0) {
-        if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
-        run(K.points + tl.node0 + tl.k0, buf + S_TAU, tl.cnt);
-      } else {
-        if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
-        if (WJ) run(K.diag + tl.node0 + tl.k0, buf + S_DG, tl.cnt);
-        run(reinterpret_cast<const double*>(K.nodes + tl.node0 + tl.k0), buf + S_ND, 2 * tl.cnt);
-      }
+      for (int j = 0; j < NU; ++j) run(x + tl.x_control0 + j * tl.N + tl.k0, buf + S_U + j * T, tl.cnt);
+      run(K.points + tl.node0 + tl.k0, buf + S_TAU, tl.cnt);
+      if (WJ) run(K.diag + tl.node0 + tl.k0, buf + S_DG, tl.cnt);
+      run(reinterpret_cast<const double*>(K.nodes + tl.node0 + tl.k0), buf + S_ND, 2 * tl.cnt);
+      if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
+      if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
     };
+    if (dw == 0 && lane == 0) *fb_ready = 0;
     if (n_iter > 0) stage(w, lds, runs_of(reinterpret_cast<const int*>(K.tiles + (w - (w / nt) * nt))));
     for (int j = 0; j < n_iter_wg; ++j) {
       const double* cur = lds + (j & 1) * S_SIZE;
@@ -878,36 +897,28 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
       __builtin_amdgcn_s_waitcnt(0);   // the staged loads (and the constant stores before them) have landed
       __syncthreads();                 // A: buffer `cur` is complete
       RPM_PTRC(j, 16);
-      // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718): LDS -> registers now, so that no
-      // LDS read of this wave sits behind the direct-to-LDS loads issued next
-      d2u cv[PL_CCH];
-      int c_cnt = 0, c_stride = 0;
-      double* __restrict__ cdst = nullptr;
-      double ctail = 0.0;
+      // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718), written while the compute waves are
+      // in their first pass and store nothing; then the next tile's loads.  (The order matters twice: an LDS read of
+      // this wave after the direct-to-LDS loads would wait for them, and the Jacobian stores of the later passes
+      // should not meet these in the memory system.)
       if (WJ && j < n_iter) {
         const int* rec = reinterpret_cast<const int*>(cur);
         const int c_dst0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_dst0) / 4]);
         const int inst = __builtin_amdgcn_readfirstlane(rec[NREC]);
-        c_cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_cnt) / 4]);
-        c_stride = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_stride) / 4]);
-        cdst = vall + size_t(inst) * K.nnz + c_dst0;
+        const int c_cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_cnt) / 4]);
+        const int c_stride = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_stride) / 4]);
+        double* __restrict__ cdst = vall + size_t(inst) * K.nnz + c_dst0;
+        d2u cv[CCH];
 #pragma unroll
-        for (int ch = 0; ch < PL_CCH; ++ch) {
-          const int q = min((2 * ch + dw) * 128 + 2 * lane, c_cnt - 2);
+        for (int ch = 0; ch < CCH; ++ch) {
+          const int q = min((NDMA * ch + dw) * 128 + 2 * lane, c_cnt - 2);
           cv[ch].x = cur[S_CV + q];
           cv[ch].y = cur[S_CV + q + 1];
         }
-        ctail = cur[S_CV + c_cnt - 1];
-      }
-      const bool more = j + 1 < n_iter;
-      if (more) stage(w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
-      RPM_PTRC(j, 17);
-      __syncthreads();   // F (the compute waves publish the unperturbed dynamics here)
-      RPM_PTRC(j, 18);
-      if (WJ && j < n_iter) {
+        const double ctail = cur[S_CV + c_cnt - 1];
 #pragma unroll
-        for (int ch = 0; ch < PL_CCH; ++ch) {
-          const int q = (2 * ch + dw) * 128 + 2 * lane;   // 16 B per lane: 1 KB per store instruction
+        for (int ch = 0; ch < CCH; ++ch) {
+          const int q = (NDMA * ch + dw) * 128 + 2 * lane;   // 16 B per lane: 1 KB per store instruction
           if (q + 1 < c_cnt) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) *reinterpret_cast<d2u*>(cdst + size_t(i) * c_stride + q) = cv[ch];
@@ -915,11 +926,13 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
         }
         if ((c_cnt & 1) && dw == 0 && lane < NX) cdst[size_t(lane) * c_stride + c_cnt - 1] = ctail;
       }
-      RPM_PTRC(j, 19);
+      RPM_PTRC(j, 17);
+      if (j + 1 < n_iter) stage(w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
+      RPM_PTRC(j, 18);
     }
-    // endpoint work items of this half, one wave each
+    // endpoint work items of this workgroup, one wave each
     const int n_end = K.n_tasks * n_inst;
-    for (int it = 2 * w + dw; it < n_end; it += 2 * G) {
+    for (int it = NDMA * w + dw; it < n_end; it += NDMA * G) {
       const int inst = it / K.n_tasks;
       endpoint_block<Prob, WG, WJ, AN, true>(K, K.tasks[it - inst * K.n_tasks], xall + size_t(inst) * K.n,
                                              gall + size_t(inst) * K.m, vall + size_t(inst) * K.nnz, nullptr);
@@ -941,11 +954,8 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
   for (int jt = 0; jt < n_iter_wg; ++jt) {
     const double* cur = lds + (jt & 1) * S_SIZE;
     __syncthreads();   // A
-    if (jt >= n_iter) {   // the other half still has a tile: keep the barrier count
-      __syncthreads();   // F
-      continue;
-    }
-    RPM_PTRC(jt, grp * 4 + 0);
+    if (jt >= n_iter) continue;   // the other half still has a tile: keep the barrier count
+    if (grp < 4) { RPM_PTRC(jt, grp * 4 + 0); }
     const int* rec = reinterpret_cast<const int*>(cur);
     const int k0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, k0) / 4]);
     const int cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, cnt) / 4]);
@@ -970,7 +980,7 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
     for (int role = grp; role < R || first; role += RG) {
       const bool act = node_ok && role < R;
 #ifdef RPM_DIAG
-      const bool trc = role == 1 + RG;
+      const bool trc = role == 5;
       if (trc) { RPM_PTRC(jt, 24); }
 #endif
       double xs[NXs], us[NUs];
@@ -1040,9 +1050,16 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
             if (WG) g[g0 + (NX + j) * N + k] = cp[j];           // path rows, :138-164
           }
         }
-        RPM_PTRC(jt, grp * 4 + 1);
-        __syncthreads();   // F
-        RPM_PTRC(jt, grp * 4 + 2);
+        if (grp < 4) { RPM_PTRC(jt, grp * 4 + 1); }
+        // F: the other compute waves wait for role 0's outputs.  A flag in LDS, not s_barrier: the DMA waves stay out
+        // of it (they are busy with the constant block and the next tile), and the role-0 wave never waits.
+        if (grp == 0) {
+          __hip_atomic_store(fb_ready, jt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          while (__hip_atomic_load(fb_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < jt + 1)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (grp < 4) { RPM_PTRC(jt, grp * 4 + 2); }
         first = false;
       }
       if (act) {
@@ -1093,7 +1110,7 @@ __global__ __launch_bounds__(2 * PL_HALF) void rpm_tile_pl_kernel(const KParams 
       if (trc) { RPM_PTRC(jt, 27); }
 #endif
     }
-    RPM_PTRC(jt, grp * 4 + 3);
+    if (grp < 4) { RPM_PTRC(jt, grp * 4 + 3); }
   }
 }
 
@@ -1904,14 +1921,30 @@ int device_init(Engine& e, int device_id) {
     e.err = "mesh interval too large for the LDS-staged D tile (reduce nodes per interval)";
     return RPM_E_UNSUPPORTED;
   }
-  {   // rpm_tile_pl_kernel: one workgroup of two 5-wave halves per CU, inputs staged through registers of the DMA waves
+  {   // rpm_tile_pl_kernel: persistent workgroups of RG compute + 2 DMA waves; as many per CU as the occupancy
+      // calculator grants the full (g + Jacobian) variant
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu <= 0) ncu = 256;
-    d->pl_slots = 2 * ncu;
     const int max_c = d->kp.max_cshare;
     const size_t stage = size_t(PL_REC + 2) + size_t(pd.nx) * e.max_span + size_t(pd.nu) * 64 + e.max_drow + 4 * 64 + max_c;
-    d->pl_lds = 2 * (2 * stage + size_t(pd.nx + pd.nc) * 64) * sizeof(double);
-    d->pl_ok = e.role_looped && e.tile_nodes == 64 && max_c <= 2 * 128 * PL_CCH && max_c >= 2 && 2 * pd.nx + 3 <= 64 && d->pl_lds <= 160 * 1024;
+    int per_cu = 0;
+    with_problem(e.problem_id, [&](auto prob) {
+      using P = decltype(prob);
+      constexpr PlShape S = pl_shape(P::NX + P::NU + 2);
+      d->pl_lds = S.NH * (2 * stage + size_t(pd.nx + pd.nc) * 64 + 2) * sizeof(double);
+      if (d->pl_lds > 160 * 1024) return;
+      auto kern = rpm_tile_pl_kernel<P, S.NH, S.RG, S.NDMA, true, true, false>;
+      if (d->pl_lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  int(d->pl_lds));
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, S.NH * 64 * (S.RG + S.NDMA), d->pl_lds) != hipSuccess)
+        per_cu = 0;
+      (void)hipGetLastError();
+      per_cu *= S.NH;   // resident halves per CU
+    });
+    d->pl_slots = per_cu * ncu;
+    d->pl_ok = e.role_looped && e.tile_nodes == 64 && max_c <= PL_CMAX && max_c >= 2 && 2 * pd.nx + 3 <= 64 &&
+               per_cu >= 1;
   }
   return RPM_OK;
 }
@@ -1952,15 +1985,17 @@ static hipError_t launch_tile_rl(const Engine& e, const double* dx, double* dg, 
 template <class Prob, bool WG, bool WJ, bool AN>
 static hipError_t launch_tile_pl(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
   const Device& d = *e.dev;
-  auto kern = rpm_tile_pl_kernel<Prob, 64, 4, WG, WJ, AN>;
+  constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2);
+  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN>;
   if (d.pl_lds > 64 * 1024) {
     hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(d.pl_lds));
     if (s != hipSuccess) return s;
   }
   const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
-  const long long halves = W < d.pl_slots ? W : d.pl_slots;
-  hipLaunchKernelGGL(kern, dim3(unsigned((halves + 1) / 2)), dim3(2 * PL_HALF), d.pl_lds, st, d.kp, e.n_instances, dx, dg, dv);
+  const long long halves = W < d.pl_slots ? W : d.pl_slots;   // pl_slots: resident halves (occupancy query)
+  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA)), d.pl_lds, st, d.kp,
+                     e.n_instances, dx, dg, dv);
   return hipGetLastError();
 }
 

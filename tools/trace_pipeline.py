@@ -48,9 +48,8 @@ for j in (0, 1):
         stat("wave %d: first pass (A -> arrive F)" % wv, t[:, j, b + 1] - t[:, j, b])
         stat("wave %d: wait at F" % wv, t[:, j, b + 2] - t[:, j, b + 1])
         stat("wave %d: later passes (F -> end)" % wv, t[:, j, b + 3] - t[:, j, b + 2])
-    stat("dma: A -> loads issued", t[:, j, 17] - t[:, j, 16])
-    stat("dma: wait at F", t[:, j, 18] - t[:, j, 17])
-    stat("dma: const stores issued", t[:, j, 19] - t[:, j, 18])
+    stat("dma: A -> const stores issued", t[:, j, 17] - t[:, j, 16])
+    stat("dma: next tile's loads issued", t[:, j, 18] - t[:, j, 17])
     print("  tile end (slowest wave, abs): mean %.2f" % (t[:, j, [3, 7, 11, 15]].max(axis=1) - t00).mean())
 print("kernel end: %.2f" % (t[:, 1, [3, 7, 11, 15]].max() - t00))
 print("second pass of wave 1 (role 5: a velocity perturbation, with D.X):")
