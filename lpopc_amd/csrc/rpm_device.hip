@@ -311,7 +311,7 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
 #ifdef RPM_DIAG
   if (K.diag_mask & 64) { if (tl.cnt < 0) vals[0] = 0; return; }
 #endif
-  const double* __restrict__ c = K.consts;
+  const auto c = (const __attribute__((address_space(4))) double*)K.consts;   // constant address space: scalar loads
   double* Xs = lds;                          // [NX][max_span]  state-matrix rows the tile's D rows touch
   double* Us = Xs + NX * K.max_span;         // [NU][T]
   double* Ds = Us + NU * T;                  // the tile's D rows, row-major per node
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(T* RG) RPM_RL_ATTR void rpm_tile_rl_kernel(const KP
   const int nt = K.n_my_tiles, per = nt >> 3, rem = nt & 7, xcd = int(blockIdx.x) & 7, slot = int(blockIdx.x) >> 3;
   const TileDev tl = K.tiles[xcd * per + (xcd < rem ? xcd : rem) + slot];
   const TileDev& ph = tl;
-  const double* __restrict__ c = K.consts;
+  const auto c = (const __attribute__((address_space(4))) double*)K.consts;   // constant address space: scalar loads
   double* Xs = lds;
   double* Us = Xs + NX * K.max_span;
   double* Ds = Us + NU * T;
