@@ -341,8 +341,10 @@ def test_role_looped_layout_is_bit_identical(built, name, make, mode):
 
 
 @pytest.mark.parametrize("name,make,mode,B", [(CASES[5][0], CASES[5][1], CASES[5][2], 20), (CASES[6][0], CASES[6][1], CASES[6][2], 7),
-                                              (CASES[7][0], CASES[7][1], CASES[7][2], 3), ("launch_metric", lambda: problems.config("launch"), "perturb", 18)],
-                         ids=[CASES[5][0], CASES[6][0], CASES[7][0], "launch_metric"])
+                                              (CASES[7][0], CASES[7][1], CASES[7][2], 3), ("launch_metric", lambda: problems.config("launch"), "perturb", 18),
+                                              ("launch_ragged", _launch_ragged, "perturb", 150), ("climb_16x16", CASES[4][1], "perturb", 300),
+                                              ("bryson_denham", CASES[1][1], "perturb", 9)],
+                         ids=[CASES[5][0], CASES[6][0], CASES[7][0], "launch_metric", "launch_ragged", "climb_16x16", "bryson_denham"])
 def test_pipelined_kernel_is_bit_identical(built, name, make, mode, B):
     """rpm_tile_pl_kernel (persistent workgroups: 4 compute waves + 1 DMA wave, endpoint items on the DMA waves) writes
     exactly what the role-looped kernel writes: g, Jacobian, every instance, whether a workgroup walks one tile or
