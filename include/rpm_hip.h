@@ -193,6 +193,24 @@ int rpm_ph_refine_from_error(rpm_engine* e, int phase, const double* rel_err, do
                              int capacity, double* new_mesh_points, int* new_nodes_per_interval,
                              int* new_n_intervals, double* interval_error, int* no_more_refine);
 
+/* hp-Liu refinement: LiuHpMeshRefineAlg::RefineMesh, Core/LpLiuHpMeshRefineAlg.cpp:12-260 (with Reducing_N :438-481,
+ * Increasing_N :379-436, Dividing_mesh :321-377, CanWeIncreaseN :606-681; Merging_mesh's verdict is unused by the
+ * reference, equal-N satisfied neighbours always merge).  The object keeps the reference's histories (meshes with their
+ * per-interval errors, previous solution, previous mesh points) across meshes: create it once per problem
+ * (tol = desired-relative-error, nmax = Nmax, ratio_r = R, Core/LpMeshRefiner.h:54-61), call rpm_hpliu_refine after every
+ * solve with the engine built on the mesh the previous call returned.  Outputs for all phases: phase p's new mesh
+ * points at new_mesh_points[mesh_off[p] .. + new_n_intervals[p]], node counts at new_nodes_per_interval[nodes_off[p]
+ * ..]; `capacity` entries each.  rel_err: NULL = estimate on the device (rpm_solution_error), else the caller's matrices
+ * phase after phase (host only).  Fails with RPM_E_INVALID + message where the reference would throw or hit an
+ * undefined cast (see csrc/rpm_hpliu.cpp). */
+typedef struct rpm_hpliu rpm_hpliu;
+int rpm_hpliu_create(int n_phases, double tol, int nmax, double ratio_r, rpm_hpliu** out);
+void rpm_hpliu_destroy(rpm_hpliu* h);
+const char* rpm_hpliu_last_error(const rpm_hpliu* h);
+int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double* rel_err, int capacity,
+                     double* new_mesh_points, int* new_nodes_per_interval, int* mesh_off, int* nodes_off,
+                     int* new_n_intervals, int* no_more_refine);
+
 /* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
  *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
  *      engine's device; `stream` is a hipStream_t with HIP's own meaning (NULL = the legacy

@@ -373,6 +373,77 @@ int rpm_ph_refine_mesh(rpm_engine* h, int phase, const double* x, double tol, in
   RPM_GUARD_END(e)
 }
 
+// ---- hp-Liu mesh refinement (second method) ------------------------------------
+struct rpm_hpliu {
+  rpm::HpLiu h;
+  int n_phases = 0;
+  std::string err;
+};
+
+int rpm_hpliu_create(int n_phases, double tol, int nmax, double ratio_r, rpm_hpliu** out) {
+  if (!out || n_phases < 1 || !(tol > 0) || nmax < 2 || !(ratio_r > 0)) return RPM_E_INVALID;
+  rpm_hpliu* p = new (std::nothrow) rpm_hpliu();
+  if (!p) return RPM_E_INVALID;
+  p->n_phases = n_phases;
+  p->h.tol = tol;
+  p->h.Nmax = nmax;
+  p->h.R = ratio_r;
+  *out = p;
+  return RPM_OK;
+}
+
+void rpm_hpliu_destroy(rpm_hpliu* p) { delete p; }
+
+const char* rpm_hpliu_last_error(const rpm_hpliu* p) { return p ? p->err.c_str() : "null hp-Liu object"; }
+
+int rpm_hpliu_refine(rpm_hpliu* p, rpm_engine* h, const double* x, const double* rel_err, int capacity,
+                     double* new_mesh_points, int* new_nodes_per_interval, int* mesh_off, int* nodes_off,
+                     int* new_n_intervals, int* no_more_refine) {
+  if (!p || !h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (e.P != p->n_phases) return fail(e, RPM_E_INVALID, "hpliu_refine: phase count differs from rpm_hpliu_create");
+  if (e.n_instances != 1) return fail(e, RPM_E_UNSUPPORTED, "hpliu_refine: one instance per engine");
+  if (!x) {
+    if (!e.has_solution) return fail(e, RPM_E_INVALID, "hpliu_refine: no x given and no solution stored");
+    x = e.sol_x.data();
+  }
+  std::vector<std::vector<double>> rel(e.P);
+  const double* src = rel_err;
+  for (int ip = 0; ip < e.P; ++ip) {
+    const rpm::PhaseHost& ph = e.ph[ip];
+    const size_t cnt = size_t(ph.N + ph.K + 1) * ph.nx;
+    rel[ip].resize(cnt);
+    if (src) {   // the caller's matrices, phase after phase (host only)
+      std::memcpy(rel[ip].data(), src, cnt * sizeof(double));
+      src += cnt;
+    } else {
+      int rc = rpm::dev_solution_error(e, ip, x, rel[ip].data());
+      if (rc) return rc;
+    }
+  }
+  std::vector<std::vector<double>> mesh;
+  std::vector<std::vector<int>> nodes;
+  bool done = false;
+  int rc = p->h.refine(e, x, rel, mesh, nodes, &done, &p->err);
+  if (rc) return fail(e, rc, p->err.c_str());
+  int moff = 0, noff = 0;
+  for (int ip = 0; ip < e.P; ++ip) {
+    const int nk = int(nodes[ip].size());
+    if (moff + nk + 1 > capacity || noff + nk > capacity) return fail(e, RPM_E_INVALID, "hpliu_refine: capacity too small for the new meshes (the refinement itself has been recorded)");
+    std::memcpy(new_mesh_points + moff, mesh[ip].data(), sizeof(double) * (nk + 1));
+    std::memcpy(new_nodes_per_interval + noff, nodes[ip].data(), sizeof(int) * nk);
+    mesh_off[ip] = moff;
+    nodes_off[ip] = noff;
+    new_n_intervals[ip] = nk;
+    moff += nk + 1;
+    noff += nk;
+  }
+  if (no_more_refine) *no_more_refine = done ? 1 : 0;
+  return RPM_OK;
+  RPM_GUARD_END(e)
+}
+
 int rpm_final_result_save(rpm_engine* h, const char* dir) {
   if (!h) return RPM_E_INVALID;
   Engine& e = h->e;

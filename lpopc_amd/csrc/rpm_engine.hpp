@@ -185,6 +185,23 @@ int dev_eval_h(Engine& e, const double* d_x, double obj_factor, const double* d_
 int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, double* time, double* state, double* control,
                double* costate, double* pathmult, double* hamiltonian, double* mayer_cost, double* lagrange_cost);
 
+// rpm_hpliu.cpp: LiuHpMeshRefineAlg's state across meshes (mesh_history_, state_history_, mesh_points_history_)
+struct HpLiu {
+  struct Mesh { std::vector<double> mesh; std::vector<int> nodes; std::vector<double> e_k; };
+  struct Solution { int rows = 0; std::vector<double> v; };
+  double tol = 1e-6, R = 1.2;
+  int Nmax = 16, mesh_index = 0;
+  std::vector<std::vector<Mesh>> meshes;
+  std::vector<std::vector<Solution>> states;
+  std::vector<std::vector<std::vector<double>>> points_hist;
+  int refine(const Engine& e, const double* x, const std::vector<std::vector<double>>& rel,
+             std::vector<std::vector<double>>& new_mesh, std::vector<std::vector<int>>& new_nodes, bool* no_more,
+             std::string* why);
+  int smooth_enough(int ip, int first_row, int n, const std::vector<double>& tau, const double* state, int ld, int nx) const;
+  bool exponent(int ip, double m0, double mf, int N, double e_k, double* q) const;
+};
+void lagrange_rows(const double* src, int m, const double* dst, int nq, double* H, double* S, int* hit);
+
 // rpm_mesh.cpp: tables of the mesh-error estimate and the ph refinement decision (host); rpm_device.hip: the estimate
 void build_mesh_err_tables(const PhaseHost& p, MeshErrTables& t);
 bool ph_refine(const PhaseHost& p, const double* rel, double tol, int nmin, int nmax, std::vector<double>& mesh,

@@ -24,6 +24,8 @@ double pair_product(const std::vector<double>& a) {
   return p0 * p1;
 }
 
+}  // namespace
+
 // barycentric-form interpolation rows from `src` (m points) to `dst` (nq points): H is nq x m column-major with
 // H(r,j) = w_j / (dst_r - src_j); S its row sums; hit[r] = j when dst_r coincides with src_j (the value is copied)
 void lagrange_rows(const double* src, int m, const double* dst, int nq, double* H, double* S, int* hit) {
@@ -48,6 +50,8 @@ void lagrange_rows(const double* src, int m, const double* dst, int nq, double* 
     S[r] = sum;
   }
 }
+
+namespace {
 
 // dense inverse, Gaussian elimination with row pivoting, then one forward/back substitution per unit vector
 void invert(int n, std::vector<double> a, double* out) {

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_get_phase_sizes", "rpm_get_phase_tables",
     "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
+    "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
 ]
 
 
@@ -88,6 +89,12 @@ def lib():
     L.rpm_solution_error.argtypes = [vp, C.c_int, dp, dp, ip]
     L.rpm_ph_refine_mesh.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, ip]
     L.rpm_ph_refine_from_error.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, ip]
+    L.rpm_hpliu_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(vp)]
+    L.rpm_hpliu_destroy.argtypes = [vp]
+    L.rpm_hpliu_destroy.restype = None
+    L.rpm_hpliu_last_error.argtypes = [vp]
+    L.rpm_hpliu_last_error.restype = C.c_char_p
+    L.rpm_hpliu_refine.argtypes = [vp, vp, dp, dp, C.c_int, dp, ip, ip, ip, ip, ip]
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
     L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -349,3 +356,42 @@ class NLPEngine:
     def shard_unpack_dev(self, which, d_gathered, stride, d_full, stream=None):
         self._check(self._L.rpm_shard_unpack_dev(self._h, which, self._ptr(d_gathered), int(stride),
                                                  self._ptr(d_full), self._stream(stream)))
+
+
+class HpLiuRefiner:
+    """LiuHpMeshRefineAlg behind rpm_hpliu_* (Core/LpLiuHpMeshRefineAlg.cpp): one object per problem, it keeps the
+    reference's mesh / solution histories across meshes."""
+
+    def __init__(self, n_phases, tol, nmax, ratio_r):
+        self._L = lib()
+        self._h = C.c_void_p()
+        rc = self._L.rpm_hpliu_create(int(n_phases), float(tol), int(nmax), float(ratio_r), C.byref(self._h))
+        if rc != RPM_OK:
+            raise RpmError(rc, "rpm_hpliu_create: invalid arguments")
+        self.P = int(n_phases)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rpm_hpliu_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def refine(self, engine, x=None, rel_err=None, capacity=8192):
+        """-> (no_more_refine, [(mesh_points, nodes_per_interval) per phase]).  rel_err: list of per-phase relative-error
+        matrices to decide from (host only); default: estimate on the device."""
+        xp = _dp(engine._x(x)) if x is not None else None
+        rp = None
+        if rel_err is not None:
+            flat = np.concatenate([np.asfortranarray(r, dtype=np.float64).ravel(order="F") for r in rel_err])
+            rp = _dp(flat)
+        mesh, nodes = np.zeros(capacity), np.zeros(capacity, dtype=np.int32)
+        moff, noff, nk = (np.zeros(self.P, dtype=np.int32) for _ in range(3))
+        done = C.c_int()
+        rc = self._L.rpm_hpliu_refine(self._h, engine._h, xp, rp, capacity, _dp(mesh), _ip(nodes), _ip(moff), _ip(noff),
+                                      _ip(nk), C.byref(done))
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_last_error(engine._h).decode())
+        return bool(done.value), [(mesh[moff[p]:moff[p] + nk[p] + 1].copy(), nodes[noff[p]:noff[p] + nk[p]].copy())
+                                  for p in range(self.P)]
+

@@ -1,9 +1,10 @@
 """Mesh refinement driver: the host-side mirror of lpopc's MeshRefiner.
 
 Reference: Core/LpMeshRefiner.h:36-92 and Core/LpMeshRefiner.cpp:62-90 (grid counter, mesh history, method choice
-from the option list), Core/LpPhMeshRefineAlg.cpp (the ph method), Core/Nlp2OPConverter.cpp:149-193 (the extracted
+from the option list), Core/LpPhMeshRefineAlg.cpp (the ph method), Core/LpLiuHpMeshRefineAlg.cpp (hp-Liu),
+Core/Nlp2OPConverter.cpp:149-193 (the extracted
 solution becomes the next mesh's guess).  The per-node work runs on the device behind rpm_solution_error /
-rpm_ph_refine_mesh; this class only keeps the reference's bookkeeping and error behaviour.
+rpm_ph_refine_mesh / rpm_hpliu_refine; this class only keeps the reference's bookkeeping and error behaviour.
 """
 from .problem import LpopcException
 
@@ -23,11 +24,10 @@ class MeshRefiner:
         self.gridmaxnum_ = options.GetIntegerValue("max-grid-num")
         self.Nmax_ = options.GetIntegerValue("Nmax")
         self.Nmin_ = options.GetIntegerValue("Nmin")
-        if self.method_ != "ph":
-            # hp-Liu (Core/LpLiuHpMeshRefineAlg.cpp) is not built yet: say so instead of silently running ph
-            raise LpopcException("mesh-refine-methods=%s is not supported by this build (only ph)" % self.method_)
+        self.R_ = options.GetNumericValue("R")
         self.grid_ = 0
         self.meshhistory = []
+        self._hpliu = None   # LiuHpMeshRefineAlg keeps its own histories across meshes (Core/LpMeshRefiner.h:54-61)
 
     def CurrentGrid(self):
         return self.grid_
@@ -42,10 +42,17 @@ class MeshRefiner:
             self.meshhistory.append([LpMesh(optpro.GetPhase(i).GetMeshPoints(), optpro.GetPhase(i).GetNodesPerInterval())
                                      for i in range(nph)])
         no_more, newmesh = True, []
-        for i in range(nph):
-            done, mesh, nodes, _ = engine.ph_refine_mesh(i, self.tol_, self.Nmin_, self.Nmax_, x=x)
-            no_more = no_more and done
-            newmesh.append(LpMesh(mesh.tolist(), [int(v) for v in nodes]))
+        if self.method_ == "hp-Liu":
+            if self._hpliu is None:
+                from .engine import HpLiuRefiner
+                self._hpliu = HpLiuRefiner(nph, self.tol_, self.Nmax_, self.R_)
+            no_more, meshes = self._hpliu.refine(engine, x=x)
+            newmesh = [LpMesh(mesh.tolist(), [int(v) for v in nodes]) for mesh, nodes in meshes]
+        else:
+            for i in range(nph):
+                done, mesh, nodes, _ = engine.ph_refine_mesh(i, self.tol_, self.Nmin_, self.Nmax_, x=x)
+                no_more = no_more and done
+                newmesh.append(LpMesh(mesh.tolist(), [int(v) for v in nodes]))
         for i, mesh in enumerate(newmesh):   # the reference rewrites the mesh even when nothing changed
             ph = optpro.GetPhase(i)
             ph.meshpoints = list(mesh.meshpoints)

@@ -17,7 +17,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liborpm.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm_post.c", "orpm_mesh.c", "orpm.h", "orpm_internal.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orpm_core.c", "orpm_problems.c", "orpm_hess.c", "orpm_post.c", "orpm_mesh.c", "orpm_hpliu.c", "orpm.h", "orpm_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "rpm_hip.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborpm.so"], stdout=subprocess.DEVNULL)
@@ -53,6 +53,11 @@ def lib():
         L.orpm_ph_refine.argtypes = [C.c_void_p, C.c_int, dp, C.c_double, C.c_int, C.c_int, dp, ip, ip, dp]
         L.orpm_inverse.argtypes = [C.c_int, dp, dp]
         L.orpm_bary_tables.argtypes = [C.c_int, dp, C.c_int, dp, dp, dp, ip]
+        L.orpm_hpliu_create.restype = C.c_void_p
+        L.orpm_hpliu_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double]
+        L.orpm_hpliu_destroy.argtypes = [C.c_void_p]
+        L.orpm_hpliu_refine.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, dp, ip, ip, ip, ip]
+        L.orpm_hpliu_alj.argtypes = [C.c_int, dp]
         L.orpm_lgr_points.argtypes = [C.c_int, dp, dp]
         L.orpm_colloc_d.argtypes = [C.c_int, dp, dp]
         _LIB = L
@@ -79,6 +84,35 @@ def colloc_d(points):
     D = np.zeros((M - 1) * M)
     lib().orpm_colloc_d(M, _dp(pts), _dp(D))
     return D.reshape((M - 1, M), order="F")
+
+
+def hpliu_alj(N):
+    a = np.zeros((N + 1) * (N + 1))
+    lib().orpm_hpliu_alj(N, _dp(a))
+    return a.reshape((N + 1, N + 1), order="F")
+
+
+class HpLiu:
+    """LiuHpMeshRefineAlg (Core/LpLiuHpMeshRefineAlg.cpp), stateful across meshes."""
+
+    def __init__(self, n_phases, tol, nmax, ratio_r):
+        self._h = lib().orpm_hpliu_create(n_phases, float(tol), int(nmax), float(ratio_r))
+        self.P = n_phases
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orpm_hpliu_destroy(self._h)
+            self._h = None
+
+    def refine(self, oracle, x, cap=4096):
+        """-> (no_more_refine, [(mesh_points, nodes_per_interval) per phase]); raises where the reference would throw."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        mesh, nodes = np.zeros(cap), np.zeros(cap, dtype=np.int32)
+        moff, noff, nk = (np.zeros(self.P, dtype=np.int32) for _ in range(3))
+        rc = lib().orpm_hpliu_refine(self._h, oracle._h, _dp(x), cap, _dp(mesh), _ip(nodes), _ip(moff), _ip(noff), _ip(nk))
+        if rc < 0:
+            raise RuntimeError("hp-Liu: the reference would throw here (empty find / row out of range / undefined cast)")
+        return bool(rc), [(mesh[moff[p]:moff[p] + nk[p] + 1].copy(), nodes[noff[p]:noff[p] + nk[p]].copy()) for p in range(self.P)]
 
 
 class Oracle:

@@ -118,6 +118,15 @@ int orpm_ph_refine(orpm* o, int phase, const double* x, double tol, int Nmin, in
 void orpm_bary_tables(int M, const double* data_x, int Nq, const double* xq, double* H, double* S, int* fix);
 void orpm_inverse(int n, const double* A, double* inv);
 
+/* hp-Liu mesh refinement, LiuHpMeshRefineAlg (Core/LpLiuHpMeshRefineAlg.cpp:12-709); stateful across meshes like the
+ * reference object (mesh / state / mesh-point histories).  See oracle/orpm_hpliu.c for what is kept bug for bug. */
+typedef struct orpm_hpliu orpm_hpliu;
+orpm_hpliu* orpm_hpliu_create(int n_phases, double tol, int Nmax, double R);
+void orpm_hpliu_destroy(orpm_hpliu* h);
+int orpm_hpliu_refine(orpm_hpliu* h, orpm* o, const double* x, int cap, double* new_mesh, int* new_nodes, int* mesh_off,
+                      int* nodes_off, int* new_K);
+void orpm_hpliu_alj(int N, double* alj /* (N+1) x (N+1) */);
+
 /* stand-alone table helpers (exposed for the invariant tests) */
 void orpm_lgr_points(int n, double* x, double* w);                    /* RPMGenerator.cpp:253-291 */
 void orpm_colloc_d(int M, const double* x, double* D /*(M-1) x M col-major*/); /* :107-130 */

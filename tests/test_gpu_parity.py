@@ -455,3 +455,39 @@ def test_refinement_pass_builds_the_next_mesh(built):
     assert np.array_equal(x2, orc2.starting_point())               # the extracted solution, re-interpolated as the guess
     assert np.array_equal(eng2.eval_g(x2), orc2.eval_g(x2)) or rel_err(eng2.eval_g(x2), orc2.eval_g(x2)) <= 1e-12
     eng2.close()
+
+
+def test_hpliu_refinement_end_to_end(built):
+    """hp-Liu with the estimate computed on the device: same meshes as the oracle, call after call (the histories
+    live in both objects), through the MeshRefiner mirror with mesh-refine-methods=hp-Liu."""
+    from lpopc_amd.engine import HpLiuRefiner
+    from lpopc_amd.mesh import MeshRefiner
+    from lpopc_amd.problem import Options
+    from oracle import oracle as orc_mod
+    prob = problems.launch(3, 6)
+    opts = Options()
+    opts.SetStringValue("mesh-refine-methods", "hp-Liu")
+    opts.SetNumericValue("desired-relative-error", 1e-4)
+    refiner = MeshRefiner(opts)
+    ho = orc_mod.HpLiu(prob.GetPhaseNum(), 1e-4, opts.GetIntegerValue("Nmax"), opts.GetNumericValue("R"))
+    for it in range(3):
+        eng, orc = NLPEngine(prob, device=0), oracle_for(prob)
+        xl, xu, _, _ = eng.get_bounds_info()
+        x = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 11 + it)
+        eng.finalize_solution(0, x, np.zeros(eng.m), 0.0)
+        try:
+            d_ref, m_ref = ho.refine(orc, x)
+        except RuntimeError:
+            with pytest.raises(Exception):
+                refiner.RefineMesh(eng, prob)
+            eng.close()
+            break
+        done = refiner.RefineMesh(eng, prob)
+        eng.close()
+        assert done == d_ref
+        for i in range(prob.GetPhaseNum()):
+            assert np.array_equal(prob.GetPhase(i).GetMeshPoints(), m_ref[i][0]), (it, i)
+            assert list(prob.GetPhase(i).GetNodesPerInterval()) == [int(v) for v in m_ref[i][1]], (it, i)
+        if done:
+            break
+

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from lpopc_amd import problems
-from lpopc_amd.engine import NLPEngine, RpmError
+from lpopc_amd.engine import HpLiuRefiner, NLPEngine, RpmError
 from lpopc_amd.mesh import MeshRefiner, install_guess
 from lpopc_amd.problem import LpopcException, Options
 from oracle import oracle as orc
@@ -152,5 +152,92 @@ def test_mesh_refiner_bookkeeping():
     with pytest.raises(LpopcException):   # grid_ > max-grid-num, Core/LpMeshRefiner.cpp:65-68
         r.RefineMesh(_FakeEngine(grow), p)
     opts.SetStringValue("mesh-refine-methods", "hp-Liu")
-    with pytest.raises(LpopcException):
-        MeshRefiner(opts)
+    assert MeshRefiner(opts).method_ == "hp-Liu"
+
+
+# ---- hp-Liu (LiuHpMeshRefineAlg) -----------------------------------------------------------------------------
+def _sine_iterate(o):
+    """x = sin 2t on [0, 2] written into a Bryson-Denham iterate (x' = v, v' = u, e' = u^2/2): smooth, not polynomial."""
+    t = o.phase_tables(0)
+    N = t["points"].size
+    M = N + 1
+    tt = np.append(t["points"], 1.0) + 1
+    x = o.starting_point()
+    x[-2], x[-1] = 0.0, 2.0
+    x[:M] = np.sin(2 * tt)
+    x[M:2 * M] = 2 * np.cos(2 * tt)
+    x[2 * M:3 * M] = 8 * (tt / 2 - np.sin(4 * tt) / 8)
+    x[3 * M:3 * M + N] = -4 * np.sin(2 * tt[:N])
+    return x
+
+
+def test_lagrange_power_series_coefficients():
+    """alj (GetLagrangeInterpCoefficientsImpl): column i holds the descending power-series coefficients of the i-th
+    Lagrange basis polynomial on [LGR(N); 1] -> alj @ y are the coefficients of the interpolant of y."""
+    for N in (2, 3, 4, 6, 9):
+        a = orc.hpliu_alj(N)
+        x = np.append(orc.lgr_points(N)[0], 1.0)
+        y = np.random.default_rng(N).standard_normal(N + 1)
+        assert np.abs(np.polyval(a @ y, x) - y).max() < 1e-11
+        assert np.abs(a[0].sum()) < 1e-9 if N > 0 else True   # the leading coefficients of a partition of unity cancel
+
+
+@pytest.mark.parametrize("tol,nmax", [(1e-4, 14), (1e-6, 10), (1e-3, 16)])
+def test_hpliu_host_logic_matches_oracle(built, tol, nmax):
+    """The product's hp-Liu object (C++ behind rpm_hpliu_*) fed with the ORACLE's relative-error matrices decides exactly
+    what the oracle's restatement decides, mesh after mesh, until NoMoreRefine or a reference-would-throw stop."""
+    p = problems.bryson_denham()
+    ph = p.GetPhase(0)
+    ph.meshpoints, ph.nodesperinterval = [-1, -0.3, 0.4, 1], [5, 6, 4]
+    ho, hp = orc.HpLiu(1, tol, nmax, 1.2), HpLiuRefiner(1, tol, nmax, 1.2)
+    kinds = set()
+    for it in range(8):
+        o, e = orc.Oracle(p), NLPEngine(p)
+        x = _sine_iterate(o)
+        rel = o.solution_error(0, x)
+        try:
+            d1, m1 = ho.refine(o, x)
+        except RuntimeError:
+            with pytest.raises(RpmError):
+                hp.refine(e, x=x, rel_err=[rel])
+            kinds.add("throw")
+            e.close()
+            break
+        d2, m2 = hp.refine(e, x=x, rel_err=[rel])
+        e.close()
+        assert d1 == d2 and np.array_equal(m1[0][0], m2[0][0]) and np.array_equal(m1[0][1], m2[0][1]), it
+        old_k = len(ph.nodesperinterval)
+        kinds.add("split" if len(m1[0][1]) > old_k else "merge" if len(m1[0][1]) < old_k else "p")
+        assert m1[0][0][0] == -1 and m1[0][0][-1] == 1 and (np.diff(m1[0][0]) > 0).all() and (m1[0][1] >= 2).all()
+        ph.meshpoints, ph.nodesperinterval = m1[0][0].tolist(), [int(v) for v in m1[0][1]]
+        if d1:
+            kinds.add("done")
+            break
+    assert kinds & {"done", "throw"} and len(kinds) >= 2
+    hp.close()
+
+
+def test_hpliu_first_pass_rules(built):
+    """First mesh (mesh_index_ == 0): an unsatisfied interval gets exactly three more nodes (:122-131); a satisfied one
+    is reduced to the degree its power-series coefficients need, never below 2 (:438-481)."""
+    p = problems.bryson_denham()
+    ph = p.GetPhase(0)
+    ph.meshpoints, ph.nodesperinterval = [-1, 0.0, 1], [12, 3]
+    o = orc.Oracle(p)
+    x = _sine_iterate(o)
+    rel = o.solution_error(0, x)
+    emax = o.ph_refine(0, x, 1e-5, 4, 16)[3]
+    assert emax[0] < 1e-5 < emax[1]
+    done, meshes = orc.HpLiu(1, 1e-5, 16, 1.2).refine(o, x)
+    mesh, nodes = meshes[0]
+    assert not done and np.array_equal(mesh, [-1, 0, 1]) and nodes[1] == 6 and 2 <= nodes[0] <= 12
+    e = NLPEngine(p)
+    d2, m2 = HpLiuRefiner(1, 1e-5, 16, 1.2).refine(e, x=x, rel_err=[rel])
+    assert d2 == done and np.array_equal(m2[0][1], nodes)
+    with pytest.raises(RpmError):   # a second object fed an engine on a mesh it did not produce
+        h = HpLiuRefiner(1, 1e-5, 16, 1.2)
+        h.refine(e, x=x, rel_err=[rel])
+        ph.meshpoints, ph.nodesperinterval = [-1, 1], [5]
+        e2 = NLPEngine(p)
+        h.refine(e2, x=_sine_iterate(orc.Oracle(p)), rel_err=[orc.Oracle(p).solution_error(0, _sine_iterate(orc.Oracle(p)))])
+    e.close()
