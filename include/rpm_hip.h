@@ -240,6 +240,10 @@ int rpm_synchronize(rpm_engine* e);
  *                    persistent pipelined kernel (4 compute waves + 1 DMA wave per workgroup; inputs of the next tile
  *                    prefetched, constant block written by the DMA wave); automatic = every resident workgroup has
  *                    at least two tiles.  get-only "pipeline_active": 1 if the next launch uses it
+ * "const_once"       0 (default) | 1: host-pointer rpm_eval_jac_g downloads the linear and constant tail of `values`
+ *                    (they never change, LpNLPWrapper.cpp:242, :715-718) only into a buffer it did not fill on the
+ *                    previous call, afterwards just the NL prefix — for callers that hand the same array every
+ *                    iteration and leave it alone in between (Ipopt's TNLPAdapter does); one instance per engine
  * "check_finite"     1 (default): NaN/Inf in a result -> RPM_E_NONFINITE (checked on the device); 0: lpopc's behaviour
  * "pin_host"         1 (default): the host-pointer entry points page-lock (hipHostRegister) the caller's x / g /
  *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —

@@ -190,10 +190,24 @@ int rpm_eval_g(rpm_engine* h, int n, const double* x, int new_x, int m, double* 
   rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), flags, rpm::dev_stream(e));
   if (rc) return rc;
   rpm::dev_pin_host(e, g, size_t(e.n_instances) * e.m * sizeof(double));
-  rc = rpm::dev_download(e, g, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m);
+  // one round trip for the call: the download of g, the NaN/Inf scan of g and — when the launch was the fused pair —
+  // of the Jacobian that the following eval_jac_g(new_x = false) will only have to copy
+  rc = rpm::dev_download_enqueue(e, g, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m);
+  if (rc) return rc;
+  e.jac_nonfinite = -1;
+  if (e.opt_check_finite) {
+    rc = rpm::dev_nonfinite_enqueue(e, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m, 0);
+    if (rc == RPM_OK && flags == 3) rc = rpm::dev_nonfinite_enqueue(e, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac, 1);
+    if (rc == RPM_OK) rc = rpm::dev_flags_fetch(e);
+    if (rc) return rc;
+  }
+  rc = rpm::dev_sync(e);
   if (rc) return rc;
   rpm::dev_cache_valid(e) = (flags == 3);
-  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m) != 0) return fail(e, RPM_E_NONFINITE, "eval_g: non-finite constraint value");
+  if (e.opt_check_finite) {
+    if (flags == 3) e.jac_nonfinite = rpm::dev_flag_value(e, 1);
+    if (rpm::dev_flag_value(e, 0) != 0) return fail(e, RPM_E_NONFINITE, "eval_g: non-finite constraint value");
+  }
   return RPM_OK;
   RPM_GUARD_END(e)
 }
@@ -220,9 +234,18 @@ int rpm_eval_jac_g(rpm_engine* h, int n, const double* x, int new_x, int m, int 
     if (rc) return rc;
   }
   rpm::dev_pin_host(e, values, size_t(e.n_instances) * e.nnz_jac * sizeof(double));
-  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac);
+  // values = [NL | LIN | CONST]: with "const_once" the constant tail (54 % of the entries at the metric problem) crosses
+  // PCIe only when the caller hands a buffer this engine did not fill last time
+  size_t count = size_t(e.n_instances) * e.nnz_jac;
+  if (e.opt_const_once && e.n_instances == 1 && values == e.const_filled) count = size_t(e.nnz_nl);
+  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 2), count);
   if (rc) return rc;
-  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac) != 0) return fail(e, RPM_E_NONFINITE, "eval_jac_g: non-finite Jacobian value");
+  e.const_filled = values;
+  if (e.opt_check_finite) {
+    const int bad = (cached && e.jac_nonfinite >= 0) ? e.jac_nonfinite   // scanned with the pair launch already
+                                                      : rpm::dev_nonfinite(e, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac);
+    if (bad != 0) return fail(e, RPM_E_NONFINITE, "eval_jac_g: non-finite Jacobian value");
+  }
   return RPM_OK;
   RPM_GUARD_END(e)
 }
@@ -547,6 +570,10 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
       e.role_looped = false;
       rpm::build_tiles(e, value);
     }
+  } else if (k == "const_once") {
+    if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "const_once must be 0 or 1");
+    e.opt_const_once = value;
+    e.const_filled = nullptr;
   } else if (k == "pipeline") {
     if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "pipeline must be -1 (auto), 0 or 1");
     e.opt_pipeline = value;
@@ -576,6 +603,7 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "n_tiles") *value = int(e.tiles.size());
   else if (k == "role_loop") *value = e.role_looped ? 1 : 0;
   else if (k == "pipeline") *value = e.opt_pipeline;
+  else if (k == "const_once") *value = e.opt_const_once;
   else if (k == "pipeline_active") *value = rpm::dev_pipeline_active(e);
   else return fail(e, RPM_E_INVALID, "unknown option");
   return RPM_OK;

@@ -69,6 +69,8 @@ struct HParams {
 
 struct Device {
   int device_id = -1;
+  int* d_flags2 = nullptr;      // two non-finite flag words (g, Jacobian) and their page-locked host mirror
+  int* h_flags2 = nullptr;
   size_t trace_words = 0;
   hipStream_t stream = nullptr;
   KParams kp{};
@@ -1811,6 +1813,8 @@ void device_destroy(Engine& e) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->d_flag) (void)hipFree(d->d_flag);
+  if (d->d_flags2) (void)hipFree(d->d_flags2);
+  if (d->h_flags2) (void)hipHostFree(d->h_flags2);
   for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.first));
   (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
   for (auto& row : d->segtab)
@@ -2144,6 +2148,34 @@ int dev_nonfinite(Engine& e, const double* dev, size_t count) {
   if (hipMemcpyAsync(&h, d.d_flag, sizeof(int), hipMemcpyDeviceToHost, d.stream) != hipSuccess) return -1;
   if (hipStreamSynchronize(d.stream) != hipSuccess) return -1;
   return h;
+}
+
+// The same check without its own round trip: zero flag word `slot` (0 or 1) and scan dev[0..count) on the engine's
+// stream; dev_flags_fetch queues the copy of both words into page-locked host memory.  The caller synchronises once,
+// together with its result download, and reads dev_flag_value.
+int dev_nonfinite_enqueue(Engine& e, const double* dev, size_t count, int slot) {
+  Device& d = *e.dev;
+  if (!d.d_flags2) {
+    if (hipMalloc(reinterpret_cast<void**>(&d.d_flags2), 2 * sizeof(int)) != hipSuccess) return RPM_E_DEVICE;
+    if (hipHostMalloc(reinterpret_cast<void**>(&d.h_flags2), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return RPM_E_DEVICE;
+    d.h_flags2[0] = d.h_flags2[1] = 0;
+  }
+  HIP_TRY(e, hipMemsetAsync(d.d_flags2 + slot, 0, sizeof(int), d.stream));
+  unsigned blocks = unsigned((count + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(rpm_finite_kernel, dim3(blocks), dim3(256), 0, d.stream, dev, count, d.d_flags2 + slot);
+  return RPM_OK;
+}
+int dev_flags_fetch(Engine& e) {
+  Device& d = *e.dev;
+  HIP_TRY(e, hipMemcpyAsync(d.h_flags2, d.d_flags2, 2 * sizeof(int), hipMemcpyDeviceToHost, d.stream));
+  return RPM_OK;
+}
+int dev_flag_value(Engine& e, int slot) { return e.dev->h_flags2 ? e.dev->h_flags2[slot] : 0; }
+int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count) {
+  HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e.dev->stream));
+  return RPM_OK;
 }
 
 // Page-lock the caller's buffer once (Ipopt hands the same x / g / values arrays every iteration) so that

@@ -159,6 +159,8 @@ struct Engine {
   int opt_fuse_pair = 1, opt_dx_mode = 0, opt_tile_nodes = 0, opt_check_finite = 1, opt_const_once = 0;
   int opt_role_loop = -1;        // -1 automatic, 0 never, 1 always (when tile_nodes is automatic)
   int opt_pipeline = -1;         // rpm_tile_pl_kernel: -1 automatic (>= 2 tiles per resident workgroup), 0 never, 1 whenever the mesh fits
+  int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
+  const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)
   int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
   std::vector<double> sol_x, sol_lambda;
@@ -232,6 +234,10 @@ double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 
 bool& dev_cache_valid(Engine& e);
 void* dev_stream(Engine& e);
 int dev_nonfinite(Engine& e, const double* dev, size_t count);   // 1 if a NaN/Inf is present, checked on the device
+int dev_nonfinite_enqueue(Engine& e, const double* dev, size_t count, int slot);   // asynchronous form: flag word 0 or 1
+int dev_flags_fetch(Engine& e);
+int dev_flag_value(Engine& e, int slot);
+int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count);
 void dev_pin_host(Engine& e, const void* ptr, size_t bytes);       // page-lock a caller buffer once (best effort)            // the engine's own stream (host-pointer TNLP path)
 
 }  // namespace rpm

@@ -491,3 +491,28 @@ def test_hpliu_refinement_end_to_end(built):
         if done:
             break
 
+
+def test_const_once_downloads_only_the_changing_prefix(built):
+    """Option const_once: the second eval_jac_g into the same host array refreshes only the NL prefix; the array still
+    equals a full evaluation, and a different array gets a full download again."""
+    prob = problems.launch(3, 6)
+    eng, full = NLPEngine(prob, device=0), NLPEngine(prob, device=0)
+    eng.set_option("const_once", 1)
+    xl, xu, _, _ = eng.get_bounds_info()
+    x1 = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 1)
+    x2 = problems.seeded_iterate(eng.get_starting_point(), xl, xu, 2)
+    buf = np.full(eng.nnz_jac, np.nan)
+    eng.eval_jac_g(x1, out=buf)
+    assert np.array_equal(buf, full.eval_jac_g(x1))
+    nl = eng.nnz_jac - int(np.sum(buf == full.eval_jac_g(x2)))   # entries that change with x: all inside the NL prefix
+    tail_probe = buf[-1]
+    buf[-1] = 12345.0                                             # a caller that scribbles on the tail keeps its scribble
+    eng.eval_jac_g(x2, out=buf)
+    ref = full.eval_jac_g(x2)
+    assert buf[-1] == 12345.0 and np.array_equal(buf[:-1], ref[:-1]) and ref[-1] == tail_probe and nl > 0
+    other = np.full(eng.nnz_jac, np.nan)
+    eng.eval_jac_g(x2, out=other)
+    assert np.array_equal(other, ref)
+    eng.close()
+    full.close()
+

@@ -93,8 +93,9 @@ def main():
         if name.startswith("3") and B == 1:
             # host-pointer (Ipopt) path: x up, g down, values down through PCIe every pair
             # (Ipopt reuses its x / g / values arrays, so they are page-locked once: pin_host = 1)
-            for pin in (0, 1):
+            for pin, once in ((0, 0), (1, 0), (1, 1)):
                 one.set_option("pin_host", pin)
+                one.set_option("const_once", once)
                 xh = np.ascontiguousarray(xs[:8].copy())
                 gh, vh = np.zeros(one.m), np.zeros(one.nnz_jac)
                 for n in range(8):
@@ -102,8 +103,9 @@ def main():
                 t0 = time.perf_counter(); n = 0
                 while time.perf_counter() - t0 < 2.0:
                     one.eval_g(xh[n % 8], True, out=gh); one.eval_jac_g(xh[n % 8], False, out=vh); n += 1
-                out["host_pointer_pairs_per_s_pcie_inclusive" + ("_pinned" if pin else "_pageable")] = n / (time.perf_counter() - t0)
+                out["host_pointer_pairs_per_s_pcie_inclusive" + ("_pinned" if pin else "_pageable") + ("_const_once" if once else "")] = n / (time.perf_counter() - t0)
             one.set_option("pin_host", 0)
+            one.set_option("const_once", 0)
         print(json.dumps(out), flush=True)
         one.close()
         if eng is not one:
