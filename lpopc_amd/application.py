@@ -1,0 +1,97 @@
+"""Host-side mirror of lpopc's application shell, for end-to-end runs of the GPU path.
+
+Reference: `LpopcApplication` (Core/LpLpopcApplication.hpp:28-36: SetOptimalControlProblem / Options /
+SolveOptimalProblem) and the outer loop of `LpopcAlgorithm::Optimization` (Core/LpLpopcAlgorithm.cpp:20-43):
+
+    SetFirstMesh; GetSizes; GetBounds; GetGuess; SolveNlp; Nlp2OpControl;
+    while (!RefineMesh()) { UpdateGrid; GetSizes; GetBounds; GetGuess; SolveNlp; Nlp2OpControl; }
+    FinalResultSave
+
+`GetSizes/GetBounds/GetGuess` are what `rpm_create` does per mesh; `Nlp2OpControl`, the error estimate and the
+refinement decision are the post-solve entry points of the C ABI.  The NLP solver itself is NOT part of the reference's
+sources (it hands an `Ipopt::TNLP` to Ipopt 3.12.3, Core/LpNLPSolver.cpp:13-53) and Ipopt is not in this image:
+`ScipyNLPSolver` drives the same callbacks with scipy's trust-constr instead.  It is a stand-in for small problems (tests,
+demos), not a replacement for Ipopt; in particular its constraint multipliers are not of Ipopt's quality, so costates and
+Hamiltonian extracted from them are indicative only.
+"""
+import numpy as np
+
+from .engine import NLPEngine
+from .mesh import MeshRefiner, install_guess
+from .problem import LpopcException, Options
+
+console_not_print, console_print = 0, 1
+
+
+class ScipyNLPSolver:
+    """Stand-in for NLPSolver::SolveNlp (Core/LpNLPSolver.cpp:13-53): min f(x) s.t. g_l <= g(x) <= g_u, x_l <= x <= x_u
+    through the TNLP callbacks (eval_f, eval_grad_f, eval_g, eval_jac_g + structure), quasi-Newton Hessian like the
+    reference's default hessian-approximation=limited-memory."""
+
+    def __init__(self, tol=1e-6, maxiter=1500):
+        self.tol, self.maxiter = float(tol), int(maxiter)
+
+    def SolveNlp(self, nlp):
+        from scipy.optimize import BFGS, Bounds, NonlinearConstraint, minimize
+        from scipy.sparse import coo_matrix
+
+        xl, xu, gl, gu = nlp.get_bounds_info()
+        i, j = nlp.eval_jac_g_structure()
+        n, m = nlp.n, nlp.m
+
+        def jac(x):
+            return coo_matrix((nlp.eval_jac_g(x), (i, j)), shape=(m, n)).tocsr()
+
+        res = minimize(lambda x: float(np.ravel(nlp.eval_f(x))[0]), np.clip(nlp.get_starting_point(), xl, xu),
+                       jac=nlp.eval_grad_f, hess=BFGS(), bounds=Bounds(xl, xu),
+                       constraints=[NonlinearConstraint(nlp.eval_g, gl, gu, jac=jac)], method="trust-constr",
+                       options={"maxiter": self.maxiter, "gtol": self.tol * 1e-2, "xtol": 1e-12, "verbose": 0})
+        lam = np.asarray(res.v[0], dtype=np.float64) if len(res.v) else np.zeros(m)
+        nlp.finalize_solution(int(res.status), res.x, lam, float(res.fun))
+        self.last = res
+        # trust-constr creeps through its last digits on some problems; a feasible point at the iteration limit is
+        # still reported (the caller sees res.status in self.last)
+        return res.status in (1, 2) or res.constr_violation <= 1e-5
+
+
+class LpopcApplication:
+    def __init__(self, if_console_print=console_print):
+        self.print_ = if_console_print
+        self.optionlist_ = Options()
+        self.optpro_ = None
+        self.result = None          # per phase: the arrays of Nlp2OpControl on the final mesh
+        self.objective = None
+        self.meshrefiner_ = None
+
+    def SetOptimalControlProblem(self, user_optimal_control_problem):
+        self.optpro_ = user_optimal_control_problem
+
+    def Options(self):
+        return self.optionlist_
+
+    def _say(self, msg):
+        if self.print_:
+            print(msg)
+
+    def SolveOptimalProblem(self, nlp_solver=None, device=0, result_dir=None):
+        if self.optpro_ is None:
+            raise LpopcException("No optimal control problem has been set")
+        solver = nlp_solver or ScipyNLPSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))
+        self.meshrefiner_ = MeshRefiner(self.optionlist_)
+        while True:
+            eng = NLPEngine(self.optpro_, self.optionlist_, device=device)     # GetSizes, GetBounds, GetGuess
+            try:
+                ok = solver.SolveNlp(eng)
+                self.objective = eng.get_solution()[2]
+                self._say("grid %d: n=%d m=%d objective %.9g%s" % (self.meshrefiner_.CurrentGrid(), eng.n, eng.m, self.objective,
+                                                                  "" if ok else " (NLP solver did not converge)"))
+                install_guess(eng, self.optpro_)                                   # Nlp2OpControl
+                self.result = [eng.nlp2op_control(i) for i in range(self.optpro_.GetPhaseNum())]
+                done = self.meshrefiner_.RefineMesh(eng, self.optpro_)             # error estimate + new mesh
+                if done and result_dir is not None:
+                    eng.final_result_save(result_dir)                             # FinalResultSave
+            finally:
+                eng.close()
+            if done:
+                self._say("Optimal Problem Solved!Lpopc Exited!")
+                return True
