@@ -86,6 +86,11 @@ def lower(problem, options=None, n_instances=1, shard_mode=0, shard_rank=0, shar
     from .problem import Options, apply_mesh_defaults
 
     options = options or Options()
+    if options.GetStringValue("auto-scale") == "yes":
+        # LpScaleOCP (Core/LpSacleOCP.cpp) derives its function scales from random samples (CalculateFunScaleFromRand) and
+        # the reference itself warns "auto-scale may fail" (Core/LpLpopcAlgorithm.cpp:295); it is out of this path's scope.
+        from .problem import LpopcException
+        raise LpopcException("auto-scale=yes is not supported by the GPU path (SURVEY scope: scaling stays off)")
     keep = []
     phases = (rpm_phase_desc * problem.GetPhaseNum())()
     for i in range(problem.GetPhaseNum()):

@@ -163,3 +163,11 @@ def test_interval_shard_segments_partition_the_vectors(built):
                     pos += ln
                     cover[off:off + ln] += 1
             assert np.all(cover == 1)                                # every entry owned by exactly one rank
+
+
+def test_auto_scale_is_refused_loudly(built):
+    opts = Options()
+    opts.SetStringValue("auto-scale", "yes")
+    with pytest.raises(LpopcException):
+        NLPEngine(problems.bryson_denham(), opts)
+
