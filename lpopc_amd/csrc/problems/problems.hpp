@@ -61,11 +61,7 @@ struct LaunchProblem {
     const double rho = exp(-altitude / c[13]) * c[12];                 // :676-677
     const double bc = rho / (m * 2) * (c[11] * c[10]);                 // :678
     const double bcspeed = bc * speedrel;
-#ifdef RPM_EXP_CUBE
-    const double mu3 = (1.0 * c[9]) / (rad * rad * rad);
-#else
     const double mu3 = (1.0 * c[9]) / cube_rn(rad);                    // mu / pow(rad, 3), :683-684
-#endif
     double T_tot, mdot;
     if (ph == 1 || ph == 2) {                                          // :688-711
       const double T_srb = 1.0 * ((ph == 1 ? 6 : 3) * c[16]);

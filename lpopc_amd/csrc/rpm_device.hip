@@ -272,13 +272,8 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 }
 
 // ------------------------------------------------------------------------------------------
-#ifdef RPM_EXP_WAVES
-#define RPM_TILE_ATTR __attribute__((amdgpu_waves_per_eu(RPM_EXP_WAVES, 8)))
-#else
-#define RPM_TILE_ATTR
-#endif
 template <class Prob, int T, bool WG, bool WJ, bool AN, bool DXM = false>
-__global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
+__global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
                                 double* __restrict__ gall, double* __restrict__ vall) {
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
   constexpr int NO = NX + NC;              // outputs per node: f then c
@@ -302,12 +297,8 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
   // XCD-aware tile order: workgroups b, b+8, b+16, ... are dealt to the same XCD, so give each XCD a
   // contiguous run of tiles; neighbouring 128-byte pieces of every Jacobian block then meet in one L2
   // and leave it as longer contiguous write-backs (speed only, correctness does not depend on placement)
-#ifndef RPM_EXP_NOXCD
   const int nt = K.n_my_tiles, per = nt >> 3, rem = nt & 7, xcd = int(blockIdx.x) & 7, slot = int(blockIdx.x) >> 3;
   const int tix = xcd * per + (xcd < rem ? xcd : rem) + slot;
-#else
-  const int tix = blockIdx.x;
-#endif
   const TileDev tl = K.tiles[tix];
   const TileDev& ph = tl;   // the phase fields the kernel needs are replicated in the tile record
 #ifdef RPM_DIAG
@@ -329,11 +320,7 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
   const double tau = K.points[nidx];
   const NodeDev nd = K.nodes[nidx];
   const double ddiag = WJ ? K.diag[nidx] : 0.0;
-#ifdef RPM_EXP_CPRE
-  constexpr int CPRE = RPM_EXP_CPRE;
-#else
   constexpr int CPRE = 8;                          // constant-block sources prefetched per thread
-#endif
   double cpre[CPRE > 0 ? CPRE : 1];
   if (WJ) {
 #pragma unroll
@@ -465,17 +452,10 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
 #endif
     if (WJ && role >= 1) {
       double J[NO];
-#ifdef RPM_EXP_RCP
-      const double rh = 1.0 / h;
-#endif
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
         const double pert = o < NX ? f[o < NX ? o : 0] : cp[o >= NX ? o - NX : 0];
-#ifdef RPM_EXP_RCP
-        J[o] = AN ? pert : (pert - Fb[o * T + kk]) * rh;
-#else
         J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
-#endif
       }
       double* vb = vals + ph.v_nl0 + k;
       if (v < NX + NU) {
@@ -552,13 +532,8 @@ __global__ RPM_TILE_ATTR void rpm_tile_kernel(const KParams K, const double* __r
 #else
 #define RPM_TRC(i)
 #endif
-#ifdef RPM_EXP_RL_WAVES
-#define RPM_RL_ATTR __attribute__((amdgpu_waves_per_eu(RPM_EXP_RL_WAVES, 8)))
-#else
-#define RPM_RL_ATTR
-#endif
 template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
-__global__ __launch_bounds__(T* RG) RPM_RL_ATTR void rpm_tile_rl_kernel(const KParams K, const double* __restrict__ xall,
+__global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, const double* __restrict__ xall,
                                                             double* __restrict__ gall, double* __restrict__ vall) {
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
   constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
