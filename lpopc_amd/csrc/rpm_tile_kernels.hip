@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
     // staging buffer also carries the record of the tile AFTER its own), so issuing the next tile's loads never waits
     // for global memory; only the first tile of a workgroup reads its record from HBM.
     struct TileRuns { int k0, cnt, span0, span_len, drow0, drow_len, N, x_state0, x_control0, x_t0, node0, c_src0, c_cnt; };
-    auto runs_of = [&](const int* p) {
+    auto runs_of = [&](auto p) {   // p: the record as ints, in LDS or (first tile) in the constant address space
       TileRuns r;
 #define RPM_RF(f) r.f = __builtin_amdgcn_readfirstlane(p[offsetof(TileDev, f) / 4])
       RPM_RF(k0); RPM_RF(cnt); RPM_RF(span0); RPM_RF(span_len); RPM_RF(drow0); RPM_RF(drow_len); RPM_RF(N);
@@ -771,7 +771,8 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
       if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
     };
     if (dw == 0 && lane == 0) *fb_ready = 0;
-    if (n_iter > 0) stage(w, lds, runs_of(reinterpret_cast<const int*>(K.tiles + (w - (w / nt) * nt))));
+    if (n_iter > 0)   // the tile table never changes: constant address space, i.e. scalar loads for the first record
+      stage(w, lds, runs_of((const __attribute__((address_space(4))) int*)(K.tiles + (w - (w / nt) * nt))));
     for (int j = 0; j < n_iter_wg; ++j) {
       const double* cur = lds + (j & 1) * S_SIZE;
       double* nxt = lds + ((j + 1) & 1) * S_SIZE;
