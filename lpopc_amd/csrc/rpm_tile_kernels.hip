@@ -512,13 +512,18 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
     double h = 1.0;
     const int v = role - 1;
     if (WJ && !AN && role >= 1) {     // h = tol (1+|v|), v+h  (LpFiniteDifferenceDerive.cpp:208-214)
+      // the role is wave-uniform: fetch the one perturbed variable by its (scalar) row, form h and v+h once
+      double pv;
+      if (v < NX) pv = Xs[v * K.max_span + (k - tl.span0)];
+      else if (v < NX + NU) pv = Us[(v - NX) * T + kc];
+      else pv = tk;
+      h = K.tol * (1 + fabs(pv));
+      const double pp = pv + h;
 #pragma unroll
-      for (int i = 0; i < NX; ++i)
-        if (v == i) { h = K.tol * (1 + fabs(xs[i])); xs[i] += h; }
+      for (int i = 0; i < NX; ++i) xs[i] = (v == i) ? pp : xs[i];
 #pragma unroll
-      for (int j = 0; j < NU; ++j)
-        if (v == NX + j) { h = K.tol * (1 + fabs(us[j])); us[j] += h; }
-      if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
+      for (int j = 0; j < NU; ++j) us[j] = (v == NX + j) ? pp : us[j];
+      tk = (v == NX + NU) ? pp : tk;
     }
     double f[NX > 0 ? NX : 1], cp[NCs];
 #ifdef RPM_DIAG
