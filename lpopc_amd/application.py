@@ -42,10 +42,19 @@ class ScipyNLPSolver:
         def jac(x):
             return coo_matrix((nlp.eval_jac_g(x), (i, j)), shape=(m, n)).tocsr()
 
-        res = minimize(lambda x: float(np.ravel(nlp.eval_f(x))[0]), np.clip(nlp.get_starting_point(), xl, xu),
-                       jac=nlp.eval_grad_f, hess=BFGS(), bounds=Bounds(xl, xu),
-                       constraints=[NonlinearConstraint(nlp.eval_g, gl, gu, jac=jac)], method="trust-constr",
-                       options={"maxiter": self.maxiter, "gtol": self.tol * 1e-2, "xtol": 1e-12, "verbose": 0})
+        try:   # the KKT systems here are small: a BLAS thread pool only gets in its own way (100x on a many-core host)
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        except ImportError:
+            limit = None
+        try:
+            res = minimize(lambda x: float(np.ravel(nlp.eval_f(x))[0]), np.clip(nlp.get_starting_point(), xl, xu),
+                           jac=nlp.eval_grad_f, hess=BFGS(), bounds=Bounds(xl, xu),
+                           constraints=[NonlinearConstraint(nlp.eval_g, gl, gu, jac=jac)], method="trust-constr",
+                           options={"maxiter": self.maxiter, "gtol": self.tol * 1e-2, "xtol": 1e-12, "verbose": 0})
+        finally:
+            if limit is not None:
+                limit.restore_original_limits()
         lam = np.asarray(res.v[0], dtype=np.float64) if len(res.v) else np.zeros(m)
         nlp.finalize_solution(int(res.status), res.x, lam, float(res.fun))
         self.last = res

@@ -5,6 +5,9 @@ gradient, constraints, Jacobian, bounds, starting point) of the transcribed prob
 (scipy's trust-constr; Ipopt is not in this image), must reproduce optima known in closed form.
   * Bryson-Denham (state-constrained double integrator, l = 1/9): J* = 4 / (9 l) = 4.
   * Brachistochrone: T* from the cycloid through the end point.
+  * Hypersensitive (Lagrange cost, turnpike): for tf >> 1 the optimum is V(x0) + W(xf) with V' = -x^3 + sqrt(x^6 + x^2)
+    (decay to the origin) and W' = x^3 + sqrt(x^6 + x^2) (arrival from it), from the Hamilton-Jacobi-Bellman equation
+    of  min 1/2 int (x^2 + u^2),  x' = -x^3 + u.
 CPU: the oracle's callbacks.  GPU: the product's, inside the reference's outer loop (solve -> extract -> estimate ->
 refine) through the LpopcApplication mirror."""
 import numpy as np
@@ -78,6 +81,22 @@ def test_brachistochrone_optimum_with_oracle_callbacks():
     T = _cycloid_time(ev[3], ev[4], prob.GetOpimalProblemFuns().consts[0])
     assert abs(obj - T) < 1e-4 * T, (obj, T)
     assert abs(x[-1] - T) < 1e-4 * T
+
+
+def test_hypersensitive_turnpike_cost_with_oracle_callbacks():
+    """The Lagrange-cost path (quadrature, gradient of the integrand, analytic first derivatives): J* = V(1.5) + W(1)."""
+    from scipy.integrate import quad
+    from lpopc_amd.application import ScipyNLPSolver
+    from lpopc_amd.problem import Options
+    V = quad(lambda x: -x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.5)[0]
+    W = quad(lambda x: x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.0)[0]
+    K, n = 6, 10
+    prob = problems.hypersensitive(np.linspace(-1, 1, K + 1).tolist(), [n] * K, tf=30.0)
+    opts = Options()
+    opts.SetStringValue("first-derive", "analytic")
+    nlp = _OracleNLP(orc.Oracle(prob, opts))
+    assert ScipyNLPSolver(1e-7, maxiter=300).SolveNlp(nlp)
+    assert abs(nlp.sol[2] - (V + W)) < 1e-3 * (V + W), (nlp.sol[2], V + W)
 
 
 @pytest.mark.gpu
