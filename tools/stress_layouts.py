@@ -40,10 +40,20 @@ for t in range(trials):
     for mode in ("rl", "pl"):
         eng = NLPEngine(prob, n_instances=B, device=0, role_loop=1)
         eng.set_option("pipeline", 1 if mode == "pl" else 0)
-        dg = torch.full((B, eng.m), np.nan, dtype=torch.float64, device="cuda")
-        dv = torch.full((B, eng.nnz_jac), np.nan, dtype=torch.float64, device="cuda")
+        # outputs sit between guard bands: an out-of-bounds store of a kernel shows up as a changed guard word
+        GUARD = 4096
+        raw_g = torch.full((B * eng.m + 2 * GUARD,), 7.25, dtype=torch.float64, device="cuda")
+        raw_v = torch.full((B * eng.nnz_jac + 2 * GUARD,), 7.25, dtype=torch.float64, device="cuda")
+        dg = raw_g[GUARD:GUARD + B * eng.m].view(B, eng.m)
+        dv = raw_v[GUARD:GUARD + B * eng.nnz_jac].view(B, eng.nnz_jac)
+        dg.fill_(float("nan"))
+        dv.fill_(float("nan"))
         eng.eval_pair_dev(dx, dg, dv)
         torch.cuda.synchronize()
+        for raw in (raw_g, raw_v):
+            if not (bool((raw[:GUARD] == 7.25).all()) and bool((raw[-GUARD:] == 7.25).all())):
+                bad += 1
+                print("GUARD BAND TOUCHED", t, name, mode, "B", B)
         active = eng.get_option("pipeline_active")
         g, v = dg.cpu().numpy(), dv.cpu().numpy()
         ok = all(np.array_equal(g[b], ref_g[b]) and np.array_equal(v[b], ref_v[b]) for b in range(xs.shape[0]))
