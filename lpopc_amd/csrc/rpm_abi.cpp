@@ -196,8 +196,8 @@ int rpm_eval_g(rpm_engine* h, int n, const double* x, int new_x, int m, double* 
   if (rc) return rc;
   e.jac_nonfinite = -1;
   if (e.opt_check_finite) {
-    rc = rpm::dev_nonfinite_enqueue(e, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m, 0);
-    if (rc == RPM_OK && flags == 3) rc = rpm::dev_nonfinite_enqueue(e, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac, 1);
+    rc = rpm::dev_nonfinite_enqueue(e, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m, rpm::dev_buf(e, 2),
+                                    flags == 3 ? size_t(e.n_instances) * e.nnz_jac : 0);
     if (rc == RPM_OK) rc = rpm::dev_flags_fetch(e);
     if (rc) return rc;
   }

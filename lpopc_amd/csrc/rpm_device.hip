@@ -180,8 +180,7 @@ void device_destroy(Engine& e) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->d_flag) (void)hipFree(d->d_flag);
-  if (d->d_flags2) (void)hipFree(d->d_flags2);
-  if (d->h_flags2) (void)hipHostFree(d->h_flags2);
+  if (d->h_flags2) (void)hipHostFree(d->h_flags2);   // d_flags2 is its device alias
   for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.first));
   (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
   for (auto& row : d->segtab)
@@ -362,26 +361,36 @@ int dev_nonfinite(Engine& e, const double* dev, size_t count) {
   return h;
 }
 
-// The same check without its own round trip: zero flag word `slot` (0 or 1) and scan dev[0..count) on the engine's
-// stream; dev_flags_fetch queues the copy of both words into page-locked host memory.  The caller synchronises once,
-// together with its result download, and reads dev_flag_value.
-int dev_nonfinite_enqueue(Engine& e, const double* dev, size_t count, int slot) {
+__global__ void rpm_finite2_kernel(const double* __restrict__ a, size_t na, const double* __restrict__ b, size_t nb,
+                                   int* __restrict__ flags) {
+  // flags[0]: a NaN/Inf in a[0..na); flags[1]: in b[0..nb).  The host zeroes both words before the launch.
+  bool bad_a = false, bad_b = false;
+  const size_t stride = size_t(gridDim.x) * blockDim.x, first = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (size_t i = first; i < na; i += stride) bad_a |= !isfinite(a[i]);
+  for (size_t i = first; i < nb; i += stride) bad_b |= !isfinite(b[i]);
+  if (__any(bad_a) && (threadIdx.x & 63) == 0) atomicOr_system(flags, 1);       // host memory
+  if (__any(bad_b) && (threadIdx.x & 63) == 0) atomicOr_system(flags + 1, 1);
+}
+
+// The same check without its own round trip: scan a[0..na) (flag word 0) and b[0..nb) (word 1, may be empty) in ONE
+// launch on the engine's stream; the words are device-visible host memory.  The caller synchronises once, together
+// with its result download, and reads dev_flag_value.
+int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b, size_t nb) {
   Device& d = *e.dev;
-  if (!d.d_flags2) {
-    if (hipMalloc(reinterpret_cast<void**>(&d.d_flags2), 2 * sizeof(int)) != hipSuccess) return RPM_E_DEVICE;
-    if (hipHostMalloc(reinterpret_cast<void**>(&d.h_flags2), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return RPM_E_DEVICE;
-    d.h_flags2[0] = d.h_flags2[1] = 0;
+  if (!d.h_flags2) {   // the two words live in page-locked host memory the device can write: no memset, no copy back
+    if (hipHostMalloc(reinterpret_cast<void**>(&d.h_flags2), 2 * sizeof(int), hipHostMallocMapped) != hipSuccess) return RPM_E_DEVICE;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_flags2), d.h_flags2, 0) != hipSuccess) return RPM_E_DEVICE;
   }
-  HIP_TRY(e, hipMemsetAsync(d.d_flags2 + slot, 0, sizeof(int), d.stream));
-  unsigned blocks = unsigned((count + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  d.h_flags2[0] = d.h_flags2[1] = 0;   // the previous scan was synchronised before its words were read
+  const size_t most = na > nb ? na : nb;
+  unsigned blocks = unsigned((most + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(rpm_finite_kernel, dim3(blocks), dim3(256), 0, d.stream, dev, count, d.d_flags2 + slot);
+  hipLaunchKernelGGL(rpm_finite2_kernel, dim3(blocks), dim3(256), 0, d.stream, a, na, b, nb, d.d_flags2);
   return RPM_OK;
 }
-int dev_flags_fetch(Engine& e) {
-  Device& d = *e.dev;
-  HIP_TRY(e, hipMemcpyAsync(d.h_flags2, d.d_flags2, 2 * sizeof(int), hipMemcpyDeviceToHost, d.stream));
+int dev_flags_fetch(Engine& e) {   // nothing to queue: the kernel ORs straight into host memory (rarely: only on NaN/Inf)
+  (void)e;
   return RPM_OK;
 }
 int dev_flag_value(Engine& e, int slot) { return e.dev->h_flags2 ? e.dev->h_flags2[slot] : 0; }

@@ -234,7 +234,7 @@ double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 
 bool& dev_cache_valid(Engine& e);
 void* dev_stream(Engine& e);
 int dev_nonfinite(Engine& e, const double* dev, size_t count);   // 1 if a NaN/Inf is present, checked on the device
-int dev_nonfinite_enqueue(Engine& e, const double* dev, size_t count, int slot);   // asynchronous form: flag word 0 or 1
+int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b, size_t nb);   // asynchronous form, flag words 0 / 1
 int dev_flags_fetch(Engine& e);
 int dev_flag_value(Engine& e, int slot);
 int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count);
