@@ -82,11 +82,42 @@ class LpopcApplication:
         if self.print_:
             print(msg)
 
+    def CheckAnalyticDerive(self, device=0):
+        """analytic-derive-check=yes (LpANDeriveChecker::CheckeAnlyticlDerive, Core/LpANDeriveChecker.cpp:13-571; wired in
+        Core/LpLpopcAlgorithm.cpp:179-184): at the guess, the user's analytic derivatives against forward differences with
+        perturbation analytic-derive-check-tol, entries differing by more than that tolerance are reported.  The reference
+        compares the raw derivative matrices of every user function; here the comparison is made on what those matrices
+        become — the NLP Jacobian values and the objective gradient — so a (dt/2) factor sits on the dynamics entries.
+        Returns the list of (kind, index, analytic, finite difference) that differ; prints them like the reference warns."""
+        from .problem import Options
+        tol = self.optionlist_.GetNumericValue("analytic-derive-check-tol")
+        fd = Options()
+        fd.SetNumericValue("finite-difference-tol", tol)
+        an = Options()
+        an.SetStringValue("first-derive", "analytic")
+        bad = []
+        ea, ef = NLPEngine(self.optpro_, an, device=device), NLPEngine(self.optpro_, fd, device=device)
+        try:
+            x = ea.get_starting_point()
+            for kind, a, f in (("jacobian value", ea.eval_jac_g(x), ef.eval_jac_g(x)),
+                               ("objective gradient", ea.eval_grad_f(x), ef.eval_grad_f(x))):
+                for k in np.nonzero(np.abs(a - f) > tol)[0]:
+                    bad.append((kind, int(k), float(a[k]), float(f[k])))
+                    self._say("%s %d: \tuser=%16f,\t finite difference =%16f,\t error=%16f" % (kind, k, a[k], f[k], abs(a[k] - f[k])))
+        finally:
+            ea.close()
+            ef.close()
+        return bad
+
     def SolveOptimalProblem(self, nlp_solver=None, device=0, result_dir=None):
         if self.optpro_ is None:
             raise LpopcException("No optimal control problem has been set")
         solver = nlp_solver or ScipyNLPSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))
         self.meshrefiner_ = MeshRefiner(self.optionlist_)
+        if (self.optionlist_.GetStringValue("first-derive") == "analytic"
+                and self.optionlist_.GetStringValue("analytic-derive-check") == "yes"):
+            self._say("Checking user defined analytic derivatives against finite difference")
+            self.derive_check = self.CheckAnalyticDerive(device)
         while True:
             eng = NLPEngine(self.optpro_, self.optionlist_, device=device)     # GetSizes, GetBounds, GetGuess
             try:

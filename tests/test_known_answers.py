@@ -126,3 +126,24 @@ def test_application_loop_on_gpu_reaches_the_analytic_optimum(built, tmp_path):
     assert r["state"][:M].max() <= 1.0 / 9.0 + 1e-6
     if finished:
         assert (tmp_path / "state1").exists() and (tmp_path / "Hamiltonian1").exists()
+
+
+@pytest.mark.gpu
+def test_analytic_derive_check_option(built):
+    """analytic-derive-check=yes: the hypersensitive problem's analytic derivatives against forward differences at the
+    guess; a deliberately huge tolerance-perturbation makes the finite differences disagree grossly."""
+    from lpopc_amd.application import LpopcApplication, console_not_print
+    prob = problems.hypersensitive(np.linspace(-1, 1, 5).tolist(), [6] * 4, tf=30.0)
+    app = LpopcApplication(console_not_print)
+    app.SetOptimalControlProblem(prob)
+    app.Options().SetStringValue("first-derive", "analytic")
+    app.Options().SetStringValue("analytic-derive-check", "yes")
+    app.Options().SetNumericValue("analytic-derive-check-tol", 1e-5)
+    small = app.CheckAnalyticDerive()
+    # like the reference's checker the same number is perturbation and threshold, so curved functions are always reported:
+    # here by the forward-difference truncation error h f''/2 (times dt/2), nothing larger
+    assert all(abs(a - f) < 1e-2 for _, _, a, f in small)
+    app.Options().SetNumericValue("analytic-derive-check-tol", 1e-1)   # h ~ 0.1: forward differences of -x^3 are far off
+    bad = app.CheckAnalyticDerive()
+    assert bad and max(abs(a - f) for _, _, a, f in bad) > 1.0
+    assert all(k[0] in ("jacobian value", "objective gradient") for k in bad)
