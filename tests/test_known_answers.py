@@ -129,6 +129,31 @@ def test_application_loop_on_gpu_reaches_the_analytic_optimum(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_application_loop_with_hp_liu_refinement(built):
+    """The same loop with mesh-refine-methods=hp-Liu (LiuHpMeshRefineAlg behind rpm_hpliu_*): +3 nodes on the first
+    pass, divisions / reductions / merges afterwards; the objective stays at 4 / (9 l) and the loop ends like the
+    reference's (NoMoreRefine, the max-grid error, or the exception the reference would raise from its history look-ups)."""
+    from lpopc_amd.application import LpopcApplication, console_not_print
+    from lpopc_amd.engine import RpmError
+    from lpopc_amd.problem import LpopcException
+    prob = problems.bryson_denham(2, 8)
+    app = LpopcApplication(console_not_print)
+    app.SetOptimalControlProblem(prob)
+    app.Options().SetStringValue("mesh-refine-methods", "hp-Liu")
+    app.Options().SetNumericValue("desired-relative-error", 1e-6)
+    app.Options().SetIntegerValue("max-grid-num", 4)
+    app.Options().SetIntegerValue("Nmax", 12)
+    try:
+        app.SolveOptimalProblem()
+    except (LpopcException, RpmError):
+        pass
+    assert app.meshrefiner_.CurrentGrid() >= 1 and abs(app.objective - 4.0) < 1e-3
+    first, second = app.meshrefiner_.meshhistory[0][0], app.meshrefiner_.meshhistory[1][0]
+    assert first.nodesPerInterval == [8, 8]
+    assert all(n in (8, 11) or 2 <= n <= 8 for n in second.nodesPerInterval)   # +3 where unsatisfied, reduced where satisfied
+
+
+@pytest.mark.gpu
 def test_analytic_derive_check_option(built):
     """analytic-derive-check=yes: the hypersensitive problem's analytic derivatives against forward differences at the
     guess; a deliberately huge tolerance-perturbation makes the finite differences disagree grossly."""
