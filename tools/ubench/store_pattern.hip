@@ -20,6 +20,19 @@ __global__ __launch_bounds__(256) void k_pattern8(double* out, int N, int nblk, 
   double* p = out + size_t(inst) * inst_stride + tile * 64 + (threadIdx.x & 63);
   for (int b = threadIdx.x >> 6; b < nblk; b += 4) p[size_t(b) * N] = 1.0 + b;
 }
+__global__ __launch_bounds__(256) void k_pattern8_nt(double* out, int N, int nblk, size_t inst_stride) {
+  const int tiles = N / 64;
+  const int inst = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  double* p = out + size_t(inst) * inst_stride + tile * 64 + (threadIdx.x & 63);
+  for (int b = threadIdx.x >> 6; b < nblk; b += 4) __builtin_nontemporal_store(1.0 + b, p + size_t(b) * N);
+}
+__global__ __launch_bounds__(256) void k_linear16_nt(double2* out, size_t per_wg2) {
+  double* p = reinterpret_cast<double*>(out + size_t(blockIdx.x) * per_wg2);
+  for (size_t q = threadIdx.x; q < per_wg2; q += 256) {
+    __builtin_nontemporal_store(1.0 + q, p + 2 * q);
+    __builtin_nontemporal_store(2.0, p + 2 * q + 1);
+  }
+}
 __global__ __launch_bounds__(256) void k_pattern16(double2* out, int N, int nblk, size_t inst_stride) {
   const int tiles = N / 128;
   const int inst = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -45,6 +58,8 @@ float run(int mode, int lds_bytes, void** outs, int nbuf, int N, int nblk, int i
     if (mode == 0) hipLaunchKernelGGL(k_linear8, dim3(instances * (N / 64)), dim3(256), lds_bytes, st, static_cast<double*>(out), size_t(64) * nblk);
     if (mode == 2) hipLaunchKernelGGL(k_linear16, dim3(instances * (N / 64)), dim3(256), lds_bytes, st, static_cast<double2*>(out), size_t(32) * nblk);
     if (mode == 1) hipLaunchKernelGGL(k_pattern8, dim3(instances * (N / 64)), dim3(256), lds_bytes, st, static_cast<double*>(out), N, nblk, inst_stride);
+    if (mode == 4) hipLaunchKernelGGL(k_pattern8_nt, dim3(instances * (N / 64)), dim3(256), lds_bytes, st, static_cast<double*>(out), N, nblk, inst_stride);
+    if (mode == 5) hipLaunchKernelGGL(k_linear16_nt, dim3(instances * (N / 64)), dim3(256), lds_bytes, st, static_cast<double2*>(out), size_t(32) * nblk);
     if (mode == 3) hipLaunchKernelGGL(k_pattern16, dim3(instances * (N / 128)), dim3(256), lds_bytes, st, static_cast<double2*>(out), N, nblk, inst_stride);
   }
   (void)hipEventRecord(e1, st);
