@@ -63,8 +63,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--iterates", type=int, default=64,
-                    help="distinct NLP iterates resident in HBM (64 x 7.1 MB of outputs > the 256 MiB Infinity Cache)")
+    ap.add_argument("--iterates", type=int, default=256,
+                    help="distinct NLP iterates resident in HBM: 256 x 7.1 MB = 1.8 GB of outputs, of which the 0.77 GB written "
+                         "with ordinary (cacheable) stores alone are 3x the 256 MiB Infinity Cache; with 64 the Jacobian blocks "
+                         "of a cycle fit it and the kernel reads 13 %% faster than HBM allows")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--unfused", action="store_true", help="separate eval_g and eval_jac_g kernels per step")
     ap.add_argument("--shard", choices=["instances", "intervals"], default="instances")

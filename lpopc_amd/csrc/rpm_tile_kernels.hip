@@ -21,6 +21,7 @@
 
 namespace rpm {
 
+
 // ------------------------------------------------------------------------------------------
 // endpoint rows: events, linkages, linear rows.  Each work item (TaskDev) is one workgroup of the same
 // launch, so the three kinds run concurrently on different CUs.
@@ -808,7 +809,14 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
           const int q = (NDMA * ch + dw) * 128 + 2 * lane;   // 16 B per lane: 1 KB per store instruction
           if (q + 1 < c_cnt) {
 #pragma unroll
+            // non-temporal: this bulk stream (55 % of the bytes) is never read again and would otherwise push the
+            // Jacobian blocks' half-written lines out of L2 before their neighbours arrive (-14 % kernel time;
+            // non-temporal Jacobian stores, in contrast, lose that merging and cost +8 %)
+#ifdef RPM_EXP_NO_CNT
             for (int i = 0; i < NX; ++i) *reinterpret_cast<d2u*>(cdst + size_t(i) * c_stride + q) = cv[ch];
+#else
+            for (int i = 0; i < NX; ++i) __builtin_nontemporal_store(cv[ch], reinterpret_cast<d2u*>(cdst + size_t(i) * c_stride + q));
+#endif
           }
         }
         if ((c_cnt & 1) && dw == 0 && lane < NX) cdst[size_t(lane) * c_stride + c_cnt - 1] = ctail;
