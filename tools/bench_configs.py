@@ -76,7 +76,7 @@ def main():
         xl, xu, _, _ = one.get_bounds_info()
         x0 = one.get_starting_point()
         R = max(2 * B, 32)
-        while R * (one.nnz_jac + one.m) * 8 < 300e6 and R < 4096 * max(B, 1):
+        while R * (one.nnz_jac + one.m) * 8 < 1500e6 and R < 4096 * max(B, 1):   # outputs cycle through >= 1.5 GB: far past the 256 MiB Infinity Cache
             R *= 2
         R -= R % B
         xs = np.stack([problems.seeded_iterate(x0, xl, xu, 5 + r, mode) for r in range(min(R, 2048))])
