@@ -17,11 +17,11 @@ L.run.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c
 N, instances = 4096, 16
 nblk = 204   # ~ (852356 / 4096): 16 instances x 204 x 4096 x 8 B = 107 MB per launch
 stride = nblk * N + 8
-bufs = [torch.empty(instances * stride + 64, dtype=torch.float64, device="cuda") for _ in range(5)]
+bufs = [torch.empty(instances * stride + 64, dtype=torch.float64, device="cuda") for _ in range(16)]
 torch.cuda.synchronize()
 for mode, name in [(0, "linear 8B/lane"), (2, "linear 16B/lane"), (1, "pattern 512B runs"), (3, "pattern 1KB runs"), (4, "pattern 512B nontemporal"), (5, "linear nontemporal")]:
-    for nb, lds in ((1, 0), (5, 0), (5, 40 * 1024), (5, 80 * 1024), (5, 159 * 1024)):
+    for nb, lds in ((1, 0), (5, 0), (16, 0), (16, 80 * 1024)):
         ptrs = (C.c_void_p * nb)(*[b.data_ptr() for b in bufs[:nb]])
-        t = L.run(mode, lds, ptrs, nb, N, nblk, instances, stride, 40, None)
+        t = L.run(mode, lds, ptrs, nb, N, nblk, instances, stride, 64, None)
         print("%d buffer(s), %3d KB LDS/WG: " % (nb, lds // 1024), end="")
         print("%-20s %8.2f us  %7.1f GB/s" % (name, t, instances * nblk * N * 8 / t / 1e3))
