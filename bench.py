@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--dx-mode", type=int, default=0, help="0: scalar D.X in the reference's order, 1: FP64 MFMA tiles")
     ap.add_argument("--tile-nodes", type=int, default=0)
     ap.add_argument("--role-loop", type=int, default=-1, help="-1 auto, 0 one role per thread, 1 role-looped 64-node tiles")
+    ap.add_argument("--instance-align", type=int, default=16,
+                    help="doubles; start of every instance's g / values array inside a batch (1 = packed back to back)")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 role-looped kernel only, 1 force the pipelined kernel")
     ap.add_argument("--batch", type=int, default=16,
                     help="NLP iterates evaluated per launch (independent instances of the same problem)")
@@ -123,8 +125,14 @@ def main():
     seed0 = 3 if sharded else 3 + 1000 * rank
     xs = [problems.seeded_iterate(x0, xl, xu, seed0 + r) for r in range(R)]
     d_x = torch.from_numpy(np.stack(xs)).cuda()
-    d_g = torch.empty((R, eng.m), dtype=torch.float64, device="cuda")
-    d_v = torch.empty((R, eng.nnz_jac), dtype=torch.float64, device="cuda")
+    # every iterate's g / values array starts on a 128-byte boundary, as separately allocated arrays would: packed
+    # back to back (m and nnz_jac are not multiples of 8) three quarters of the store runs would straddle 64-byte
+    # granules, which costs the HBM write path a third of its rate (tools/ubench/store_pattern.py)
+    if not sharded:
+        eng.set_option("instance_align", args.instance_align)
+    sg, sv = eng.get_option("stride_g"), eng.get_option("stride_values")
+    d_g = torch.empty((R, sg), dtype=torch.float64, device="cuda")
+    d_v = torch.empty((R, sv), dtype=torch.float64, device="cuda")
     comm = None
     if sharded:
         from lpopc_amd.dist import IntervalGather
@@ -194,7 +202,7 @@ def main():
         for r in (0, R - 1):
             one.eval_pair_dev(d_x[r], chk_g, chk_v)
             torch.cuda.synchronize()
-            assert torch.equal(chk_g, d_g[r]) and torch.equal(chk_v, d_v[r]) and bool(torch.isfinite(chk_v).all())
+            assert torch.equal(chk_g, d_g[r, :eng.m]) and torch.equal(chk_v, d_v[r, :eng.nnz_jac]) and bool(torch.isfinite(chk_v).all())
         one.close()
 
     if rank == 0:

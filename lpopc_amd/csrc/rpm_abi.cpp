@@ -504,21 +504,21 @@ int rpm_eval_g_dev(rpm_engine* h, const double* d_x, double* d_g, void* stream) 
   if (!h) return RPM_E_INVALID;
   RPM_GUARD_BEGIN
   if (!d_x || !d_g) return fail(h->e, RPM_E_INVALID, "eval_g_dev: NULL pointer");
-  return rpm::dev_eval_cons(h->e, d_x, d_g, nullptr, 1, stream);
+  return rpm::dev_eval_cons(h->e, d_x, d_g, nullptr, 1 | 4, stream);
   RPM_GUARD_END(h->e)
 }
 int rpm_eval_jac_g_dev(rpm_engine* h, const double* d_x, double* d_values, void* stream) {
   if (!h) return RPM_E_INVALID;
   RPM_GUARD_BEGIN
   if (!d_x || !d_values) return fail(h->e, RPM_E_INVALID, "eval_jac_g_dev: NULL pointer");
-  return rpm::dev_eval_cons(h->e, d_x, nullptr, d_values, 2, stream);
+  return rpm::dev_eval_cons(h->e, d_x, nullptr, d_values, 2 | 4, stream);
   RPM_GUARD_END(h->e)
 }
 int rpm_eval_pair_dev(rpm_engine* h, const double* d_x, double* d_g, double* d_values, void* stream) {
   if (!h) return RPM_E_INVALID;
   RPM_GUARD_BEGIN
   if (!d_x || !d_g || !d_values) return fail(h->e, RPM_E_INVALID, "eval_pair_dev: NULL pointer");
-  return rpm::dev_eval_cons(h->e, d_x, d_g, d_values, 3, stream);
+  return rpm::dev_eval_cons(h->e, d_x, d_g, d_values, 3 | 4, stream);
   RPM_GUARD_END(h->e)
 }
 int rpm_eval_f_dev(rpm_engine* h, const double* d_x, double* d_obj, void* stream) {
@@ -570,6 +570,9 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
       e.role_looped = false;
       rpm::build_tiles(e, value);
     }
+  } else if (k == "instance_align") {
+    if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) return fail(e, RPM_E_INVALID, "instance_align must be 1, 2, 4, 8, 16 or 32 doubles");
+    e.opt_instance_align = value;
   } else if (k == "const_once") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "const_once must be 0 or 1");
     e.opt_const_once = value;
@@ -604,6 +607,9 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "role_loop") *value = e.role_looped ? 1 : 0;
   else if (k == "pipeline") *value = e.opt_pipeline;
   else if (k == "const_once") *value = e.opt_const_once;
+  else if (k == "instance_align") *value = e.opt_instance_align;
+  else if (k == "stride_g") *value = int(e.stride_g());
+  else if (k == "stride_values") *value = int(e.stride_values());
   else if (k == "pipeline_active") *value = rpm::dev_pipeline_active(e);
   else return fail(e, RPM_E_INVALID, "unknown option");
   return RPM_OK;

@@ -268,6 +268,8 @@ int device_init(Engine& e, int device_id) {
   k.nnz_const = e.nnz_const;
   k.max_span = e.max_span;
   k.max_drow = e.max_drow;
+  k.sg = e.m;
+  k.sv = e.nnz_jac;
   k.max_cshare = 0;
   for (const TileDev& t : e.tiles) k.max_cshare = t.c_cnt > k.max_cshare ? t.c_cnt : k.max_cshare;
   const bool sharded = e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1;

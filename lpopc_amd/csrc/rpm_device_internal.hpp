@@ -34,6 +34,7 @@ struct KParams {
   const double* alin_v;
   double tol;
   int P, L, n, m, m_nl, nnz, nnz_nl, nnz_lin, nnz_const;
+  long long sg, sv;                     // distance between the g / values arrays of consecutive instances (>= m, nnz)
   int max_span, max_drow;
   int max_cshare;                       // largest constant-block share of a tile (c_cnt)
   int diag_mask;                        // ablation mask, only honoured by the -DRPM_DIAG diagnostic build

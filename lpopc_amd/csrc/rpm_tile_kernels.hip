@@ -189,8 +189,8 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const double* __restrict__ x = xall + size_t(blockIdx.y) * K.n;
-  double* __restrict__ g = gall + size_t(blockIdx.y) * K.m;
-  double* __restrict__ vals = vall + size_t(blockIdx.y) * K.nnz;
+  double* __restrict__ g = gall + size_t(blockIdx.y) * K.sg;
+  double* __restrict__ vals = vall + size_t(blockIdx.y) * K.sv;
 #ifdef RPM_DIAG
   if (K.diag_mask & 32) return;
   if ((K.diag_mask & 1) && int(blockIdx.x) >= K.n_my_tiles) return;
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const double* __restrict__ x = xall + size_t(blockIdx.y) * K.n;
-  double* __restrict__ g = gall + size_t(blockIdx.y) * K.m;
-  double* __restrict__ vals = vall + size_t(blockIdx.y) * K.nnz;
+  double* __restrict__ g = gall + size_t(blockIdx.y) * K.sg;
+  double* __restrict__ vals = vall + size_t(blockIdx.y) * K.sv;
   RPM_TRC(0);
   if (int(blockIdx.x) >= K.n_my_tiles) {
     endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
@@ -795,31 +795,35 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
         const int inst = __builtin_amdgcn_readfirstlane(rec[NREC]);
         const int c_cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_cnt) / 4]);
         const int c_stride = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_stride) / 4]);
-        double* __restrict__ cdst = vall + size_t(inst) * K.nnz + c_dst0;
+        double* __restrict__ cdst = vall + size_t(inst) * K.sv + c_dst0;
+        // 16-byte stores that start on 64-byte boundaries of the destination: misaligned by 32 B the same stream
+        // reaches 3.6 instead of 5.4 TB/s (tools/ubench/store_pattern.py).  `head` elements bring the first copy to a
+        // boundary (the others follow when c_stride is a multiple of 8, e.g. on uniform meshes); they and an odd last
+        // element go out as single stores.
+        const int head = min(int((8 - ((reinterpret_cast<size_t>(cdst) >> 3) & 7)) & 7), c_cnt);
         d2u cv[CCH];
 #pragma unroll
         for (int ch = 0; ch < CCH; ++ch) {
-          const int q = min((NDMA * ch + dw) * 128 + 2 * lane, c_cnt - 2);
+          const int q = max(min(head + (NDMA * ch + dw) * 128 + 2 * lane, c_cnt - 2), 0);
           cv[ch].x = cur[S_CV + q];
           cv[ch].y = cur[S_CV + q + 1];
         }
-        const double ctail = cur[S_CV + c_cnt - 1];
+        const bool odd_tail = ((c_cnt - head) & 1) != 0;
+        const int edge = lane < head ? lane : (lane == head && odd_tail ? c_cnt - 1 : -1);   // lanes 0..head: the leftovers
+        const double cedge = cur[S_CV + max(edge, 0)];
 #pragma unroll
         for (int ch = 0; ch < CCH; ++ch) {
-          const int q = (NDMA * ch + dw) * 128 + 2 * lane;   // 16 B per lane: 1 KB per store instruction
+          const int q = head + (NDMA * ch + dw) * 128 + 2 * lane;   // 16 B per lane: 1 KB per store instruction
           if (q + 1 < c_cnt) {
 #pragma unroll
-            // non-temporal: this bulk stream (55 % of the bytes) is never read again and would otherwise push the
-            // Jacobian blocks' half-written lines out of L2 before their neighbours arrive (-14 % kernel time;
-            // non-temporal Jacobian stores, in contrast, lose that merging and cost +8 %)
-#ifdef RPM_EXP_NO_CNT
-            for (int i = 0; i < NX; ++i) *reinterpret_cast<d2u*>(cdst + size_t(i) * c_stride + q) = cv[ch];
-#else
+            // non-temporal: this bulk stream (55 % of the bytes) is never read again
             for (int i = 0; i < NX; ++i) __builtin_nontemporal_store(cv[ch], reinterpret_cast<d2u*>(cdst + size_t(i) * c_stride + q));
-#endif
           }
         }
-        if ((c_cnt & 1) && dw == 0 && lane < NX) cdst[size_t(lane) * c_stride + c_cnt - 1] = ctail;
+        if (dw == 0 && edge >= 0) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) cdst[size_t(i) * c_stride + edge] = cedge;
+        }
       }
       RPM_PTRC(j, 17);
       if (j + 1 < n_iter) stage(w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
     for (int it = NDMA * w + dw; it < n_end; it += NDMA * G) {
       const int inst = it / K.n_tasks;
       endpoint_block<Prob, WG, WJ, AN, true>(K, K.tasks[it - inst * K.n_tasks], xall + size_t(inst) * K.n,
-                                             gall + size_t(inst) * K.m, vall + size_t(inst) * K.nnz, nullptr);
+                                             gall + size_t(inst) * K.sg, vall + size_t(inst) * K.sv, nullptr);
     }
     return;
   }
@@ -861,8 +865,8 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
     const int g0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, g0) / 4]);
     const int v_nl0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, v_nl0) / 4]);
     const int inst = __builtin_amdgcn_readfirstlane(rec[NREC]);
-    double* __restrict__ g = gall + size_t(inst) * K.m;
-    double* __restrict__ vals = vall + size_t(inst) * K.nnz;
+    double* __restrict__ g = gall + size_t(inst) * K.sg;
+    double* __restrict__ vals = vall + size_t(inst) * K.sv;
     const double* Xs = cur + S_X;
     const double* Us = cur + S_U;
     const double* Ds = cur + S_D;
@@ -1039,7 +1043,7 @@ void tile_pipeline_setup(Engine& e, Device* d, const ProblemDims& pd, int device
 
 // ------------------------------------------------------------------------------------------
 template <class Prob, int T, bool WG, bool WJ, bool AN, bool DXM = false>
-static hipError_t launch_tile_inst(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
+static hipError_t launch_tile_inst(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
   constexpr int R = WJ ? Prob::NX + Prob::NU + 2 : (Prob::NX > 0 ? Prob::NX : 1);
   int threads = T * R;
   threads = (threads + 63) / 64 * 64;
@@ -1052,12 +1056,12 @@ static hipError_t launch_tile_inst(const Engine& e, const double* dx, double* dg
     if (s != hipSuccess) return s;
   }
   dim3 grid(unsigned(d.kp.n_my_tiles + d.kp.n_tasks), unsigned(e.n_instances));
-  hipLaunchKernelGGL(kern, grid, dim3(threads), d.lds_bytes, st, d.kp, dx, dg, dv);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), d.lds_bytes, st, kp, dx, dg, dv);
   return hipGetLastError();
 }
 
 template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
-static hipError_t launch_tile_rl(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
+static hipError_t launch_tile_rl(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
   const Device& d = *e.dev;
   auto kern = rpm_tile_rl_kernel<Prob, T, RG, WG, WJ, AN>;
   if (d.lds_bytes > 64 * 1024) {
@@ -1066,12 +1070,12 @@ static hipError_t launch_tile_rl(const Engine& e, const double* dx, double* dg, 
     if (s != hipSuccess) return s;
   }
   dim3 grid(unsigned(d.kp.n_my_tiles + d.kp.n_tasks), unsigned(e.n_instances));
-  hipLaunchKernelGGL(kern, grid, dim3(T * RG), d.lds_bytes, st, d.kp, dx, dg, dv);
+  hipLaunchKernelGGL(kern, grid, dim3(T * RG), d.lds_bytes, st, kp, dx, dg, dv);
   return hipGetLastError();
 }
 
 template <class Prob, bool WG, bool WJ, bool AN>
-static hipError_t launch_tile_pl(const Engine& e, const double* dx, double* dg, double* dv, hipStream_t st) {
+static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
   const Device& d = *e.dev;
   constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2);
   auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN>;
@@ -1082,7 +1086,7 @@ static hipError_t launch_tile_pl(const Engine& e, const double* dx, double* dg, 
   }
   const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
   const long long halves = W < d.pl_slots ? W : d.pl_slots;   // pl_slots: resident halves (occupancy query)
-  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA)), d.pl_lds, st, d.kp,
+  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA)), d.pl_lds, st, kp,
                      e.n_instances, dx, dg, dv);
   return hipGetLastError();
 }
@@ -1102,46 +1106,46 @@ static bool use_pipeline(const Engine& e) {
 int dev_pipeline_active(const Engine& e) { return e.dev && e.role_looped && e.opt_dx_mode == 0 && use_pipeline(e) ? 1 : 0; }
 
 template <class Prob, int T>
-static hipError_t launch_tile_T(const Engine& e, bool wg, bool wj, const double* dx, double* dg, double* dv,
-                                hipStream_t st) {
+static hipError_t launch_tile_T(const Engine& e, const KParams& kp, bool wg, bool wj, const double* dx, double* dg,
+                                double* dv, hipStream_t st) {
   if (e.role_looped && T == 64 && e.opt_dx_mode == 0 && use_pipeline(e)) {
     const bool an_pl = e.first_derive == RPM_DERIVE_ANALYTIC;
     if constexpr (Prob::HAS_ANALYTIC) {
       if (an_pl) {
-        if (wg && wj) return launch_tile_pl<Prob, true, true, true>(e, dx, dg, dv, st);
-        if (wj) return launch_tile_pl<Prob, false, true, true>(e, dx, dg, dv, st);
+        if (wg && wj) return launch_tile_pl<Prob, true, true, true>(e, kp, dx, dg, dv, st);
+        if (wj) return launch_tile_pl<Prob, false, true, true>(e, kp, dx, dg, dv, st);
       }
     }
-    if (wg && wj) return launch_tile_pl<Prob, true, true, false>(e, dx, dg, dv, st);
-    if (wj) return launch_tile_pl<Prob, false, true, false>(e, dx, dg, dv, st);
-    return launch_tile_pl<Prob, true, false, false>(e, dx, dg, dv, st);
+    if (wg && wj) return launch_tile_pl<Prob, true, true, false>(e, kp, dx, dg, dv, st);
+    if (wj) return launch_tile_pl<Prob, false, true, false>(e, kp, dx, dg, dv, st);
+    return launch_tile_pl<Prob, true, false, false>(e, kp, dx, dg, dv, st);
   }
   if (e.role_looped && T == 64 && e.opt_dx_mode == 0) {   // throughput layout (see rpm_tile_rl_kernel)
     const bool an_rl = e.first_derive == RPM_DERIVE_ANALYTIC;
     if constexpr (Prob::HAS_ANALYTIC) {
       if (an_rl) {
-        if (wg && wj) return launch_tile_rl<Prob, 64, 4, true, true, true>(e, dx, dg, dv, st);
-        if (wj) return launch_tile_rl<Prob, 64, 4, false, true, true>(e, dx, dg, dv, st);
+        if (wg && wj) return launch_tile_rl<Prob, 64, 4, true, true, true>(e, kp, dx, dg, dv, st);
+        if (wj) return launch_tile_rl<Prob, 64, 4, false, true, true>(e, kp, dx, dg, dv, st);
       }
     }
-    if (wg && wj) return launch_tile_rl<Prob, 64, 4, true, true, false>(e, dx, dg, dv, st);
-    if (wj) return launch_tile_rl<Prob, 64, 4, false, true, false>(e, dx, dg, dv, st);
-    return launch_tile_rl<Prob, 64, 4, true, false, false>(e, dx, dg, dv, st);
+    if (wg && wj) return launch_tile_rl<Prob, 64, 4, true, true, false>(e, kp, dx, dg, dv, st);
+    if (wj) return launch_tile_rl<Prob, 64, 4, false, true, false>(e, kp, dx, dg, dv, st);
+    return launch_tile_rl<Prob, 64, 4, true, false, false>(e, kp, dx, dg, dv, st);
   }
   const bool an = e.first_derive == RPM_DERIVE_ANALYTIC;
   if constexpr (Prob::HAS_ANALYTIC) {
     if (an) {
-      if (wg && wj) return launch_tile_inst<Prob, T, true, true, true>(e, dx, dg, dv, st);
-      if (wj) return launch_tile_inst<Prob, T, false, true, true>(e, dx, dg, dv, st);
+      if (wg && wj) return launch_tile_inst<Prob, T, true, true, true>(e, kp, dx, dg, dv, st);
+      if (wj) return launch_tile_inst<Prob, T, false, true, true>(e, kp, dx, dg, dv, st);
     }
   }
   if (e.opt_dx_mode == 1) {   // MFMA D.X (finite-difference derivative mode)
-    if (wg && wj) return launch_tile_inst<Prob, T, true, true, false, true>(e, dx, dg, dv, st);
-    if (wg) return launch_tile_inst<Prob, T, true, false, false, true>(e, dx, dg, dv, st);
+    if (wg && wj) return launch_tile_inst<Prob, T, true, true, false, true>(e, kp, dx, dg, dv, st);
+    if (wg) return launch_tile_inst<Prob, T, true, false, false, true>(e, kp, dx, dg, dv, st);
   }
-  if (wg && wj) return launch_tile_inst<Prob, T, true, true, false>(e, dx, dg, dv, st);
-  if (wj) return launch_tile_inst<Prob, T, false, true, false>(e, dx, dg, dv, st);
-  return launch_tile_inst<Prob, T, true, false, false>(e, dx, dg, dv, st);
+  if (wg && wj) return launch_tile_inst<Prob, T, true, true, false>(e, kp, dx, dg, dv, st);
+  if (wj) return launch_tile_inst<Prob, T, false, true, false>(e, kp, dx, dg, dv, st);
+  return launch_tile_inst<Prob, T, true, false, false>(e, kp, dx, dg, dv, st);
 }
 
 // flags: bit0 = g, bit1 = jacobian values
@@ -1152,13 +1156,18 @@ int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, i
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool wg = flags & 1, wj = flags & 2;
+  // flags bit 2: the caller's g / values arrays use the padded instance strides (device-resident entry points with option
+  // "instance_align"); the host-pointer path keeps its staging buffers dense
+  KParams kp = e.dev->kp;
+  kp.sg = (flags & 4) ? e.stride_g() : e.m;
+  kp.sv = (flags & 4) ? e.stride_values() : e.nnz_jac;
   hipError_t s = hipErrorInvalidValue;
   with_problem(e.problem_id, [&](auto prob) {
     using P = decltype(prob);
     switch (e.tile_nodes) {
-      case 64: s = launch_tile_T<P, 64>(e, wg, wj, d_x, d_g, d_values, st); break;
-      case 32: s = launch_tile_T<P, 32>(e, wg, wj, d_x, d_g, d_values, st); break;
-      default: s = launch_tile_T<P, 16>(e, wg, wj, d_x, d_g, d_values, st); break;
+      case 64: s = launch_tile_T<P, 64>(e, kp, wg, wj, d_x, d_g, d_values, st); break;
+      case 32: s = launch_tile_T<P, 32>(e, kp, wg, wj, d_x, d_g, d_values, st); break;
+      default: s = launch_tile_T<P, 16>(e, kp, wg, wj, d_x, d_g, d_values, st); break;
     }
   });
   if (s != hipSuccess) {

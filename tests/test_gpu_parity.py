@@ -516,3 +516,43 @@ def test_const_once_downloads_only_the_changing_prefix(built):
     eng.close()
     full.close()
 
+
+def test_padded_instance_strides(built):
+    """Option instance_align: in the device-resident batched calls every instance's g / values array starts on a
+    multiple of that many doubles (rpm_get_option stride_g / stride_values); the numbers are those of the packed layout,
+    the padding words are never written, with the pipelined, the role-looped and the one-role kernel."""
+    import torch
+    prob = problems.launch(3, 6)
+    for role_loop, pipeline, B in ((0, 0, 5), (1, 0, 9), (1, 1, 11)):
+        dense = NLPEngine(prob, n_instances=B, device=0, role_loop=role_loop)
+        pad = NLPEngine(prob, n_instances=B, device=0, role_loop=role_loop)
+        for e_ in (dense, pad):
+            e_.set_option("pipeline", pipeline)
+        pad.set_option("instance_align", 16)
+        sg, sv = pad.get_option("stride_g"), pad.get_option("stride_values")
+        assert sg % 16 == 0 and sv % 16 == 0 and sg >= pad.m and sv >= pad.nnz_jac and sg - pad.m < 16
+        assert dense.get_option("stride_values") == dense.nnz_jac
+        xl, xu, _, _ = dense.get_bounds_info()
+        one = NLPEngine(prob, device=0)
+        xs = np.stack([problems.seeded_iterate(one.get_starting_point(), xl, xu, 60 + i) for i in range(B)])
+        one.close()
+        dx = torch.from_numpy(xs).cuda()
+        g0 = torch.empty((B, dense.m), dtype=torch.float64, device="cuda")
+        v0 = torch.empty((B, dense.nnz_jac), dtype=torch.float64, device="cuda")
+        g1 = torch.full((B, sg), 3.5, dtype=torch.float64, device="cuda")
+        v1 = torch.full((B, sv), 3.5, dtype=torch.float64, device="cuda")
+        dense.eval_pair_dev(dx, g0, v0)
+        pad.eval_pair_dev(dx, g1, v1)
+        torch.cuda.synchronize()
+        assert pad.get_option("pipeline_active") == pipeline
+        assert torch.equal(g1[:, :pad.m], g0) and torch.equal(v1[:, :pad.nnz_jac], v0)
+        assert bool((g1[:, pad.m:] == 3.5).all()) and bool((v1[:, pad.nnz_jac:] == 3.5).all())
+        g2 = torch.full((B, sg), 3.5, dtype=torch.float64, device="cuda")
+        v2 = torch.full((B, sv), 3.5, dtype=torch.float64, device="cuda")
+        pad.eval_g_dev(dx, g2)
+        pad.eval_jac_g_dev(dx, v2)
+        torch.cuda.synchronize()
+        assert torch.equal(g2, g1) and torch.equal(v2, v1)
+        dense.close()
+        pad.close()
+

@@ -25,3 +25,12 @@ for mode, name in [(0, "linear 8B/lane"), (2, "linear 16B/lane"), (1, "pattern 5
         t = L.run(mode, lds, ptrs, nb, N, nblk, instances, stride, 64, None)
         print("%d buffer(s), %3d KB LDS/WG: " % (nb, lds // 1024), end="")
         print("%-20s %8.2f us  %7.1f GB/s" % (name, t, instances * nblk * N * 8 / t / 1e3))
+
+# alignment of the instance stride: every 512-byte run starts (stride * 8 * inst) bytes into a 128-byte line
+print("pattern 512B runs, 16 buffers, instance stride = nblk*N + pad doubles:")
+for pad in (0, 16, 8, 4, 1):
+    st = nblk * N + pad
+    ptrs = (C.c_void_p * 16)(*[b.data_ptr() for b in bufs])
+    t = L.run(1, 0, ptrs, 16, N, nblk, instances, st, 64, None)
+    print("  pad %2d doubles (%3d B): %8.2f us  %7.1f GB/s" % (pad, (pad * 8) % 128, t, instances * nblk * N * 8 / t / 1e3))
+
