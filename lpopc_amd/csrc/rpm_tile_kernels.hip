@@ -610,10 +610,16 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
     // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718)
     const double* __restrict__ src = K.doff_vals + tl.c_src0;
     double* __restrict__ dst = vals + tl.c_dst0;
-    for (int q = tid; q < tl.c_cnt; q += NTHR) {
-      const double dv = src[q];
+    // lane 0 of every wave lands on a 128-byte line of the destination (a run that straddles lines costs the HBM write
+    // path a third of its rate, tools/ubench/store_pattern.py): the index range is shifted down by the distance of
+    // dst from the line boundary below it
+    const int lead = int((reinterpret_cast<size_t>(dst) >> 3) & 15);
+    for (int q = tid - lead; q < tl.c_cnt; q += NTHR) {
+      if (q >= 0) {
+        const double dv = src[q];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = dv;
+        for (int i = 0; i < NX; ++i) dst[size_t(i) * tl.c_stride + q] = dv;
+      }
     }
   }
 #ifdef RPM_DIAG
@@ -796,11 +802,11 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
         const int c_cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_cnt) / 4]);
         const int c_stride = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, c_stride) / 4]);
         double* __restrict__ cdst = vall + size_t(inst) * K.sv + c_dst0;
-        // 16-byte stores that start on 64-byte boundaries of the destination: misaligned by 32 B the same stream
-        // reaches 3.6 instead of 5.4 TB/s (tools/ubench/store_pattern.py).  `head` elements bring the first copy to a
-        // boundary (the others follow when c_stride is a multiple of 8, e.g. on uniform meshes); they and an odd last
-        // element go out as single stores.
-        const int head = min(int((8 - ((reinterpret_cast<size_t>(cdst) >> 3) & 7)) & 7), c_cnt);
+        // 16-byte stores that start on 128-byte lines of the destination: misaligned by 32 B the same stream reaches
+        // 3.6 instead of 5.4 TB/s, by 64 B 5.1 (tools/ubench/store_pattern.py).  `head` elements bring the first copy to
+        // a line boundary (the others follow when c_stride is a multiple of 16, e.g. on uniform meshes); they and an odd
+        // last element go out as single stores.
+        const int head = min(int((16 - ((reinterpret_cast<size_t>(cdst) >> 3) & 15)) & 15), c_cnt);   // to a 128-byte line
         d2u cv[CCH];
 #pragma unroll
         for (int ch = 0; ch < CCH; ++ch) {
