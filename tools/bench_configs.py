@@ -24,8 +24,9 @@ def rel(a, b):
 def gpu_rate(eng, xs, B, steps=300):
     R = xs.shape[0]
     d_x = torch.from_numpy(xs).cuda()
-    d_g = torch.empty((R, eng.m), dtype=torch.float64, device="cuda")
-    d_v = torch.empty((R, eng.nnz_jac), dtype=torch.float64, device="cuda")
+    eng.set_option("instance_align", 16)   # every iterate's g / values array on a 128-byte line, like separate allocations
+    d_g = torch.empty((R, eng.get_option("stride_g")), dtype=torch.float64, device="cuda")
+    d_v = torch.empty((R, eng.get_option("stride_values")), dtype=torch.float64, device="cuda")
 
     def step(k):
         r = (k * B) % R
