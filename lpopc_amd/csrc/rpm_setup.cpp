@@ -198,8 +198,15 @@ void build_tiles(Engine& e, int T) {
     int k = 0, s = 0, used = 0;  // node cursor, interval cursor, nodes of interval s already tiled
     while (k < p.N) {
       int cnt = 0;
-      // whole intervals while they fit
-      while (s < p.K && used == 0 && cnt + p.nk[s] <= T) {
+      if (e.role_looped) {
+        // throughput layouts: tiles are nodes [T t, T t + T) whatever the interval boundaries (a tile's D rows and X span
+        // simply cover the intervals it touches).  Every wave is full, and the 8 T-byte store runs of the Jacobian
+        // blocks start on 128-byte lines of each block — a run that straddles lines costs the HBM write path a third of
+        // its rate (tools/ubench/store_pattern.py).
+        cnt = p.N - k < T ? p.N - k : T;
+      }
+      // one-role layout: whole intervals while they fit
+      while (!e.role_looped && s < p.K && used == 0 && cnt + p.nk[s] <= T) {
         cnt += p.nk[s];
         ++s;
       }
@@ -236,7 +243,9 @@ void build_tiles(Engine& e, int T) {
     const PhaseDev& q = e.phd[ip];
     for (int t = 0; t < q.ntiles; ++t) {
       TileDev& tl = e.tiles[q.tile0 + t];
-      const int q0 = int((long long)t * q.off_nnz / q.ntiles), q1 = int((long long)(t + 1) * q.off_nnz / q.ntiles);
+      // equal shares, cut at multiples of 16 entries so that every share starts on the same offset within a 128-byte line
+      auto cut = [&](int tt) { return tt >= q.ntiles ? q.off_nnz : int(((long long)tt * q.off_nnz / q.ntiles) & ~15LL); };
+      const int q0 = cut(t), q1 = cut(t + 1);
       tl.c_src0 = q.doff_base + q0;
       tl.c_cnt = q1 - q0;
       tl.c_dst0 = e.nnz_nl + e.nnz_lin + q.const_cum + q0;
