@@ -211,6 +211,42 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
                      double* new_mesh_points, int* new_nodes_per_interval, int* mesh_off, int* nodes_off,
                      int* new_n_intervals, int* no_more_refine);
 
+/* ---- row f-2: the NLP solve itself, batched and device-resident ---------------------------------------------------
+ * The reference hands the TNLP to Ipopt 3.12.3 (NLPSolver::SolveNlp, Core/LpNLPSolver.cpp:13-53: "tol" from the
+ * Ipopt-tol option, hessian_approximation from the option list; Ipopt is a third-party dependency that is not in the
+ * reference tree).  rpm_ipm restates Ipopt's published algorithm (Waechter & Biegler 2006: primal-dual barrier,
+ * fraction-to-the-boundary rule, filter line search, inertia correction; monotone barrier update; no restoration phase,
+ * no second-order correction, no scaling) for the engine's n_instances independent NLPs at once — the MPC sweep —
+ * with iterates, multipliers, the band + border KKT matrices and their LDL^T factors resident in HBM; per iteration
+ * only three counters cross PCIe.  The engine must be created with hessian_approximation = exact; set the engine's
+ * "instance_align" before rpm_ipm_create.
+ *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
+ *                       "delta_c" (1e-8, constraint regularisation that makes the pivot-free LDL^T well defined),
+ *                       "max_line_search" (40)
+ *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
+ *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
+ *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,
+ *                       status (0 converged, 2 iteration limit, 3 line search failed where Ipopt would enter
+ *                       restoration, 4 inertia correction failed, 5 NaN/Inf), iteration count, scaled KKT error
+ *   rpm_ipm_get_info:   order of the KKT system, of its banded part, half bandwidth, border size, doubles of storage per
+ *                       instance, number of slack variables (one per inequality row) */
+typedef struct rpm_ipm rpm_ipm;
+int rpm_ipm_create(rpm_engine* e, rpm_ipm** out);
+void rpm_ipm_destroy(rpm_ipm* s);
+const char* rpm_ipm_last_error(const rpm_ipm* s);
+int rpm_ipm_set_option(rpm_ipm* s, const char* key, double value);
+int rpm_ipm_set_bounds(rpm_ipm* s, int instance, const double* x_l, const double* x_u);
+int rpm_ipm_get_info(rpm_ipm* s, int* kkt_order, int* band_order, int* half_bandwidth, int* border,
+                     long long* storage_doubles, int* n_slacks);
+int rpm_ipm_get_stats(rpm_ipm* s, int* iterations, int* factorizations, int* trial_points);
+int rpm_ipm_solve(rpm_ipm* s, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error);
+int rpm_ipm_solve_dev(rpm_ipm* s, double* d_x, double* d_lambda, double* obj, int* status, int* iterations,
+                      double* kkt_error);
+/* test hooks: KKT position of every unknown ([0,n) variables, slacks, then the m multipliers); factor + solve the
+ * caller's matrices given in the band + border storage (host pointers, n_instances of each) */
+int rpm_ipm_get_permutation(rpm_ipm* s, int* pos, int capacity);
+int rpm_ipm_debug_solve(rpm_ipm* s, const double* k_storage, const double* rhs, double* sol, int* n_pos, int* n_neg);
+
 /* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
  *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
  *      engine's device; `stream` is a hipStream_t with HIP's own meaning (NULL = the legacy

@@ -30,6 +30,8 @@ ABI_SYMBOLS = [
     "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
+    "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_get_info",
+    "rpm_ipm_get_stats", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
 ]
 
 
@@ -95,6 +97,19 @@ def lib():
     L.rpm_hpliu_last_error.argtypes = [vp]
     L.rpm_hpliu_last_error.restype = C.c_char_p
     L.rpm_hpliu_refine.argtypes = [vp, vp, dp, dp, C.c_int, dp, ip, ip, ip, ip, ip]
+    L.rpm_ipm_create.argtypes = [vp, C.POINTER(vp)]
+    L.rpm_ipm_destroy.argtypes = [vp]
+    L.rpm_ipm_destroy.restype = None
+    L.rpm_ipm_last_error.argtypes = [vp]
+    L.rpm_ipm_last_error.restype = C.c_char_p
+    L.rpm_ipm_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.rpm_ipm_set_bounds.argtypes = [vp, C.c_int, dp, dp]
+    L.rpm_ipm_get_info.argtypes = [vp, ip, ip, ip, ip, C.POINTER(C.c_longlong), ip]
+    L.rpm_ipm_get_stats.argtypes = [vp, ip, ip, ip]
+    L.rpm_ipm_solve.argtypes = [vp, dp, dp, dp, ip, ip, dp]
+    L.rpm_ipm_solve_dev.argtypes = [vp, vp, vp, dp, ip, ip, dp]
+    L.rpm_ipm_get_permutation.argtypes = [vp, ip, C.c_int]
+    L.rpm_ipm_debug_solve.argtypes = [vp, dp, dp, dp, ip, ip]
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
     L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -395,3 +410,88 @@ class HpLiuRefiner:
         return bool(done.value), [(mesh[moff[p]:moff[p] + nk[p] + 1].copy(), nodes[noff[p]:noff[p] + nk[p]].copy())
                                   for p in range(self.P)]
 
+
+
+class BatchedIPM:
+    """rpm_ipm_* : the NLP solve (the reference's NLPSolver::SolveNlp -> Ipopt, Core/LpNLPSolver.cpp:13-53) for all of an
+    engine's instances at once, iterates and KKT factors resident on the device.  The engine must have been created
+    with hessian-approximation=exact."""
+
+    STATUS = {0: "converged", 2: "iteration limit", 3: "line search failed (restoration needed)",
+              4: "inertia correction failed", 5: "NaN/Inf"}
+
+    def __init__(self, engine, **options):
+        self._L = lib()
+        self._e = engine
+        self._h = C.c_void_p()
+        rc = self._L.rpm_ipm_create(engine._h, C.byref(self._h))
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_last_error(engine._h).decode())
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rpm_ipm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_ipm_last_error(self._h).decode())
+
+    def set_option(self, key, value):
+        self._chk(self._L.rpm_ipm_set_option(self._h, key.encode(), float(value)))
+
+    def set_bounds(self, instance, x_l, x_u):
+        x_l, x_u = np.ascontiguousarray(x_l, dtype=np.float64), np.ascontiguousarray(x_u, dtype=np.float64)
+        assert x_l.size == self._e.n and x_u.size == self._e.n
+        self._chk(self._L.rpm_ipm_set_bounds(self._h, int(instance), _dp(x_l), _dp(x_u)))
+
+    def info(self):
+        a = [C.c_int() for _ in range(4)]
+        st, ns = C.c_longlong(), C.c_int()
+        self._chk(self._L.rpm_ipm_get_info(self._h, C.byref(a[0]), C.byref(a[1]), C.byref(a[2]), C.byref(a[3]), C.byref(st), C.byref(ns)))
+        return {"kkt_order": a[0].value, "band_order": a[1].value, "half_bandwidth": a[2].value, "border": a[3].value,
+                "storage_doubles": st.value, "n_slacks": ns.value}
+
+    def stats(self):
+        a = [C.c_int() for _ in range(3)]
+        self._chk(self._L.rpm_ipm_get_stats(self._h, C.byref(a[0]), C.byref(a[1]), C.byref(a[2])))
+        return {"iterations": a[0].value, "factorizations": a[1].value, "trial_points": a[2].value}
+
+    def permutation(self):
+        nt = self.info()["kkt_order"]
+        pos = np.zeros(nt, dtype=np.int32)
+        self._chk(self._L.rpm_ipm_get_permutation(self._h, _ip(pos), nt))
+        return pos
+
+    def debug_solve(self, k_storage, rhs):
+        B, nt = self._e.n_instances, self.info()["kkt_order"]
+        k = np.ascontiguousarray(k_storage, dtype=np.float64)
+        r = np.ascontiguousarray(rhs, dtype=np.float64)
+        assert k.size == B * self.info()["storage_doubles"] and r.size == B * nt
+        sol = np.zeros((B, nt))
+        npos, nneg = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(self._L.rpm_ipm_debug_solve(self._h, _dp(k), _dp(r), _dp(sol), _ip(npos), _ip(nneg)))
+        return sol, npos, nneg
+
+    def solve(self, x0):
+        """x0: (n_instances, n) starting points -> dict(x, lambda, obj, status, iterations, kkt_error)."""
+        B, n, m = self._e.n_instances, self._e.n, self._e.m
+        x = np.array(x0, dtype=np.float64, order="C").reshape(B, n)
+        lam = np.zeros((B, max(m, 1)))[:, :m].copy()
+        obj, err = np.zeros(B), np.zeros(B)
+        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(self._L.rpm_ipm_solve(self._h, _dp(x), _dp(lam), _dp(obj), _ip(status), _ip(iters), _dp(err)))
+        return {"x": x, "lambda": lam, "obj": obj, "status": status, "iterations": iters, "kkt_error": err}
+
+    def solve_dev(self, d_x, d_lambda=None):
+        """d_x: torch CUDA tensor (n_instances, n), overwritten with the solutions; d_lambda: optional (n_instances, m)."""
+        B = self._e.n_instances
+        obj, err = np.zeros(B), np.zeros(B)
+        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        lp = C.c_void_p(d_lambda.data_ptr()) if d_lambda is not None else None
+        self._chk(self._L.rpm_ipm_solve_dev(self._h, C.c_void_p(d_x.data_ptr()), lp, _dp(obj), _ip(status), _ip(iters), _dp(err)))
+        return {"obj": obj, "status": status, "iterations": iters, "kkt_error": err}
