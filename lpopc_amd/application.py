@@ -10,7 +10,8 @@ SolveOptimalProblem) and the outer loop of `LpopcAlgorithm::Optimization` (Core/
 `GetSizes/GetBounds/GetGuess` are what `rpm_create` does per mesh; `Nlp2OpControl`, the error estimate and the
 refinement decision are the post-solve entry points of the C ABI.  The NLP solver itself is NOT part of the reference's
 sources (it hands an `Ipopt::TNLP` to Ipopt 3.12.3, Core/LpNLPSolver.cpp:13-53) and Ipopt is not in this image:
-`ScipyNLPSolver` drives the same callbacks with scipy's trust-constr instead.  It is a stand-in for small problems (tests,
+`DeviceIPMSolver` (hessian-approximation=exact) runs a restatement of Ipopt's published algorithm on the device
+(rpm_ipm_*, row f-2); `ScipyNLPSolver` drives the same callbacks with scipy's trust-constr instead.  It is a stand-in for small problems (tests,
 demos), not a replacement for Ipopt; in particular its constraint multipliers are not of Ipopt's quality, so costates and
 Hamiltonian extracted from them are indicative only.
 """
@@ -63,6 +64,27 @@ class ScipyNLPSolver:
         return res.status in (1, 2) or res.constr_violation <= 1e-5
 
 
+class DeviceIPMSolver:
+    """NLPSolver::SolveNlp (Core/LpNLPSolver.cpp:13-53) on the device: rpm_ipm_* restates the interior-point algorithm of
+    the Ipopt the reference calls (see include/rpm_hip.h, row f-2), with "tol" = the Ipopt-tol option exactly as the
+    reference passes it.  Needs hessian-approximation=exact (eval_h).  Its multipliers are the NLP's (lambda of the
+    primal-dual system), so costates and the Hamiltonian extracted from them are meaningful."""
+
+    def __init__(self, tol=1e-6, maxiter=3000):
+        self.tol, self.maxiter = float(tol), int(maxiter)
+
+    def SolveNlp(self, nlp):
+        from .engine import BatchedIPM
+        ipm = BatchedIPM(nlp, tol=self.tol, max_iter=self.maxiter)
+        try:
+            r = ipm.solve(nlp.get_starting_point())
+            self.last = dict(r, stats=ipm.stats(), info=ipm.info())
+        finally:
+            ipm.close()
+        nlp.finalize_solution(int(r["status"][0]), r["x"][0], r["lambda"][0], float(r["obj"][0]))
+        return int(r["status"][0]) == 0
+
+
 class LpopcApplication:
     def __init__(self, if_console_print=console_print):
         self.print_ = if_console_print
@@ -112,7 +134,12 @@ class LpopcApplication:
     def SolveOptimalProblem(self, nlp_solver=None, device=0, result_dir=None):
         if self.optpro_ is None:
             raise LpopcException("No optimal control problem has been set")
-        solver = nlp_solver or ScipyNLPSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))
+        if nlp_solver is not None:
+            solver = nlp_solver
+        elif self.optionlist_.GetStringValue("hessian-approximation") == "exact":
+            solver = DeviceIPMSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))     # the whole solve stays on the device
+        else:
+            solver = ScipyNLPSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))
         self.meshrefiner_ = MeshRefiner(self.optionlist_)
         if (self.optionlist_.GetStringValue("first-derive") == "analytic"
                 and self.optionlist_.GetStringValue("analytic-derive-check") == "yes"):

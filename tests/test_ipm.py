@@ -1,0 +1,259 @@
+"""Row f-2: the NLP solve, batched and device-resident (rpm_ipm_*), against its CPU restatement (oracle/ipm_oracle.py).
+
+The reference's solver is Ipopt 3.12.3 (Core/LpNLPSolver.cpp:13-53), a third-party dependency that is not in the
+reference tree; both sides here restate its published algorithm, so parity is device-vs-restatement on the same
+inputs (same iteration counts, same optimum to solver tolerance) and the restatement itself is pinned by optima known
+in closed form and by scipy's trust-constr — not by traces of the reference, which holds none.
+
+CPU (not gpu): the restatement reaches the analytic optima; agrees with scipy.
+GPU: band + border LDL^T vs numpy; device solves vs the restatement (smooth problems: identical iteration counts);
+per-instance bounds (an MPC sweep over initial states); device-pointer entry; the application loop with the device
+solver, whose multipliers give the analytic Bryson-Denham costates.
+"""
+import numpy as np
+import pytest
+
+from lpopc_amd import problems
+from lpopc_amd.problem import Options
+from oracle import ipm_oracle
+from oracle import oracle as orc
+
+
+def _exact():
+    o = Options()
+    o.SetStringValue("hessian-approximation", "exact")
+    return o
+
+
+def _cycloid_time(xf, yf, g):
+    from scipy.optimize import brentq
+    th = brentq(lambda t: (t - np.sin(t)) / (1 - np.cos(t)) - xf / yf, 1e-6, 2 * np.pi - 1e-6)
+    return th * np.sqrt(yf / (1 - np.cos(th)) / g)
+
+
+# ----------------------------------------------------------------------------------------------- CPU: the restatement
+def test_restatement_reaches_bryson_denham_optimum():
+    o = orc.Oracle(problems.bryson_denham(2, 8), _exact())
+    r = ipm_oracle.solve(o, o.starting_point())
+    assert r["status"] == 0 and r["kkt_error"] <= 1e-8
+    assert abs(r["obj"] - 4.0) < 1e-6                      # J* = 4 / (9 l), l = 1/9
+    M = 17
+    assert r["x"][:M].max() <= 1.0 / 9.0 + 1e-9            # the state rides its bound from inside
+
+
+def test_restatement_reaches_brachistochrone_optimum():
+    prob = problems.brachistochrone(2, 10)
+    o = orc.Oracle(prob, _exact())
+    r = ipm_oracle.solve(o, o.starting_point())
+    ev = prob.GetPhase(0).GeteventMin()
+    T = _cycloid_time(ev[3], ev[4], prob.GetOpimalProblemFuns().consts[0])
+    assert r["status"] == 0 and abs(r["obj"] - T) < 1e-5 * T
+
+
+def test_restatement_reaches_hypersensitive_turnpike_cost():
+    from scipy.integrate import quad
+    V = quad(lambda x: -x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.5)[0]
+    W = quad(lambda x: x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.0)[0]
+    o = orc.Oracle(problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), _exact())
+    r = ipm_oracle.solve(o, o.starting_point())
+    assert r["status"] == 0 and abs(r["obj"] - (V + W)) < 1e-3 * (V + W)
+
+
+def test_restatement_agrees_with_scipy_on_the_quadrotor():
+    from lpopc_amd.application import ScipyNLPSolver
+    from test_known_answers import _OracleNLP
+    o = orc.Oracle(problems.quadrotor(2, 4), _exact())
+    r = ipm_oracle.solve(o, o.starting_point())
+    nlp = _OracleNLP(o)
+    assert ScipyNLPSolver(1e-8, maxiter=400).SolveNlp(nlp)
+    assert r["status"] == 0 and abs(r["obj"] - nlp.sol[2]) < 1e-6 * abs(nlp.sol[2])
+    # KKT conditions of the restatement's answer, checked from scratch: stationarity in the free variables
+    xl, xu, gl, gu = o.bounds()
+    ji, jj = o.jac_structure()
+    lag = o.eval_grad_f(r["x"])
+    np.add.at(lag, jj, o.eval_jac_g(r["x"]) * r["lambda"][ji])
+    inner = (r["x"] > xl + 1e-6) & (r["x"] < xu - 1e-6)
+    assert np.abs(lag[inner]).max() < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+def _random_kkt(ipm, n, B, seed):
+    """Random symmetric quasi-definite matrices inside the solver's band + border envelope -> (storage, dense, signs)."""
+    info = ipm.info()
+    nt, nbo, b = info["kkt_order"], info["band_order"], info["half_bandwidth"]
+    cs = info["storage_doubles"] // nt
+    pos = ipm.permutation()
+    sign = np.ones(nt)
+    sign[pos[n + info["n_slacks"]:]] = -1.0
+    rng = np.random.RandomState(seed)
+    ii, jj = np.tril_indices(nt, -1)
+    inside = ((ii < nbo) & (ii - jj <= b)) | (ii >= nbo)
+    dense, store = np.zeros((B, nt, nt)), np.zeros((B, nt * cs))
+    for bi in range(B):
+        keep = inside & ((sign[ii] != sign[jj]) | (rng.rand(ii.size) < 0.3)) & (rng.rand(ii.size) < 0.5)
+        A = np.zeros((nt, nt))
+        A[ii[keep], jj[keep]] = rng.uniform(-1, 1, size=keep.sum())
+        A = A + A.T
+        same = sign[:, None] == sign[None, :]
+        A[np.arange(nt), np.arange(nt)] = sign * ((np.abs(A) * same).sum(axis=1) + rng.uniform(0.5, 2.0, size=nt))
+        dense[bi] = A
+        li, lj = np.tril_indices(nt)
+        ok = ((li < nbo) & (li - lj <= b)) | (li >= nbo)
+        li, lj = li[ok], lj[ok]
+        slot = np.where(li < nbo, li - lj, b + 1 + li - nbo)
+        store[bi, lj * cs + slot] = A[li, lj]
+    return store, dense, sign
+
+
+LAYOUTS = [("brachistochrone", lambda: problems.brachistochrone(2, 6), 3), ("quadrotor", lambda: problems.quadrotor(3, 4), 2),
+           ("launch", lambda: problems.launch(2, 5), 2), ("hypersensitive_hp", lambda: problems.hypersensitive([-1, -0.5, 0.4, 1], [4, 9, 3], tf=50.0), 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,B", LAYOUTS, ids=[c[0] for c in LAYOUTS])
+def test_band_border_ldlt_against_numpy(built, name, make, B):
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    eng = NLPEngine(make(), _exact(), n_instances=B, device=0)
+    ipm = BatchedIPM(eng)
+    store, dense, sign = _random_kkt(ipm, eng.n, B, 7)
+    rhs = np.random.RandomState(3).uniform(-1, 1, size=(B, sign.size))
+    sol, npos, nneg = ipm.debug_solve(store, rhs)
+    for bi in range(B):
+        ref = np.linalg.solve(dense[bi], rhs[bi])
+        assert np.max(np.abs(sol[bi] - ref)) <= 1e-11 * np.max(np.abs(ref))      # tolerance: f64 LDL^T of a well-conditioned matrix
+        assert npos[bi] == (sign > 0).sum() and nneg[bi] == (sign < 0).sum()       # Sylvester: signs of D = inertia
+    ipm.close()
+    eng.close()
+
+
+SOLVES = [
+    # name, problem, instances, relative start perturbation, identical iteration counts expected
+    ("bryson_denham", lambda: problems.bryson_denham(2, 8), 2, 0.0, True),
+    ("brachistochrone", lambda: problems.brachistochrone(2, 10), 2, 0.0, True),
+    ("hypersensitive", lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), 2, 0.0, True),
+    ("quadrotor", lambda: problems.quadrotor(2, 4), 5, 1e-2, True),
+    # libm-level differences in the second-difference Hessian (tests/test_gpu_parity.py, HESS_CASES) move the inertia
+    # corrections around: same optimum, not the same path
+    ("launch", lambda: problems.launch(2, 5), 1, 0.0, False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,B,pert,same_path", SOLVES, ids=[c[0] for c in SOLVES])
+def test_device_solve_against_restatement(built, name, make, B, pert, same_path):
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = make()
+    eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
+    o = orc.Oracle(prob, _exact())
+    x0 = np.tile(o.starting_point(), (B, 1))
+    if pert:
+        x0 = x0 * (1 + pert * np.random.RandomState(1).uniform(-1, 1, size=x0.shape))
+    ipm = BatchedIPM(eng, max_iter=400)
+    r = ipm.solve(x0)
+    for bi in range(B):
+        ref = ipm_oracle.solve(o, x0[bi], max_iter=400)
+        assert r["status"][bi] == ref["status"] == 0
+        assert abs(r["obj"][bi] - ref["obj"]) <= 1e-8 * max(1.0, abs(ref["obj"]))          # both stop at E_0 <= 1e-8
+        assert r["kkt_error"][bi] <= 1e-8
+        if same_path:
+            assert r["iterations"][bi] == ref["iterations"]
+            assert np.max(np.abs(r["x"][bi] - ref["x"])) <= 1e-6 * max(1.0, np.max(np.abs(ref["x"])))
+            assert np.max(np.abs(r["lambda"][bi] - ref["lambda"])) <= 1e-5 * max(1.0, np.max(np.abs(ref["lambda"])))
+    # every instance satisfies its bounds and constraints
+    xl, xu, gl, gu = o.bounds()
+    for bi in range(B):
+        g = o.eval_g(r["x"][bi])
+        assert (r["x"][bi] >= xl - 1e-12).all() and (r["x"][bi] <= xu + 1e-12).all()
+        assert max((gl - g).max(), (g - gu).max()) < 1e-7
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_sweep_with_per_instance_bounds(built):
+    """An MPC sweep: the same transcription from different initial states (per-instance variable bounds)."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    B = 6
+    prob = problems.quadrotor(2, 4)
+    eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
+    o = orc.Oracle(prob, _exact())
+    xl, xu, _, _ = o.bounds()
+    ipm = BatchedIPM(eng)
+    rng = np.random.RandomState(5)
+    fixed = np.nonzero(xl == xu)[0]
+    N1 = 2 * 4 + 1
+    x0_idx = [i for i in fixed if i % N1 == 0 and i < 12 * N1]          # X(0, state) of the 12 states
+    bounds = []
+    for bi in range(B):
+        l, u = xl.copy(), xu.copy()
+        l[x0_idx] = u[x0_idx] = rng.uniform(-0.3, 0.3, size=len(x0_idx))
+        ipm.set_bounds(bi, l, u)
+        bounds.append((l, u))
+    x0 = np.tile(o.starting_point(), (B, 1))
+    r = ipm.solve(x0)
+    for bi in range(B):
+        ref = ipm_oracle.solve(o, x0[bi], x_l=bounds[bi][0], x_u=bounds[bi][1])
+        assert r["status"][bi] == ref["status"] == 0
+        assert r["iterations"][bi] == ref["iterations"]
+        assert abs(r["obj"][bi] - ref["obj"]) <= 1e-8 * max(1.0, abs(ref["obj"]))
+        assert np.array_equal(r["x"][bi][x0_idx], bounds[bi][0][x0_idx])
+    assert len(set(np.round(r["obj"], 6))) == B                          # genuinely different problems
+    # a bound pattern that turns a free variable into a fixed one is refused (the KKT layout is shared)
+    bad_l, bad_u = xl.copy(), xu.copy()
+    free = np.nonzero(xl != xu)[0][0]
+    bad_l[free] = bad_u[free] = 0.0
+    with pytest.raises(Exception):
+        ipm.set_bounds(0, bad_l, bad_u)
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_device_pointer_entry_and_limits(built):
+    import torch
+    from lpopc_amd.engine import BatchedIPM, NLPEngine, RpmError
+    prob = problems.quadrotor(2, 4)
+    B = 3
+    eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
+    ipm = BatchedIPM(eng)
+    x0 = np.tile(eng.get_starting_point()[:eng.n], (B, 1))
+    host = ipm.solve(x0)
+    d_x = torch.from_numpy(x0.copy()).cuda()
+    d_l = torch.zeros((B, eng.m), dtype=torch.float64, device="cuda")
+    dev = ipm.solve_dev(d_x, d_l)
+    assert np.array_equal(d_x.cpu().numpy(), host["x"]) and np.array_equal(d_l.cpu().numpy(), host["lambda"])
+    assert np.array_equal(dev["iterations"], host["iterations"])
+    ipm.set_option("max_iter", 3)                                        # iteration limit -> status 2, no exception
+    lim = ipm.solve(x0)
+    assert (lim["status"] == 2).all() and (lim["iterations"] == 3).all()
+    with pytest.raises(RpmError):
+        ipm.set_option("no-such-option", 1.0)
+    ipm.close()
+    eng.close()
+    # the solver needs eval_h: an engine without hessian-approximation=exact is refused, loudly
+    lm = NLPEngine(prob, device=0)
+    with pytest.raises(RpmError):
+        BatchedIPM(lm)
+    lm.close()
+
+
+@pytest.mark.gpu
+def test_application_loop_with_the_device_solver(built, tmp_path):
+    """hessian-approximation=exact: LpopcApplication solves every mesh on the device (rpm_ipm_*), extracts, estimates,
+    refines.  Bryson-Denham: J* = 4/(9 l); the problem is autonomous, so the Hamiltonian built from the solver's
+    multipliers (Nlp2OpControl: costates = lambda / w) is constant along the trajectory."""
+    from lpopc_amd.application import DeviceIPMSolver, LpopcApplication, console_not_print
+    from lpopc_amd.problem import LpopcException
+    app = LpopcApplication(console_not_print)
+    app.SetOptimalControlProblem(problems.bryson_denham(2, 8))
+    app.Options().SetStringValue("hessian-approximation", "exact")
+    app.Options().SetNumericValue("Ipopt-tol", 1e-8)
+    app.Options().SetIntegerValue("max-grid-num", 3)
+    try:
+        app.SolveOptimalProblem(device=0, result_dir=str(tmp_path))
+    except LpopcException as e:                      # like the reference: running out of grids is an error exit
+        assert "grid" in str(e).lower()
+    assert abs(app.objective - 4.0) < 1e-5
+    H = np.asarray(app.result[0]["hamiltonian"])
+    assert np.ptp(H[1:-1]) < 2e-2 * max(1.0, np.abs(H).max())          # constant Hamiltonian (mesh-level accuracy)
+    assert isinstance(DeviceIPMSolver(1e-8), DeviceIPMSolver)
