@@ -253,8 +253,7 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
 
 // ------------------------------------------------------------------------------------------------ band + border LDL^T
 // Storage of one instance: column j holds rows j .. j+b of the band (slot i-j) and the nb border rows (slot b+1+i-Nb).
-// Right-looking, IPM_W columns at a time: the diagonal block is factored in LDS, each panel row is solved by one
-// thread, the rank-W update of the (b + nb)^2 trailing window runs out of LDS with 2 x 4 register tiles.
+// IPM_W columns at a time: the diagonal block is factored in LDS, each panel row is solved by the thread that owns it.
 // No pivoting: with dw large enough and dc > 0 the matrix is symmetric quasi-definite, whose LDL^T exists for every
 // ordering (Vanderbei 1995); the signs of D give the inertia Algorithm IC asks for.
 struct KktGeom {
@@ -277,100 +276,142 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
   return J0 >= G.Nb ? J1 + q : (q < nrb ? J1 + q : G.Nb + (q - nrb));
 }
 
-__global__ __launch_bounds__(256) void kkt_factor_kernel(double* Kall, long long kstride, KktGeom G, IpmInst* inst, int NRP) {
+// Left-looking over the band: block column J (IPM_W columns) gathers the contributions of the b columns before it —
+// thread = matrix row (two rows per thread), T[k][c] = d_k L(J+c, k) broadcast from LDS — so every factor entry is
+// read ~b/W times and written once (the right-looking form re-writes the whole (b+nb)^2 window per block column:
+// twice the traffic).  The small border x border corner is kept in LDS and updated right-looking, then factored there.
+__global__ __launch_bounds__(256) void kkt_factor_kernel(double* Kall, long long kstride, KktGeom G, IpmInst* inst, int unused) {
   constexpr int W = IPM_W;
-  const int bi = blockIdx.x, t = threadIdx.x;
+  const int bi = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   IpmInst& S = inst[bi];
   if (S.status != 0 || !S.refactor) return;
   double* K = Kall + size_t(bi) * kstride;
   extern __shared__ double lds[];
-  double* Dg = lds;                  // W x (W + 1)
-  double* PL = lds + W * (W + 1);    // W x NRP: L of the panel, column-major by block column
-  double* PY = PL + size_t(W) * NRP; // W x NRP: L D
+  double* T = lds;                              // b x W
+  double* Dg = T + size_t(G.b) * W;             // W x (W + 1)
+  double* BL = Dg + W * (W + 1);                // nb x W: L of the border rows in the current block column
+  double* BY = BL + size_t(G.nb) * W;           // nb x W: L D
+  double* C = BY + size_t(G.nb) * W;            // nb x nb: the corner (lower triangle used)
   __shared__ int cnt[3];
   if (t < 3) cnt[t] = 0;
   int npos = 0, nneg = 0, nbad = 0;
-  const int di = t / W, dj = t % W;
-  for (int J0 = 0; J0 < G.Nt;) {
-    int J1, nrb, nr;
-    block_range(G, J0, &J1, &nrb, &nr);
-    const int w = J1 - J0;
-    if (di < w && dj <= di) Dg[di * (W + 1) + dj] = K[G.at(J0 + di, J0 + dj)];
+  const int nb = G.nb;
+  for (int idx = t; idx < nb * nb; idx += nt) {
+    const int r = idx / nb, c = idx % nb;
+    C[idx] = r >= c ? K[G.at(G.Nb + r, G.Nb + c)] : 0.0;
+  }
+  for (int J0 = 0; J0 < G.Nb;) {
+    const int J1 = min(J0 + W, G.Nb), w = J1 - J0;
+    const int kbase = max(J0 - G.b, 0), nk = J0 - kbase;
+    const int nrb = max(min(J1 - 1 + G.b, G.Nb - 1) - J1 + 1, 0), rows = w + nrb + nb;
+    for (int idx = t; idx < nk * W; idx += nt) {
+      const int kk = idx / W, c = idx % W, k = kbase + kk, j = J0 + c;
+      T[idx] = (c < w && j - k <= G.b) ? K[G.at(j, k)] * K[G.at(k, k)] : 0.0;
+    }
+    __syncthreads();
+    double acc[2][W];
+    int rr[2];
+    const double* lp[2];        // &L(r, kbase): in-band rows walk columns with stride CS - 1, border rows with stride CS
+    int lstep[2], kfirst[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = t + h * nt;
+      const bool valid = q < rows;
+      const int r = q < w ? J0 + q : (q - w < nrb ? J1 + (q - w) : G.Nb + (q - w - nrb));
+      rr[h] = valid ? r : -1;
+      const bool border = r >= G.Nb;
+#pragma unroll
+      for (int c = 0; c < W; ++c)
+        acc[h][c] = (valid && c < w && J0 + c <= r && (border || r - (J0 + c) <= G.b)) ? K[G.at(r, J0 + c)] : 0.0;
+      kfirst[h] = valid ? (border ? 0 : max(r - G.b - kbase, 0)) : nk;      // first kk with a stored L(r, k)
+      lp[h] = K + (valid ? G.at(r, kbase) : 0);
+      lstep[h] = border ? G.CS : G.CS - 1;
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < nk; ++kk) {
+      const double l0 = kk >= kfirst[0] ? lp[0][size_t(kk) * lstep[0]] : 0.0;
+      const double l1 = kk >= kfirst[1] ? lp[1][size_t(kk) * lstep[1]] : 0.0;
+      const double* tk = T + kk * W;
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        acc[0][c] = __builtin_fma(-l0, tk[c], acc[0][c]);
+        acc[1][c] = __builtin_fma(-l1, tk[c], acc[1][c]);
+      }
+    }
+    if (t < w) {
+#pragma unroll
+      for (int c = 0; c < W; ++c)
+        if (c <= t) Dg[t * (W + 1) + c] = acc[0][c];
+    }
     __syncthreads();
     for (int k = 0; k < w; ++k) {
       const double dk = Dg[k * (W + 1) + k];
-      if (di < w && dj > k && dj <= di) Dg[di * (W + 1) + dj] -= Dg[di * (W + 1) + k] / dk * Dg[dj * (W + 1) + k];
+      for (int idx = t; idx < W * W; idx += nt) {
+        const int di = idx / W, dj = idx % W;
+        if (di < w && dj > k && dj <= di) Dg[di * (W + 1) + dj] -= Dg[di * (W + 1) + k] / dk * Dg[dj * (W + 1) + k];
+      }
       __syncthreads();
-      if (dj == k && di > k && di < w) Dg[di * (W + 1) + k] /= dk;
+      for (int idx = t; idx < W; idx += nt)
+        if (idx > k && idx < w) Dg[idx * (W + 1) + k] /= dk;
       __syncthreads();
     }
-    // panel: Y L11^T = A21, L21 = Y D^-1
-    for (int q = t; q < nr + 4 && q < NRP; q += blockDim.x) {
-      if (q >= nr) {
-        for (int c = 0; c < W; ++c) { PL[c * NRP + q] = 0.0; PY[c * NRP + q] = 0.0; }
-        continue;
-      }
-      const int row = panel_row(G, J0, J1, nrb, q);
-      double y[W];
+    // panel rows: Y L11^T = A21, L21 = Y D^-1
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = t + h * nt, r = rr[h];
+      if (r < 0 || q < w) continue;
+      const bool border = r >= G.Nb;
 #pragma unroll
       for (int c = 0; c < W; ++c) {
-        double a = 0.0;
-        const bool stored = c < w && (row >= G.Nb || row - (J0 + c) <= G.b);
-        if (stored) a = K[G.at(row, J0 + c)];
+        double a = acc[h][c];
 #pragma unroll
-        for (int k = 0; k < c; ++k) a = __builtin_fma(-y[k], Dg[c * (W + 1) + k], a);
-        y[c] = c < w ? a : 0.0;
+        for (int k = 0; k < c; ++k) a = __builtin_fma(-acc[h][k], Dg[c * (W + 1) + k], a);
+        acc[h][c] = c < w ? a : 0.0;                       // y
         const double l = c < w ? a / Dg[c * (W + 1) + c] : 0.0;
-        if (stored) K[G.at(row, J0 + c)] = l;
-        PL[c * NRP + q] = l;
-        PY[c * NRP + q] = y[c];
+        if (c < w && (border || r - (J0 + c) <= G.b)) K[G.at(r, J0 + c)] = l;
+        if (border) { BL[(r - G.Nb) * W + c] = l; BY[(r - G.Nb) * W + c] = acc[h][c]; }
       }
     }
-    __syncthreads();
-    // trailing update A22 -= L21 D L21^T, lower triangle of the window
-    {
-      const int wv = t >> 6, lane = t & 63;
-      const int ncg = (nr + 3) / 4;
-      for (int cg = 0; cg < ncg; ++cg) {
-        const int q2 = cg * 4;
-        for (int ch = 0; q2 + ch * 128 < nr; ++ch) {
-          if (((cg + ch) & 3) != wv) continue;
-          const int qa = q2 + ch * 128 + lane, qb = qa + 64;
-          const int qa_c = min(qa, nr - 1), qb_c = min(qb, nr - 1);
-          double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-          for (int c = 0; c < W; ++c) {
-            const double a0 = PL[c * NRP + qa_c], a1 = PL[c * NRP + qb_c];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const double bj = PY[c * NRP + q2 + j];
-              acc[0][j] = __builtin_fma(a0, bj, acc[0][j]);
-              acc[1][j] = __builtin_fma(a1, bj, acc[1][j]);
-            }
-          }
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int q1 = h ? qb : qa;
-            if (q1 >= nr) continue;
-            const int r1 = panel_row(G, J0, J1, nrb, q1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (q2 + j >= nr || q1 < q2 + j) continue;
-              const int r2 = panel_row(G, J0, J1, nrb, q2 + j);
-              K[G.at(r1, r2)] -= acc[h][j];
-            }
-          }
-        }
-      }
+    for (int idx = t; idx < W * W; idx += nt) {
+      const int di = idx / W, dj = idx % W;
+      if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = Dg[di * (W + 1) + dj];
     }
-    if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = Dg[di * (W + 1) + dj];
     if (t < w) {
       const double dk = Dg[t * (W + 1) + t];
       if (dk > 0) ++npos; else if (dk < 0) ++nneg; else ++nbad;
       if (!(fabs(dk) < 1e300)) ++nbad;
     }
     __syncthreads();
+    for (int idx = t; idx < nb * nb; idx += nt) {          // corner -= L_border D L_border^T of this block column
+      const int r = idx / nb, c2 = idx % nb;
+      if (r < c2) continue;
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) s = __builtin_fma(BL[r * W + c], BY[c2 * W + c], s);
+      C[idx] -= s;
+    }
+    __syncthreads();
     J0 = J1;
+  }
+  for (int k = 0; k < nb; ++k) {                            // the corner, unblocked, in LDS
+    __syncthreads();
+    const double dk = C[k * nb + k];
+    for (int idx = t; idx < nb * nb; idx += nt) {
+      const int r = idx / nb, c = idx % nb;
+      if (r > k && c > k && c <= r) C[idx] -= C[r * nb + k] / dk * C[c * nb + k];
+    }
+    __syncthreads();
+    for (int r = k + 1 + t; r < nb; r += nt) C[r * nb + k] /= dk;
+  }
+  __syncthreads();
+  for (int idx = t; idx < nb * nb; idx += nt) {
+    const int r = idx / nb, c = idx % nb;
+    if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[idx];
+    if (r == c) {
+      const double dk = C[idx];
+      if (dk > 0) ++npos; else if (dk < 0) ++nneg; else ++nbad;
+      if (!(fabs(dk) < 1e300)) ++nbad;
+    }
   }
   if (npos) atomicAdd(&cnt[0], npos);
   if (nneg) atomicAdd(&cnt[1], nneg);
@@ -627,7 +668,7 @@ struct rpm_ipm {
   std::vector<void*> allocs;
   int* h_cnt = nullptr;           // page-locked mirror of D.cnt
   size_t factor_lds = 0;
-  int NRP = 0;
+  int NRP = 0, factor_threads = 128;
   std::string err;
   std::vector<IpmInst> h_inst;
   int total_factorizations = 0, total_iterations = 0, total_trials = 0;
@@ -681,7 +722,7 @@ int launch_check(rpm_ipm* h, const char* what) {
 int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve, int check_status) {
   const IpmDev& D = h->D;
   if (factor)
-    hipLaunchKernelGGL(kkt_factor_kernel, dim3(unsigned(D.B)), dim3(256), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan), D.inst,
+    hipLaunchKernelGGL(kkt_factor_kernel, dim3(unsigned(D.B)), dim3(unsigned(h->factor_threads)), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan), D.inst,
                        h->NRP);
   if (solve)
     hipLaunchKernelGGL(kkt_solve_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, geom_of(h->plan), D.inst, D.rhs,
@@ -752,10 +793,17 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     if (hipMemcpy(D.vl, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(D.vu, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy"; return fail(RPM_E_DEVICE); }
   }
-  h->NRP = p.b + p.nb + IPM_W + 8;
-  h->factor_lds = (size_t(IPM_W) * (IPM_W + 1) + 2 * size_t(IPM_W) * h->NRP) * sizeof(double);
+  {
+    const int rows = IPM_W + p.b + p.nb;            // most rows a block column touches: two per thread
+    h->factor_threads = rows <= 256 ? 128 : 256;
+    if (rows > 512) {
+      h->err = "band + border of " + std::to_string(p.b + p.nb) + " rows exceeds the factorisation's 512 rows per block column";
+      return fail(RPM_E_UNSUPPORTED);
+    }
+  }
+  h->factor_lds = (size_t(p.b) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + 2 * size_t(p.nb) * IPM_W + size_t(p.nb) * p.nb) * sizeof(double);
   if (h->factor_lds > 150 * 1024) {
-    h->err = "band + border of " + std::to_string(p.b + p.nb) + " rows does not fit the factorisation's LDS panel";
+    h->err = "band of " + std::to_string(p.b) + " and border of " + std::to_string(p.nb) + " rows do not fit the factorisation's LDS";
     return fail(RPM_E_UNSUPPORTED);
   }
   if (h->factor_lds > 48 * 1024 &&

@@ -1,0 +1,70 @@
+"""Row f-2 measurement: the MPC sweep of BASELINE config 5 solved end to end on the device — B quadrotor instances
+(8 intervals x 8 LGR points, n=1038, m=769), each from its own initial state, one batched interior-point run.
+Prints one JSON object: solves/s, iterations, factorisations, storage, and the share of the band + border LDL^T.
+Run on the GPU box:  python tools/bench_ipm.py [instances] [cpu_instances]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from lpopc_amd import problems
+from lpopc_amd.engine import BatchedIPM, NLPEngine
+from lpopc_amd.problem import Options
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n_cpu = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+o = Options()
+o.SetStringValue("hessian-approximation", "exact")
+prob = problems.quadrotor(8, 8)
+eng = NLPEngine(prob, o, n_instances=B, device=0)
+eng.set_option("instance_align", 16)
+ipm = BatchedIPM(eng)
+one = NLPEngine(prob, o, device=0)
+xl, xu, _, _ = one.get_bounds_info()
+x_start = one.get_starting_point()
+N1 = 8 * 8 + 1
+x0_idx = [i * N1 for i in range(12)]
+rng = np.random.RandomState(5)
+bounds = []
+for bi in range(B):
+    l, u = xl.copy(), xu.copy()
+    l[x0_idx] = u[x0_idx] = np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.1, 0.1, 6)])
+    ipm.set_bounds(bi, l, u)
+    bounds.append((l, u))
+x0 = np.tile(x_start, (B, 1))
+d_x = torch.from_numpy(x0).cuda()
+r = ipm.solve_dev(d_x.clone())            # warm-up (module load, first-touch)
+torch.cuda.synchronize()
+times = []
+for rep in range(3):
+    d = d_x.clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = ipm.solve_dev(d)
+    torch.cuda.synchronize()
+    times.append(time.perf_counter() - t0)
+st, info = ipm.stats(), ipm.info()
+dt = min(times)
+nb, b, nbd = info["band_order"], info["half_bandwidth"], info["border"]
+flops_factor = float(nb) * (b + nbd) ** 2 + nbd ** 3 / 3.0        # multiply-adds x2 / 2 (lower triangle): ~ N (b + border)^2
+out = {"workload": "quadrotor MPC sweep, %d instances x (8x8), per-instance initial states" % B, "instances": B,
+       "solve_s": dt, "solves_per_s": B / dt, "iterations_min_max": [int(r["iterations"].min()), int(r["iterations"].max())],
+       "batched_iterations": st["iterations"], "factorizations": st["factorizations"], "trial_points": st["trial_points"],
+       "converged": int((r["status"] == 0).sum()), "max_kkt_error": float(r["kkt_error"].max()), "kkt": info,
+       "kkt_storage_gb": info["storage_doubles"] * 8 * B / 1e9,
+       "factor_flop_per_instance": flops_factor, "ms_per_batched_iteration": 1e3 * dt / max(1, st["iterations"])}
+if n_cpu:
+    from oracle import ipm_oracle
+    from oracle.oracle import Oracle
+    orc = Oracle(prob, o)
+    t0 = time.perf_counter()
+    for bi in range(n_cpu):
+        ref = ipm_oracle.solve(orc, x0[bi], x_l=bounds[bi][0], x_u=bounds[bi][1])
+        assert ref["status"] == 0 and abs(ref["obj"] - r["obj"][bi]) < 1e-7 * max(1, abs(ref["obj"])), (ref["obj"], r["obj"][bi])
+    out["cpu_restatement_dense_numpy_s_per_solve"] = (time.perf_counter() - t0) / n_cpu
+    out["cpu_instances_checked"] = n_cpu
+print(json.dumps(out))
