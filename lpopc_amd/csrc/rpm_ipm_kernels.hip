@@ -37,6 +37,7 @@ struct IpmInst {
   double delta_w, delta_w_last, alpha_max, alpha_z, alpha, alpha_min, dphi, phi, theta_max, theta_min;
   int status;   // 0 running, 1 converged, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
   int iter, nfilt, accepted, refactor, npos, nneg, nbad, ls, armijo, nzb, pad;
+  long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 
 struct IpmDev {
@@ -276,104 +277,170 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
   return J0 >= G.Nb ? J1 + q : (q < nrb ? J1 + q : G.Nb + (q - nrb));
 }
 
-// Left-looking over the band: block column J (IPM_W columns) gathers the contributions of the b columns before it —
-// thread = matrix row (two rows per thread), T[k][c] = d_k L(J+c, k) broadcast from LDS — so every factor entry is
-// read ~b/W times and written once (the right-looking form re-writes the whole (b+nb)^2 window per block column:
-// twice the traffic).  The small border x border corner is kept in LDS and updated right-looking, then factored there.
-__global__ __launch_bounds__(256) void kkt_factor_kernel(double* Kall, long long kstride, KktGeom G, IpmInst* inst, int unused) {
+// Left-looking over the band: block column J (IPM_W = 16 columns) gathers the contributions of the b columns before it,
+//     A(rows, J..J+15)^T  -=  T^T (16 x k) . L(rows, k)^T (k x 16 rows),      T[k][c] = d_k L(J+c, k),
+// as v_mfma_f64_16x16x4_f64 products: one 16-row tile of the matrix per accumulator, the tiles of a block column dealt to
+// the 4 waves, T staged in LDS (one conflict-free 8-byte read per lane and 4 columns), L streamed from HBM exactly where
+// it is non-zero (a tile starts at its first in-band column).  Every factor entry is read ~b/16 times and written once
+// (the right-looking form re-writes the whole (b + nb)^2 window per block column).  The panel solve is a second
+// matrix product, Y^T = L11^-1 A^T, with the accumulators fed back as the B operand.  The border x border corner lives
+// in LDS, is updated right-looking and factored there.  Operand maps (cdna_hip_programming.md §3): A: lane l holds
+// A[l&15][l>>4], B: B[l>>4][l&15], C/D: row (l>>4) + 4 reg, column l&15.
+#ifndef IPM_LB
+#define IPM_LB 3   // waves per SIMD the 4-tile factorisation is compiled for
+#endif
+constexpr int IPM_MT = 8;   // most 16-row tiles per wave: block columns of up to 4 x 8 x 16 = 512 rows
+template <int MT>           // 16-row tiles per wave: 4 (block columns of up to 256 rows, 4 workgroups per CU) or 8
+__global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(double* Kall, long long kstride, KktGeom G, IpmInst* inst) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W;
   const int bi = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   IpmInst& S = inst[bi];
   if (S.status != 0 || !S.refactor) return;
   double* K = Kall + size_t(bi) * kstride;
   extern __shared__ double lds[];
-  double* T = lds;                              // b x W
-  double* Dg = T + size_t(G.b) * W;             // W x (W + 1)
-  double* BL = Dg + W * (W + 1);                // nb x W: L of the border rows in the current block column
+  double* T = lds;                              // (b + 8) x W
+  double* Dg = T + size_t(G.b + 8) * W;         // W x (W + 1)
+  double* Mi = Dg + W * (W + 1);                // W x W: L11^-1, row-major
+  double* invd = Mi + W * W;                    // W
+  double* BL = invd + W;                        // nb x W: L of the border rows in the current block column
   double* BY = BL + size_t(G.nb) * W;           // nb x W: L D
   double* C = BY + size_t(G.nb) * W;            // nb x nb: the corner (lower triangle used)
   __shared__ int cnt[3];
   if (t < 3) cnt[t] = 0;
   int npos = 0, nneg = 0, nbad = 0;
   const int nb = G.nb;
+  const int wv = t >> 6, lr = t & 15, lq = (t & 63) >> 4;
+#ifdef IPM_TIMING
+  long long tc[6] = {0, 0, 0, 0, 0, 0}, t_prev = wall_clock64();
+#define IPM_TICK(i) do { __syncthreads(); const long long _n = wall_clock64(); tc[i] += _n - t_prev; t_prev = _n; } while (0)
+#else
+#define IPM_TICK(i)
+#endif
   for (int idx = t; idx < nb * nb; idx += nt) {
     const int r = idx / nb, c = idx % nb;
     C[idx] = r >= c ? K[G.at(G.Nb + r, G.Nb + c)] : 0.0;
   }
   for (int J0 = 0; J0 < G.Nb;) {
     const int J1 = min(J0 + W, G.Nb), w = J1 - J0;
-    const int kbase = max(J0 - G.b, 0), nk = J0 - kbase;
-    const int nrb = max(min(J1 - 1 + G.b, G.Nb - 1) - J1 + 1, 0), rows = w + nrb + nb;
-    for (int idx = t; idx < nk * W; idx += nt) {
+    const int kbase = max(J0 - G.b, 0), nk = J0 - kbase, ngrp = (nk + 3) >> 2;
+    const int nrb = max(min(J1 - 1 + G.b, G.Nb - 1) - J1 + 1, 0), rows = w + nrb + nb, ntile = (rows + 15) >> 4;
+#pragma unroll 4
+    for (int idx = t; idx < (ngrp + 1) * 4 * W; idx += nt) {
       const int kk = idx / W, c = idx % W, k = kbase + kk, j = J0 + c;
-      T[idx] = (c < w && j - k <= G.b) ? K[G.at(j, k)] * K[G.at(k, k)] : 0.0;
+      T[idx] = (kk < nk && c < w && j - k <= G.b) ? K[G.at(j, k)] * K[G.at(k, k)] : 0.0;
     }
     __syncthreads();
-    double acc[2][W];
-    int rr[2];
-    const double* lp[2];        // &L(r, kbase): in-band rows walk columns with stride CS - 1, border rows with stride CS
-    int lstep[2], kfirst[2];
+    IPM_TICK(0);
+    d4 acc[MT];
+    const double* lp[MT];       // &L(r, kbase) of this lane's row in tile i: in-band rows walk columns with stride CS - 1, border rows CS
+    int lstep[MT], kfirst[MT], gfirst[MT], rrow[MT];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = t + h * nt;
+    for (int i = 0; i < MT; ++i) {
+      const int q0 = (wv + 4 * i) * 16, q = q0 + lr;
       const bool valid = q < rows;
       const int r = q < w ? J0 + q : (q - w < nrb ? J1 + (q - w) : G.Nb + (q - w - nrb));
-      rr[h] = valid ? r : -1;
       const bool border = r >= G.Nb;
+      rrow[i] = valid ? r : -1;
+      kfirst[i] = valid ? (border ? 0 : max(r - G.b - kbase, 0)) : (1 << 30);
+      lp[i] = K + (valid ? G.at(r, kbase) : 0);
+      lstep[i] = border ? G.CS : G.CS - 1;
+      // the tile's first group of 4 columns with anything stored: from its first row when the whole tile is inside the band
+      const int r_first = q0 < w ? J0 + q0 : J1 + (q0 - w);
+      gfirst[i] = q0 >= rows ? (1 << 30) : ((q0 + 15 >= w + nrb) ? 0 : (max(r_first - G.b - kbase, 0) >> 2));
 #pragma unroll
-      for (int c = 0; c < W; ++c)
-        acc[h][c] = (valid && c < w && J0 + c <= r && (border || r - (J0 + c) <= G.b)) ? K[G.at(r, J0 + c)] : 0.0;
-      kfirst[h] = valid ? (border ? 0 : max(r - G.b - kbase, 0)) : nk;      // first kk with a stored L(r, k)
-      lp[h] = K + (valid ? G.at(r, kbase) : 0);
-      lstep[h] = border ? G.CS : G.CS - 1;
+      for (int g = 0; g < 4; ++g) {
+        const int c = lq + 4 * g;
+        acc[i][g] = (valid && c < w && J0 + c <= r && (border || r - (J0 + c) <= G.b)) ? K[G.at(r, J0 + c)] : 0.0;
+      }
     }
-#pragma unroll 4
-    for (int kk = 0; kk < nk; ++kk) {
-      const double l0 = kk >= kfirst[0] ? lp[0][size_t(kk) * lstep[0]] : 0.0;
-      const double l1 = kk >= kfirst[1] ? lp[1][size_t(kk) * lstep[1]] : 0.0;
-      const double* tk = T + kk * W;
+    {
+      // two column groups of L in flight per tile while the previous two are multiplied
+      auto ld = [&](int i, int kg) -> double {
+        const int kk = 4 * kg + lq;
+        return (kg >= gfirst[i] && kk >= kfirst[i] && kk < nk) ? lp[i][size_t(kk) * lstep[i]] : 0.0;
+      };
+      double b0[MT], b1[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { b0[i] = ld(i, 0); b1[i] = ld(i, 1); }
+      for (int kg = 0; kg < ngrp; kg += 2) {
+        const double a0 = -T[(4 * kg + lq) * W + lr], a1 = -T[(4 * kg + 4 + lq) * W + lr];
+        double n0[MT], n1[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { n0[i] = ld(i, kg + 2); n1[i] = ld(i, kg + 3); }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (kg + 1 < gfirst[i]) continue;
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[i], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[i], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { b0[i] = n0[i]; b1[i] = n1[i]; }
+      }
+    }
+    IPM_TICK(1);
+    if (wv == 0) {              // tile 0 holds the diagonal block (rows q < w): its LDL^T in the registers of 16 lanes
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = lq + 4 * g;
+        if (lr < w && c <= lr) Dg[lr * (W + 1) + c] = acc[0][g];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double row[W], inv[W];    // lane (l & 15) = row of the block and of L11^-1 (the same eliminations applied to I)
 #pragma unroll
       for (int c = 0; c < W; ++c) {
-        acc[0][c] = __builtin_fma(-l0, tk[c], acc[0][c]);
-        acc[1][c] = __builtin_fma(-l1, tk[c], acc[1][c]);
+        row[c] = (lr < w && c <= lr) ? Dg[lr * (W + 1) + c] : (c == lr ? 1.0 : 0.0);
+        inv[c] = c == lr ? 1.0 : 0.0;
       }
-    }
-    if (t < w) {
 #pragma unroll
-      for (int c = 0; c < W; ++c)
-        if (c <= t) Dg[t * (W + 1) + c] = acc[0][c];
+      for (int k = 0; k < W; ++k) {
+        // all cross-lane reads of the step first (they are independent), then the arithmetic
+        const double dk = __shfl(row[k], k, 16);                   // pivot: row k's own diagonal
+        double ajk[W], mkj[W];
+#pragma unroll
+        for (int j = k + 1; j < W; ++j) ajk[j] = __shfl(row[k], j, 16);     // a(j, k) before scaling
+#pragma unroll
+        for (int j = 0; j <= k; ++j) mkj[j] = __shfl(inv[j], k, 16);        // row k of the inverse so far
+        const double lik = lr > k ? row[k] / dk : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < W; ++j)
+          if (lr >= j) row[j] = __builtin_fma(-lik, ajk[j], row[j]);
+#pragma unroll
+        for (int j = 0; j <= k; ++j) inv[j] = __builtin_fma(-lik, mkj[j], inv[j]);
+        if (lr > k) row[k] = lik;
+      }
+      if (lq == 0) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          if (lr < w && c <= lr) Dg[lr * (W + 1) + c] = row[c];
+          Mi[lr * W + c] = inv[c];
+        }
+        invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
+      }
     }
     __syncthreads();
-    for (int k = 0; k < w; ++k) {
-      const double dk = Dg[k * (W + 1) + k];
-      for (int idx = t; idx < W * W; idx += nt) {
-        const int di = idx / W, dj = idx % W;
-        if (di < w && dj > k && dj <= di) Dg[di * (W + 1) + dj] -= Dg[di * (W + 1) + k] / dk * Dg[dj * (W + 1) + k];
-      }
-      __syncthreads();
-      for (int idx = t; idx < W; idx += nt)
-        if (idx > k && idx < w) Dg[idx * (W + 1) + k] /= dk;
-      __syncthreads();
-    }
-    // panel rows: Y L11^T = A21, L21 = Y D^-1
+    IPM_TICK(2);
+    // panel rows: Y^T = L11^-1 A^T (4 products with the accumulator as B operand), L21^T = D^-1 Y^T
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = t + h * nt, r = rr[h];
+    for (int i = 0; i < MT; ++i) {
+      if ((wv + 4 * i) * 16 >= rows) continue;
+      d4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * W + 4 * g + lq], acc[i][g], y, 0, 0, 0);
+      const int q = (wv + 4 * i) * 16 + lr, r = rrow[i];
       if (r < 0 || q < w) continue;
       const bool border = r >= G.Nb;
 #pragma unroll
-      for (int c = 0; c < W; ++c) {
-        double a = acc[h][c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) a = __builtin_fma(-acc[h][k], Dg[c * (W + 1) + k], a);
-        acc[h][c] = c < w ? a : 0.0;                       // y
-        const double l = c < w ? a / Dg[c * (W + 1) + c] : 0.0;
+      for (int g = 0; g < 4; ++g) {
+        const int c = lq + 4 * g;
+        const double l = y[g] * invd[c];
         if (c < w && (border || r - (J0 + c) <= G.b)) K[G.at(r, J0 + c)] = l;
-        if (border) { BL[(r - G.Nb) * W + c] = l; BY[(r - G.Nb) * W + c] = acc[h][c]; }
+        if (border) { BL[(r - G.Nb) * W + c] = l; BY[(r - G.Nb) * W + c] = c < w ? y[g] : 0.0; }
       }
     }
-    for (int idx = t; idx < W * W; idx += nt) {
-      const int di = idx / W, dj = idx % W;
+    {
+      const int di = t / W, dj = t % W;
       if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = Dg[di * (W + 1) + dj];
     }
     if (t < w) {
@@ -382,6 +449,7 @@ __global__ __launch_bounds__(256) void kkt_factor_kernel(double* Kall, long long
       if (!(fabs(dk) < 1e300)) ++nbad;
     }
     __syncthreads();
+    IPM_TICK(3);
     for (int idx = t; idx < nb * nb; idx += nt) {          // corner -= L_border D L_border^T of this block column
       const int r = idx / nb, c2 = idx % nb;
       if (r < c2) continue;
@@ -391,6 +459,7 @@ __global__ __launch_bounds__(256) void kkt_factor_kernel(double* Kall, long long
       C[idx] -= s;
     }
     __syncthreads();
+    IPM_TICK(4);
     J0 = J1;
   }
   for (int k = 0; k < nb; ++k) {                            // the corner, unblocked, in LDS
@@ -417,7 +486,13 @@ __global__ __launch_bounds__(256) void kkt_factor_kernel(double* Kall, long long
   if (nneg) atomicAdd(&cnt[1], nneg);
   if (nbad) atomicAdd(&cnt[2], nbad);
   __syncthreads();
-  if (t == 0) { S.npos = cnt[0]; S.nneg = cnt[1]; S.nbad = cnt[2]; }
+  IPM_TICK(5);
+  if (t == 0) {
+    S.npos = cnt[0]; S.nneg = cnt[1]; S.nbad = cnt[2];
+#ifdef IPM_TIMING
+    for (int i = 0; i < 6; ++i) S.dbg[i] = tc[i];
+#endif
+  }
 }
 
 // L y = r, then x = L^-T D^-1 y, in place in rhs (one workgroup per instance, IPM_W columns per step)
@@ -668,7 +743,7 @@ struct rpm_ipm {
   std::vector<void*> allocs;
   int* h_cnt = nullptr;           // page-locked mirror of D.cnt
   size_t factor_lds = 0;
-  int NRP = 0, factor_threads = 128;
+  int factor_mt = IPM_MT;
   std::string err;
   std::vector<IpmInst> h_inst;
   int total_factorizations = 0, total_iterations = 0, total_trials = 0;
@@ -721,9 +796,13 @@ int launch_check(rpm_ipm* h, const char* what) {
 }
 int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve, int check_status) {
   const IpmDev& D = h->D;
-  if (factor)
-    hipLaunchKernelGGL(kkt_factor_kernel, dim3(unsigned(D.B)), dim3(unsigned(h->factor_threads)), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan), D.inst,
-                       h->NRP);
+  if (factor) {
+    if (h->factor_mt == 4)
+      hipLaunchKernelGGL(kkt_factor_kernel<4>, dim3(unsigned(D.B)), dim3(256), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan), D.inst);
+    else
+      hipLaunchKernelGGL(kkt_factor_kernel<IPM_MT>, dim3(unsigned(D.B)), dim3(256), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan),
+                         D.inst);
+  }
   if (solve)
     hipLaunchKernelGGL(kkt_solve_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, geom_of(h->plan), D.inst, D.rhs,
                        check_status);
@@ -793,22 +872,20 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     if (hipMemcpy(D.vl, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(D.vu, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy"; return fail(RPM_E_DEVICE); }
   }
-  {
-    const int rows = IPM_W + p.b + p.nb;            // most rows a block column touches: two per thread
-    h->factor_threads = rows <= 256 ? 128 : 256;
-    if (rows > 512) {
-      h->err = "band + border of " + std::to_string(p.b + p.nb) + " rows exceeds the factorisation's 512 rows per block column";
-      return fail(RPM_E_UNSUPPORTED);
-    }
+  h->factor_mt = IPM_W + p.b + p.nb <= 256 ? 4 : IPM_MT;
+  if (IPM_W + p.b + p.nb > 4 * IPM_MT * 16) {
+    h->err = "band + border of " + std::to_string(p.b + p.nb) + " rows exceeds the factorisation's 512 rows per block column";
+    return fail(RPM_E_UNSUPPORTED);
   }
-  h->factor_lds = (size_t(p.b) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + 2 * size_t(p.nb) * IPM_W + size_t(p.nb) * p.nb) * sizeof(double);
+  h->factor_lds = (size_t(p.b + 8) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
+                   size_t(p.nb) * p.nb) * sizeof(double);
   if (h->factor_lds > 150 * 1024) {
     h->err = "band of " + std::to_string(p.b) + " and border of " + std::to_string(p.nb) + " rows do not fit the factorisation's LDS";
     return fail(RPM_E_UNSUPPORTED);
   }
   if (h->factor_lds > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          int(h->factor_lds)) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
+      hipFuncSetAttribute(h->factor_mt == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>) : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(h->factor_lds)) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
   h->h_inst.resize(B);
   *out = h;
   return RPM_OK;
@@ -882,6 +959,10 @@ int rpm_ipm_debug_solve(rpm_ipm* h, const double* k_storage, const double* rhs, 
   IPM_TRY(h, hipStreamSynchronize(st));
   IPM_TRY(h, hipMemcpy(sol, D.rhs, size_t(D.B) * p.Nt * sizeof(double), hipMemcpyDeviceToHost));
   IPM_TRY(h, hipMemcpy(inst.data(), D.inst, inst.size() * sizeof(IpmInst), hipMemcpyDeviceToHost));
+#ifdef IPM_TIMING
+  fprintf(stderr, "factor phases of instance 0 [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld\n",
+          inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[5]);
+#endif
   for (int bi = 0; bi < D.B; ++bi) {
     if (n_pos) n_pos[bi] = inst[bi].npos;
     if (n_neg) n_neg[bi] = inst[bi].nneg;
