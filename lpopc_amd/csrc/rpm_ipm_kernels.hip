@@ -439,9 +439,9 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(d
         if (border) { BL[(r - G.Nb) * W + c] = l; BY[(r - G.Nb) * W + c] = c < w ? y[g] : 0.0; }
       }
     }
-    {
+    {                           // the diagonal block is stored as d on the diagonal and L11^-1 below it (what the solves use)
       const int di = t / W, dj = t % W;
-      if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = Dg[di * (W + 1) + dj];
+      if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = di == dj ? Dg[di * (W + 1) + dj] : Mi[di * W + dj];
     }
     if (t < w) {
       const double dk = Dg[t * (W + 1) + t];
@@ -471,6 +471,25 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(d
     }
     __syncthreads();
     for (int r = k + 1 + t; r < nb; r += nt) C[r * nb + k] /= dk;
+  }
+  __syncthreads();
+  for (int idx = t; idx < nb; idx += nt) {                  // the corner's 16 x 16 diagonal sub-blocks: L -> L^-1, column by column
+    const int c0 = idx / W * W, cj = idx, w2 = min(W, nb - c0);
+    double x[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      double v = c0 + i == cj ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k)
+        if (i < w2 && c0 + k >= cj) v = __builtin_fma(-C[(c0 + i) * nb + c0 + k], x[k], v);
+      x[i] = c0 + i < cj ? 0.0 : v;
+    }
+    // in place: the 16 columns of a sub-block belong to 16 consecutive lanes of one wave, which has read all of them
+    // (the loop above) before any lane writes its column back
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+      if (i < w2 && c0 + i > cj) C[(c0 + i) * nb + cj] = x[i];
   }
   __syncthreads();
   for (int idx = t; idx < nb * nb; idx += nt) {
@@ -503,7 +522,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
   if (check_status && inst[bi].status != 0) return;
   const double* K = Kall + size_t(bi) * kstride;
   double* r = rhs_all + size_t(bi) * G.Nt;
-  __shared__ double Dg[W * (W + 1)], ys[W], red[4][W];
+  __shared__ double Dg[W * (W + 1)], ys[W], zs[W], red[4][W];     // Dg: d on the diagonal, L11^-1 below it
   const int di = t / W, dj = t % W;
   const int nbb = (G.Nb + W - 1) / W, ncb = (G.nb + W - 1) / W;
   for (int blk = 0; blk < nbb + ncb; ++blk) {
@@ -512,20 +531,23 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     block_range(G, J0, &J1, &nrb, &nr);
     const int w = J1 - J0;
     if (di < w && dj <= di) Dg[di * (W + 1) + dj] = K[G.at(J0 + di, J0 + dj)];
+    if (t < W) zs[t] = t < w ? r[J0 + t] : 0.0;
     __syncthreads();
-    if (t == 0)
-      for (int c = 0; c < w; ++c) {
-        double y = r[J0 + c];
-        for (int k = 0; k < c; ++k) y -= Dg[c * (W + 1) + k] * ys[k];
-        ys[c] = y;
-        r[J0 + c] = y;
-      }
+    if (t < W) {                // y = L11^-1 r: 16 lanes, one row each
+      double y = zs[t];
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+        if (k < t && t < w) y = __builtin_fma(Dg[t * (W + 1) + k], zs[k], y);
+      ys[t] = y;
+      if (t < w) r[J0 + t] = y;
+    }
     __syncthreads();
     for (int q = t; q < nr; q += blockDim.x) {
       const int row = panel_row(G, J0, J1, nrb, q);
       double acc = 0.0;
-      for (int c = 0; c < w; ++c)
-        if (row >= G.Nb || row - (J0 + c) <= G.b) acc = __builtin_fma(K[G.at(row, J0 + c)], ys[c], acc);
+#pragma unroll
+      for (int c = 0; c < W; ++c)
+        if (c < w && (row >= G.Nb || row - (J0 + c) <= G.b)) acc = __builtin_fma(K[G.at(row, J0 + c)], ys[c], acc);
       r[row] -= acc;
     }
     __syncthreads();
@@ -548,18 +570,20 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     }
 #pragma unroll
     for (int c = 0; c < W; ++c) {
-      double s = p[c];
-      for (int o = 32; o; o >>= 1) s += __shfl_down(s, o);
-      if ((t & 63) == 0) red[t >> 6][c] = s;
+      double sacc = p[c];
+      for (int o = 32; o; o >>= 1) sacc += __shfl_down(sacc, o);
+      if ((t & 63) == 0) red[t >> 6][c] = sacc;
     }
     __syncthreads();
-    if (t == 0)
-      for (int c = w - 1; c >= 0; --c) {
-        double x = r[J0 + c] / Dg[c * (W + 1) + c] - (red[0][c] + red[1][c] + red[2][c] + red[3][c]);
-        for (int k = c + 1; k < w; ++k) x -= Dg[k * (W + 1) + c] * ys[k];
-        ys[c] = x;
-        r[J0 + c] = x;
-      }
+    if (t < W) zs[t] = t < w ? r[J0 + t] / Dg[t * (W + 1) + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]) : 0.0;
+    __syncthreads();
+    if (t < w) {                // x = L11^-T z
+      double x = zs[t];
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+        if (k > t && k < w) x = __builtin_fma(Dg[k * (W + 1) + t], zs[k], x);
+      r[J0 + t] = x;
+    }
     __syncthreads();
   }
 }
