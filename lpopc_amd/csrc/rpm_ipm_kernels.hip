@@ -514,60 +514,93 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(d
   }
 }
 
-// L y = r, then x = L^-T D^-1 y, in place in rhs (one workgroup per instance, IPM_W columns per step)
+// L y = r, then x = L^-T D^-1 y, in place in rhs: one workgroup per instance, IPM_W columns per step.  The diagonal
+// blocks hold L11^-1, so a step's own 16 unknowns are 16 parallel dot products.  The right-hand side lives in LDS when it
+// fits (RL); the diagonal block and each thread's panel row of the NEXT step are fetched while the current one is worked.
+template <bool RL>
 __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long long kstride, KktGeom G, const IpmInst* inst,
                                                         double* rhs_all, int check_status) {
   constexpr int W = IPM_W;
-  const int bi = blockIdx.x, t = threadIdx.x;
+  const int bi = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   if (check_status && inst[bi].status != 0) return;
   const double* K = Kall + size_t(bi) * kstride;
-  double* r = rhs_all + size_t(bi) * G.Nt;
+  double* rg = rhs_all + size_t(bi) * G.Nt;
+  extern __shared__ double rsh[];
+  double* r = RL ? rsh : rg;
   __shared__ double Dg[W * (W + 1)], ys[W], zs[W], red[4][W];     // Dg: d on the diagonal, L11^-1 below it
   const int di = t / W, dj = t % W;
-  const int nbb = (G.Nb + W - 1) / W, ncb = (G.nb + W - 1) / W;
-  for (int blk = 0; blk < nbb + ncb; ++blk) {
-    const int J0 = blk < nbb ? blk * W : G.Nb + (blk - nbb) * W;
-    int J1, nrb, nr;
-    block_range(G, J0, &J1, &nrb, &nr);
-    const int w = J1 - J0;
-    if (di < w && dj <= di) Dg[di * (W + 1) + dj] = K[G.at(J0 + di, J0 + dj)];
-    if (t < W) zs[t] = t < w ? r[J0 + t] : 0.0;
+  const int nbb = (G.Nb + W - 1) / W, ncb = (G.nb + W - 1) / W, nblk = nbb + ncb;
+  if (RL) {
+    for (int i = t; i < G.Nt; i += nt) rsh[i] = rg[i];
+    __syncthreads();
+  }
+  struct Blk { int J0, J1, nrb, nr, w; };
+  auto blk_of = [&](int blk) {
+    Blk B;
+    B.J0 = blk < nbb ? blk * W : G.Nb + (blk - nbb) * W;
+    block_range(G, B.J0, &B.J1, &B.nrb, &B.nr);
+    B.w = B.J1 - B.J0;
+    return B;
+  };
+  // this thread's share of a step: one entry of the diagonal block and the 16 factor entries of panel row q = t
+  auto fetch = [&](int blk, double& dg, double (&l)[W]) {
+    if (blk < 0 || blk >= nblk) return;
+    const Blk B = blk_of(blk);
+    dg = (di < B.w && dj <= di) ? K[G.at(B.J0 + di, B.J0 + dj)] : 0.0;
+    const int row = t < B.nr ? panel_row(G, B.J0, B.J1, B.nrb, t) : -1;
+#pragma unroll
+    for (int c = 0; c < W; ++c)
+      l[c] = (row >= 0 && c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0;
+  };
+  double dg, l[W], dgn = 0.0, ln[W];
+  fetch(0, dg, l);
+  for (int blk = 0; blk < nblk; ++blk) {
+    const Blk B = blk_of(blk);
+    if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
+    if (t < W) zs[t] = t < B.w ? r[B.J0 + t] : 0.0;
+    fetch(blk + 1, dgn, ln);
     __syncthreads();
     if (t < W) {                // y = L11^-1 r: 16 lanes, one row each
       double y = zs[t];
 #pragma unroll
       for (int k = 0; k < W; ++k)
-        if (k < t && t < w) y = __builtin_fma(Dg[t * (W + 1) + k], zs[k], y);
+        if (k < t && t < B.w) y = __builtin_fma(Dg[t * (W + 1) + k], zs[k], y);
       ys[t] = y;
-      if (t < w) r[J0 + t] = y;
+      if (t < B.w) r[B.J0 + t] = y;
     }
     __syncthreads();
-    for (int q = t; q < nr; q += blockDim.x) {
-      const int row = panel_row(G, J0, J1, nrb, q);
+    for (int q = t; q < B.nr; q += nt) {
+      const int row = panel_row(G, B.J0, B.J1, B.nrb, q);
       double acc = 0.0;
 #pragma unroll
-      for (int c = 0; c < W; ++c)
-        if (c < w && (row >= G.Nb || row - (J0 + c) <= G.b)) acc = __builtin_fma(K[G.at(row, J0 + c)], ys[c], acc);
+      for (int c = 0; c < W; ++c) {
+        const double lv = q == t ? l[c] : ((c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0);
+        acc = __builtin_fma(lv, ys[c], acc);
+      }
       r[row] -= acc;
     }
     __syncthreads();
+    dg = dgn;
+#pragma unroll
+    for (int c = 0; c < W; ++c) l[c] = ln[c];
   }
-  for (int blk = nbb + ncb - 1; blk >= 0; --blk) {
-    const int J0 = blk < nbb ? blk * W : G.Nb + (blk - nbb) * W;
-    int J1, nrb, nr;
-    block_range(G, J0, &J1, &nrb, &nr);
-    const int w = J1 - J0;
-    if (di < w && dj <= di) Dg[di * (W + 1) + dj] = K[G.at(J0 + di, J0 + dj)];
+  fetch(nblk - 1, dg, l);
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+    const Blk B = blk_of(blk);
+    if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     double p[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) p[c] = 0.0;
-    for (int q = t; q < nr; q += blockDim.x) {
-      const int row = panel_row(G, J0, J1, nrb, q);
+    for (int q = t; q < B.nr; q += nt) {
+      const int row = panel_row(G, B.J0, B.J1, B.nrb, q);
       const double xr = r[row];
 #pragma unroll
-      for (int c = 0; c < W; ++c)
-        if (c < w && (row >= G.Nb || row - (J0 + c) <= G.b)) p[c] = __builtin_fma(K[G.at(row, J0 + c)], xr, p[c]);
+      for (int c = 0; c < W; ++c) {
+        const double lv = q == t ? l[c] : ((c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0);
+        p[c] = __builtin_fma(lv, xr, p[c]);
+      }
     }
+    fetch(blk - 1, dgn, ln);
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       double sacc = p[c];
@@ -575,17 +608,22 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       if ((t & 63) == 0) red[t >> 6][c] = sacc;
     }
     __syncthreads();
-    if (t < W) zs[t] = t < w ? r[J0 + t] / Dg[t * (W + 1) + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]) : 0.0;
+    if (t < W) zs[t] = t < B.w ? r[B.J0 + t] / Dg[t * (W + 1) + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]) : 0.0;
     __syncthreads();
-    if (t < w) {                // x = L11^-T z
+    if (t < B.w) {              // x = L11^-T z
       double x = zs[t];
 #pragma unroll
       for (int k = 0; k < W; ++k)
-        if (k > t && k < w) x = __builtin_fma(Dg[k * (W + 1) + t], zs[k], x);
-      r[J0 + t] = x;
+        if (k > t && k < B.w) x = __builtin_fma(Dg[k * (W + 1) + t], zs[k], x);
+      r[B.J0 + t] = x;
     }
     __syncthreads();
+    dg = dgn;
+#pragma unroll
+    for (int c = 0; c < W; ++c) l[c] = ln[c];
   }
+  if (RL)
+    for (int i = t; i < G.Nt; i += nt) rg[i] = rsh[i];
 }
 
 // ------------------------------------------------------------------------------------------------ inertia correction
@@ -827,9 +865,14 @@ int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve,
       hipLaunchKernelGGL(kkt_factor_kernel<IPM_MT>, dim3(unsigned(D.B)), dim3(256), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan),
                          D.inst);
   }
-  if (solve)
-    hipLaunchKernelGGL(kkt_solve_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, geom_of(h->plan), D.inst, D.rhs,
-                       check_status);
+  if (solve) {
+    if (size_t(D.Nt) * sizeof(double) <= 48 * 1024)
+      hipLaunchKernelGGL(kkt_solve_kernel<true>, dim3(unsigned(D.B)), dim3(256), size_t(D.Nt) * sizeof(double), st, D.K, D.kstride,
+                         geom_of(h->plan), D.inst, D.rhs, check_status);
+    else
+      hipLaunchKernelGGL(kkt_solve_kernel<false>, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, geom_of(h->plan), D.inst, D.rhs,
+                         check_status);
+  }
   return launch_check(h, "kkt kernels");
 }
 }  // namespace
