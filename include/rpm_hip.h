@@ -222,7 +222,7 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  * "instance_align" before rpm_ipm_create.
  *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
  *                       "delta_c" (1e-8, constraint regularisation that makes the pivot-free LDL^T well defined),
- *                       "max_line_search" (40)
+ *                       "max_line_search" (40), "trace" (0; keep the first N accepted steps of every instance)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,
@@ -239,6 +239,9 @@ int rpm_ipm_set_bounds(rpm_ipm* s, int instance, const double* x_l, const double
 int rpm_ipm_get_info(rpm_ipm* s, int* kkt_order, int* band_order, int* half_bandwidth, int* border,
                      long long* storage_doubles, int* n_slacks);
 int rpm_ipm_get_stats(rpm_ipm* s, int* iterations, int* factorizations, int* trial_points);
+/* records of the last solve when option "trace" > 0: 8 doubles per accepted step — f, theta = |c|_1, mu, alpha, alpha_z,
+ * delta_w, E_0 at the step's start, backtracking steps */
+int rpm_ipm_get_trace(rpm_ipm* s, int instance, int capacity, double* records, int* n_records);
 int rpm_ipm_solve(rpm_ipm* s, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error);
 int rpm_ipm_solve_dev(rpm_ipm* s, double* d_x, double* d_lambda, double* obj, int* status, int* iterations,
                       double* kkt_error);

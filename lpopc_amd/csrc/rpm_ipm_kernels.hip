@@ -21,6 +21,7 @@ namespace rpm {
 
 constexpr int IPM_W = 16;        // block width of the factorisation
 constexpr int IPM_FMAX = 256;    // filter entries kept per instance
+constexpr int IPM_TRACE = 8;     // doubles per trace record: f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks
 constexpr double IPM_INF = 1e19; // Ipopt's nlp_lower_bound_inf / nlp_upper_bound_inf
 
 struct IpmOpts {
@@ -49,6 +50,8 @@ struct IpmDev {
   // per-instance state
   double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
   double *xe, *xt, *grad, *g, *jac, *hess, *obj, *gt, *objt;
+  double* trace;   // per instance trace_cap records of IPM_TRACE doubles (one per accepted step), or NULL
+  int trace_cap;
   IpmInst* inst;
   int* cnt;     // [0] running, [1] to refactor, [2] line searches pending
   IpmOpts o;
@@ -787,6 +790,10 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
       F[2 * S.nfilt + 1] = S.phi - D.o.gamma_phi * S.theta;
       S.nfilt += 1;
     }
+    if (D.trace && S.iter < D.trace_cap) {
+      double* R = D.trace + (size_t(bi) * D.trace_cap + S.iter) * IPM_TRACE;
+      R[0] = S.f; R[1] = S.theta; R[2] = S.mu; R[3] = S.alpha; R[4] = S.alpha_z; R[5] = S.delta_w; R[6] = S.err0; R[7] = double(S.ls);
+    }
     S.iter += 1;
   }
 }
@@ -972,6 +979,17 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "bound_frac") o.bound_frac = value;
   else if (k == "delta_c") o.delta_c = value;
   else if (k == "max_line_search") o.max_ls = int(value);
+  else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
+    const int cap = int(value);
+    if (cap < 0 || cap > 100000) { h->err = "trace: 0 ... 100000 records"; return RPM_E_INVALID; }
+    h->D.trace = nullptr;
+    h->D.trace_cap = 0;
+    if (cap > 0) {
+      int rc = ipm_alloc(h, &h->D.trace, size_t(h->D.B) * cap * IPM_TRACE);
+      if (rc) return rc;
+      h->D.trace_cap = cap;
+    }
+  }
   else { h->err = "unknown option " + k; return RPM_E_INVALID; }
   return RPM_OK;
 }
@@ -993,6 +1011,16 @@ int rpm_ipm_get_stats(rpm_ipm* h, int* iterations, int* factorizations, int* tri
   if (iterations) *iterations = h->total_iterations;
   if (factorizations) *factorizations = h->total_factorizations;
   if (trial_points) *trial_points = h->total_trials;
+  return RPM_OK;
+}
+
+int rpm_ipm_get_trace(rpm_ipm* h, int instance, int capacity, double* records, int* n_records) {
+  if (!h || instance < 0 || instance >= h->D.B || !records || !n_records) return RPM_E_INVALID;
+  if (!h->D.trace || h->h_inst.empty()) { *n_records = 0; return RPM_OK; }
+  const int n = std::min(std::min(h->h_inst[instance].iter, h->D.trace_cap), capacity);
+  IPM_TRY(h, hipMemcpy(records, h->D.trace + size_t(instance) * h->D.trace_cap * IPM_TRACE, size_t(n) * IPM_TRACE * sizeof(double),
+                       hipMemcpyDeviceToHost));
+  *n_records = n;
   return RPM_OK;
 }
 

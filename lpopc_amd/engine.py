@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
     "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_get_info",
-    "rpm_ipm_get_stats", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
+    "rpm_ipm_get_stats", "rpm_ipm_get_trace", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.rpm_ipm_set_bounds.argtypes = [vp, C.c_int, dp, dp]
     L.rpm_ipm_get_info.argtypes = [vp, ip, ip, ip, ip, C.POINTER(C.c_longlong), ip]
     L.rpm_ipm_get_stats.argtypes = [vp, ip, ip, ip]
+    L.rpm_ipm_get_trace.argtypes = [vp, C.c_int, C.c_int, dp, ip]
     L.rpm_ipm_solve.argtypes = [vp, dp, dp, dp, ip, ip, dp]
     L.rpm_ipm_solve_dev.argtypes = [vp, vp, vp, dp, ip, ip, dp]
     L.rpm_ipm_get_permutation.argtypes = [vp, ip, C.c_int]
@@ -460,6 +461,13 @@ class BatchedIPM:
         a = [C.c_int() for _ in range(3)]
         self._chk(self._L.rpm_ipm_get_stats(self._h, C.byref(a[0]), C.byref(a[1]), C.byref(a[2])))
         return {"iterations": a[0].value, "factorizations": a[1].value, "trial_points": a[2].value}
+
+    def trace(self, instance, capacity=4096):
+        """Accepted steps of the last solve (option trace > 0): rows of f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks."""
+        rec = np.zeros((capacity, 8))
+        n = C.c_int()
+        self._chk(self._L.rpm_ipm_get_trace(self._h, int(instance), capacity, _dp(rec), C.byref(n)))
+        return rec[:n.value].copy()
 
     def permutation(self):
         nt = self.info()["kkt_order"]

@@ -146,7 +146,7 @@ def test_device_solve_against_restatement(built, name, make, B, pert, same_path)
     x0 = np.tile(o.starting_point(), (B, 1))
     if pert:
         x0 = x0 * (1 + pert * np.random.RandomState(1).uniform(-1, 1, size=x0.shape))
-    ipm = BatchedIPM(eng, max_iter=400)
+    ipm = BatchedIPM(eng, max_iter=400, trace=400)
     r = ipm.solve(x0)
     for bi in range(B):
         ref = ipm_oracle.solve(o, x0[bi], max_iter=400)
@@ -157,6 +157,22 @@ def test_device_solve_against_restatement(built, name, make, B, pert, same_path)
             assert abs(int(r["iterations"][bi]) - ref["iterations"]) <= 1      # a barrier update decided at rounding level may shift by one
             assert np.max(np.abs(r["x"][bi] - ref["x"])) <= 1e-6 * max(1.0, np.max(np.abs(ref["x"])))
             assert np.max(np.abs(r["lambda"][bi] - ref["lambda"])) <= 1e-5 * max(1.0, np.max(np.abs(ref["lambda"])))
+            # step by step, while both are on the same path (a decision taken at rounding level may part them late): same
+            # barrier parameter, inertia corrections and backtracking counts.  The first step uses lambda = 0, so its
+            # Hessian is the objective's alone and everything agrees to rounding; from the second step on the constraint
+            # Hessians enter — second differences whose CPU and GPU values differ by 1e-9 (polynomial dynamics) to 1e-3
+            # (libm calls, HESS_CASES in test_gpu_parity.py) — and the two Newton paths run ~1e-4 apart to the same optimum
+            tr = ipm.trace(bi)
+            same = min(len(tr), len(ref["trace"]), 5)
+            assert same >= min(5, ref["iterations"])
+            for k in range(same):
+                e = ref["trace"][k]
+                rel, ab = (1e-8, 1e-6) if k == 0 else (1e-2, 1e-2)
+                assert abs(tr[k, 2] - e["mu"]) <= 1e-12 * e["mu"] and abs(tr[k, 5] - e["delta_w"]) <= 1e-12 * e["delta_w"], (k, tr[k], e)
+                assert int(tr[k, 7]) == e["ls"], (k, tr[k], e)
+                assert abs(tr[k, 0] - e["f"]) <= rel * max(1.0, abs(e["f"])), (k, tr[k], e)
+                assert abs(tr[k, 1] - e["theta"]) <= rel * max(1.0, e["theta"]), (k, tr[k], e)
+                assert abs(tr[k, 3] - e["alpha"]) <= ab and abs(tr[k, 4] - e["alpha_z"]) <= ab, (k, tr[k], e)
     # every instance satisfies its bounds and constraints
     xl, xu, gl, gu = o.bounds()
     for bi in range(B):
