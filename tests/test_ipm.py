@@ -301,3 +301,23 @@ def test_climb_at_the_reference_tolerance_and_delta3_verdict(built):
         assert r["kkt_error"][0] > 1e-8 and np.isfinite(r["x"]).all()
     ipm.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_reference_hypersensitive_example_end_to_end_on_the_device(built):
+    """example/hypersensitive/HyperSensitive.cpp:17-57 as shipped: tf = 5000, hessian-approximation=exact,
+    first-derive=analytic, mesh-refine-methods=hp-Liu, max-grid-num=20.  Every mesh's NLP is solved by rpm_ipm_*; the loop
+    ends by itself (NoMoreRefine) at the turnpike cost V(1.5) + W(1) of the infinite-horizon problem."""
+    from scipy.integrate import quad
+    from lpopc_amd.application import LpopcApplication, console_not_print
+    V = quad(lambda x: -x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.5)[0]
+    W = quad(lambda x: x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.0)[0]
+    app = LpopcApplication(console_not_print)
+    app.SetOptimalControlProblem(problems.hypersensitive())
+    app.Options().SetStringValue("hessian-approximation", "exact")
+    app.Options().SetStringValue("first-derive", "analytic")
+    app.Options().SetStringValue("mesh-refine-methods", "hp-Liu")
+    app.Options().SetIntegerValue("max-grid-num", 20)
+    assert app.SolveOptimalProblem(device=0) is True
+    assert abs(app.objective - (V + W)) < 1e-5
+    assert 3 <= app.meshrefiner_.CurrentGrid() < 20
