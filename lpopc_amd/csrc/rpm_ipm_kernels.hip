@@ -45,7 +45,7 @@ struct IpmDev {
   int B, n, m, ns, nv, Nt, Nb, nb, b, CS, nnz_jac, nnz_h;
   long long sg, sv, kstride;
   // plan tables
-  const int *pos, *row_slack, *slack_row, *fixed, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
+  const int *pos, *row_slack, *slack_row, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
   const double *gl, *gu;
   // per-instance state
   double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
@@ -923,7 +923,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   auto fail = [&](int code) { e.err = "rpm_ipm_create: " + h->err; delete h; return code; };
 #define A_(call) do { int _r = (call); if (_r) return fail(_r); } while (0)
   A_(ipm_alloc_c(h, &D.pos, p.pos)); A_(ipm_alloc_c(h, &D.row_slack, p.row_slack)); A_(ipm_alloc_c(h, &D.slack_row, p.slack_row));
-  A_(ipm_alloc_c(h, &D.fixed, p.fixed)); A_(ipm_alloc_c(h, &D.jac_dst, p.jac_dst)); A_(ipm_alloc_c(h, &D.hes_dst, p.hes_dst));
+  A_(ipm_alloc_c(h, &D.jac_dst, p.jac_dst)); A_(ipm_alloc_c(h, &D.hes_dst, p.hes_dst));
   A_(ipm_alloc_c(h, &D.diag_dst, p.diag_dst)); A_(ipm_alloc_c(h, &D.slk_dst, p.slk_dst)); A_(ipm_alloc_c(h, &D.jt_ptr, p.jt_ptr));
   A_(ipm_alloc_c(h, &D.jt_ent, p.jt_ent)); A_(ipm_alloc_c(h, &D.jt_row, p.jt_row));
   A_(ipm_alloc_c(h, &D.gl, e.gl)); A_(ipm_alloc_c(h, &D.gu, e.gu));

@@ -321,3 +321,28 @@ def test_reference_hypersensitive_example_end_to_end_on_the_device(built):
     assert app.SolveOptimalProblem(device=0) is True
     assert abs(app.objective - (V + W)) < 1e-5
     assert 3 <= app.meshrefiner_.CurrentGrid() < 20
+
+
+TINY = [("brachistochrone_1x10_config1", lambda: problems.brachistochrone(1, 10)), ("brachistochrone_1x3", lambda: problems.brachistochrone(1, 3)),
+        ("bryson_denham_1x4", lambda: problems.bryson_denham(1, 4)), ("hypersensitive_1x3", lambda: problems.hypersensitive([-1, 1], [3], tf=10.0)),
+        ("hypersensitive_ragged", lambda: problems.hypersensitive([-1, -0.9, 0.0, 0.2, 1], [3, 12, 2, 7], tf=40.0)),
+        ("quadrotor_1x2", lambda: problems.quadrotor(1, 2))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", TINY, ids=[c[0] for c in TINY])
+def test_tiny_and_ragged_layouts(built, name, make):
+    """Bands narrower than a 16-column block, a band shorter than its width, ragged hp meshes, BASELINE config 1."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = make()
+    eng = NLPEngine(prob, _exact(), n_instances=2, device=0)
+    o = orc.Oracle(prob, _exact())
+    ipm = BatchedIPM(eng, max_iter=200)
+    r = ipm.solve(np.tile(o.starting_point(), (2, 1)))
+    ref = ipm_oracle.solve(o, o.starting_point(), max_iter=200)
+    assert (r["status"] == 0).all() and ref["status"] == 0
+    assert (np.abs(r["iterations"] - ref["iterations"]) <= 1).all()
+    assert np.max(np.abs(r["obj"] - ref["obj"])) <= 1e-8 * max(1.0, abs(ref["obj"]))
+    assert np.array_equal(r["x"][0], r["x"][1])                 # identical instances take identical paths
+    ipm.close()
+    eng.close()
