@@ -222,7 +222,8 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  * "instance_align" before rpm_ipm_create.
  *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
  *                       "delta_c" (1e-8, constraint regularisation that makes the pivot-free LDL^T well defined),
- *                       "max_line_search" (40), "trace" (0; keep the first N accepted steps of every instance)
+ *                       "max_line_search" (40), "trace" (0; keep the first N accepted steps of every instance),
+ *                       "restoration" (1), "restoration_max_iter" (60)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,
@@ -242,6 +243,12 @@ int rpm_ipm_get_stats(rpm_ipm* s, int* iterations, int* factorizations, int* tri
 /* records of the last solve when option "trace" > 0: 8 doubles per accepted step — f, theta = |c|_1, mu, alpha, alpha_z,
  * delta_w, E_0 at the step's start, backtracking steps */
 int rpm_ipm_get_trace(rpm_ipm* s, int instance, int capacity, double* records, int* n_records);
+/* feasibility restorations each instance went through in the last solve (option "restoration", default 1: when the line
+ * search gives up at an infeasible point — where Ipopt enters its restoration phase — damped Gauss-Newton steps on
+ * 1/2|c|^2 + zeta/2 |D_R (v - v_R)|^2 inside the bounds, from the same KKT kernels with W = zeta D_R^2 + mu/s^2 and -I in
+ * the constraint block, until the infeasibility is 0.9 of where it started and the filter accepts the point; simpler than
+ * Ipopt's l1 restoration NLP) */
+int rpm_ipm_get_restorations(rpm_ipm* s, int* per_instance);
 int rpm_ipm_solve(rpm_ipm* s, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error);
 int rpm_ipm_solve_dev(rpm_ipm* s, double* d_x, double* d_lambda, double* obj, int* status, int* iterations,
                       double* kkt_error);

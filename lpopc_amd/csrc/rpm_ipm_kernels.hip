@@ -31,6 +31,8 @@ struct IpmOpts {
   double delta_c = 1e-8, delta_w_first = 1e-4, delta_w_min = 1e-20, delta_w_max = 1e40, kw_inc_first = 100.0, kw_inc = 8.0,
          kw_dec = 1.0 / 3.0;
   int max_iter = 3000, max_ls = 40;
+  int resto = 1, resto_max = 60;     // Gauss-Newton feasibility restoration after a failed line search
+  double kappa_resto = 0.9;
 };
 
 struct IpmInst {
@@ -38,6 +40,8 @@ struct IpmInst {
   double delta_w, delta_w_last, alpha_max, alpha_z, alpha, alpha_min, dphi, phi, theta_max, theta_min;
   int status;   // 0 running, 1 converged, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
   int iter, nfilt, accepted, refactor, npos, nneg, nbad, ls, armijo, nzb, pad;
+  int mode, resto_it, enter_resto, n_resto;   // mode 1: feasibility restoration
+  double th0, zeta, psi, slope;
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 
@@ -50,6 +54,7 @@ struct IpmDev {
   // per-instance state
   double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
   double *xe, *xt, *grad, *g, *jac, *hess, *obj, *gt, *objt;
+  double *vR, *dr2;   // restoration: reference point and D_R^2 = 1 / max(1, |v_R|)^2
   double* trace;   // per instance trace_cap records of IPM_TRACE doubles (one per accepted step), or NULL
   int trace_cap;
   IpmInst* inst;
@@ -146,6 +151,68 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmDev D) {
   const double *jac = D.jac + size_t(bi) * D.sv, *g = D.g + size_t(bi) * D.sg, *grad = D.grad + size_t(bi) * D.n;
   double* glag = D.glag + size_t(bi) * D.nv;
   double dinf = 0, cinf = 0, th1 = 0, cmax = 0, cmin = 1e300, sl = 0, sz = 0, ln = 0, bad = 0, nzb = 0;
+  // pass 1: constraint values and what does not depend on the multipliers
+  double csq = 0, qd = 0;
+  for (int r = t; r < D.m; r += blockDim.x) {
+    const int s = D.row_slack[r];
+    const double cr = s < 0 ? g[r] - D.gl[r] : g[r] - v[D.n + s];
+    D.c[size_t(bi) * D.m + r] = cr;
+    if (!(fabs(cr) < 1e300)) bad = 1;
+    cinf = fmax(cinf, fabs(cr));
+    th1 += fabs(cr);
+    csq += cr * cr;
+  }
+  cinf = block_red(cinf, 1, sh); th1 = block_red(th1, 0, sh);
+  __shared__ int verdict;       // restoration: 0 stay, 1 back to the regular iteration, 2 stop
+  const int mode_in = S.mode;
+  if (mode_in == 1) {
+    const double *vR = D.vR + size_t(bi) * D.nv, *dr2 = D.dr2 + size_t(bi) * D.nv;
+    for (int i = t; i < D.nv; i += blockDim.x) {
+      const double l = vl[i], u = vu[i];
+      if (l == u) continue;
+      if (l > -IPM_INF) ln += log(v[i] - l);
+      if (u < IPM_INF) ln += log(u - v[i]);
+      const double dd = v[i] - vR[i];
+      qd += dr2[i] * dd * dd;
+    }
+    csq = block_red(csq, 0, sh); ln = block_red(ln, 0, sh); qd = block_red(qd, 0, sh); bad = block_red(bad, 1, sh);
+    if (t == 0) {
+      const IpmOpts& o = D.o;
+      const double f = D.obj[bi], phi = f - S.mu * ln;
+      verdict = 0;
+      if (bad != 0 || !(fabs(f) < 1e300) || !(fabs(ln) < 1e300)) { S.status = 5; verdict = 2; }
+      else {
+        bool back = S.resto_it > 0 && th1 <= o.kappa_resto * S.th0 && th1 <= S.theta_max;
+        const double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
+        for (int k = 0; back && k < S.nfilt; ++k)
+          if (th1 >= F[2 * k] && phi >= F[2 * k + 1]) back = false;
+        if (back) verdict = 1;
+        else if (S.resto_it >= o.resto_max || S.iter >= o.max_iter) { S.status = S.iter >= o.max_iter ? 2 : 3; verdict = 2; }
+        else {
+          S.f = f; S.theta = th1; S.lnsum = ln; S.cinf = cinf;
+          S.psi = 0.5 * csq + 0.5 * S.zeta * qd - S.mu * ln;
+          S.refactor = 1;
+          S.delta_w = 0.0;
+          atomicAdd(&D.cnt[0], 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (verdict != 1) return;
+    // back to the regular iteration: lambda = 0, bound multipliers clipped (as after Ipopt's restoration)
+    for (int r = t; r < D.m; r += blockDim.x) D.lam[size_t(bi) * D.m + r] = 0.0;
+    for (int i = t; i < D.nv; i += blockDim.x) {
+      const double l = vl[i], u = vu[i];
+      if (l == u) continue;
+      const size_t o2 = size_t(bi) * D.nv + i;
+      if (l > -IPM_INF) { const double sl2 = v[i] - l; D.zL[o2] = fmax(fmin(fmin(D.zL[o2], 1e3), D.o.kappa_sigma * S.mu / sl2), S.mu / (D.o.kappa_sigma * sl2)); }
+      if (u < IPM_INF) { const double su2 = u - v[i]; D.zU[o2] = fmax(fmin(fmin(D.zU[o2], 1e3), D.o.kappa_sigma * S.mu / su2), S.mu / (D.o.kappa_sigma * su2)); }
+    }
+    if (t == 0) { S.mode = 0; S.n_resto += 1; }
+    __syncthreads();
+    ln = 0; bad = 0;
+  }
+  // pass 2: gradient of the Lagrangian, complementarity products
   for (int i = t; i < D.nv; i += blockDim.x) {
     double acc;
     if (i < D.n) {
@@ -169,16 +236,8 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmDev D) {
       }
     }
   }
-  for (int r = t; r < D.m; r += blockDim.x) {
-    const int s = D.row_slack[r];
-    const double cr = s < 0 ? g[r] - D.gl[r] : g[r] - v[D.n + s];
-    D.c[size_t(bi) * D.m + r] = cr;
-    if (!(fabs(cr) < 1e300)) bad = 1;
-    cinf = fmax(cinf, fabs(cr));
-    th1 += fabs(cr);
-    sl += fabs(lam[r]);
-  }
-  dinf = block_red(dinf, 1, sh); cinf = block_red(cinf, 1, sh); th1 = block_red(th1, 0, sh);
+  for (int r = t; r < D.m; r += blockDim.x) sl += fabs(lam[r]);
+  dinf = block_red(dinf, 1, sh);
   cmax = block_red(cmax, 1, sh); cmin = block_red(cmin, 2, sh); sl = block_red(sl, 0, sh); sz = block_red(sz, 0, sh);
   ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh); nzb = block_red(nzb, 0, sh);
   if (t != 0) return;
@@ -231,8 +290,10 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
   const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int k = t0; k < D.nnz_h; k += stride)
-    if (D.hes_dst[k] >= 0) unsafeAtomicAdd(&K[D.hes_dst[k]], D.hess[size_t(bi) * D.nnz_h + k]);
+  const bool resto = S.mode == 1;      // restoration: W = zeta D_R^2 + mu / s^2, -I in the constraint block, no Hessian
+  if (!resto)
+    for (int k = t0; k < D.nnz_h; k += stride)
+      if (D.hes_dst[k] >= 0) unsafeAtomicAdd(&K[D.hes_dst[k]], D.hess[size_t(bi) * D.nnz_h + k]);
   for (int k = t0; k < D.nnz_jac; k += stride)
     if (D.jac_dst[k] >= 0) K[D.jac_dst[k]] = D.jac[size_t(bi) * D.sv + k];
   for (int s = t0; s < D.ns; s += stride) K[D.slk_dst[s]] = -1.0;
@@ -240,17 +301,23 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   for (int i = t0; i < D.nv; i += stride) {
     const double l = vl[i], u = vu[i];
     double diag = 1.0, r = 0.0;
-    if (l != u) {
+    if (l != u && !resto) {
       diag = S.delta_w;
       r = D.glag[size_t(bi) * D.nv + i];
       if (l > -IPM_INF) { const double d = v[i] - l; diag += zL[i] / d; r -= S.mu / d; }
       if (u < IPM_INF) { const double d = u - v[i]; diag += zU[i] / d; r += S.mu / d; }
+    } else if (l != u) {
+      const double w2 = S.zeta * D.dr2[size_t(bi) * D.nv + i];
+      diag = S.delta_w + w2;
+      r = w2 * (v[i] - D.vR[size_t(bi) * D.nv + i]);
+      if (l > -IPM_INF) { const double d = v[i] - l; diag += S.mu / (d * d); r -= S.mu / d; }
+      if (u < IPM_INF) { const double d = u - v[i]; diag += S.mu / (d * d); r += S.mu / d; }
     }
     unsafeAtomicAdd(&K[D.diag_dst[i]], diag);
     rhs[D.pos[i]] = -r;
   }
   for (int r = t0; r < D.m; r += stride) {
-    K[D.diag_dst[D.nv + r]] = -D.o.delta_c;
+    K[D.diag_dst[D.nv + r]] = resto ? -1.0 : -D.o.delta_c;
     rhs[D.pos[D.nv + r]] = -D.c[size_t(bi) * D.m + r];
   }
 }
@@ -658,6 +725,36 @@ __global__ __launch_bounds__(256) void ipm_direction_kernel(IpmDev D) {
   const double* sol = D.rhs + size_t(bi) * D.Nt;
   double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
   const double mu = S.mu, tau = S.tau;
+  if (S.mode == 1) {            // Gauss-Newton step of the restoration: slope = g_b^T d + (A d)^T c, A d = w - c
+    double slope = 0.0;
+    for (int i = t; i < D.nv; i += blockDim.x) {
+      const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
+      double d = 0.0;
+      if (l != u) {
+        d = sol[D.pos[i]];
+        if (!(fabs(d) < 1e300)) bad = 1;
+        double gb = S.zeta * D.dr2[o + i] * (vi - D.vR[o + i]);
+        if (l > -IPM_INF) { const double s = vi - l; if (d < 0) amax = fmin(amax, -tau * s / d); gb -= mu / s; }
+        if (u < IPM_INF) { const double s = u - vi; if (d > 0) amax = fmin(amax, tau * s / d); gb += mu / s; }
+        slope += gb * d;
+      }
+      D.dv[o + i] = d;
+      D.dzL[o + i] = 0.0;
+      D.dzU[o + i] = 0.0;
+    }
+    for (int r = t; r < D.m; r += blockDim.x) {
+      const double cr = D.c[size_t(bi) * D.m + r];
+      slope += (sol[D.pos[D.nv + r]] - cr) * cr;
+      D.dlam[size_t(bi) * D.m + r] = 0.0;
+    }
+    amax = block_red(amax, 2, sh); slope = block_red(slope, 0, sh); bad = block_red(bad, 1, sh);
+    if (t != 0) return;
+    if (bad != 0) { S.status = 5; return; }
+    S.alpha_max = amax; S.alpha_z = 0.0; S.alpha = amax; S.slope = slope; S.dphi = slope;
+    S.ls = 0; S.accepted = 0; S.armijo = 0;
+    atomicAdd(&D.cnt[2], 1);
+    return;
+  }
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
     double d = 0.0, dl = 0.0, du = 0.0;
@@ -716,13 +813,15 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
   if (S.status != 0 || S.accepted) return;
   const size_t o = size_t(bi) * D.nv;
   const double a = S.alpha;
-  double th = 0.0, ln = 0.0, bad = 0.0;
+  double th = 0.0, ln = 0.0, bad = 0.0, csq = 0.0, qd = 0.0;
+  const bool resto = S.mode == 1;
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
     if (l == u) continue;
     const double vt = D.v[o + i] + a * D.dv[o + i];
     if (l > -IPM_INF) ln += log(vt - l);
     if (u < IPM_INF) ln += log(u - vt);
+    if (resto) { const double dd = vt - D.vR[o + i]; qd += D.dr2[o + i] * dd * dd; }
   }
   for (int r = t; r < D.m; r += blockDim.x) {
     const int s = D.row_slack[r];
@@ -730,10 +829,21 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
     const double cr = s < 0 ? gr - D.gl[r] : gr - (D.v[o + D.n + s] + a * D.dv[o + D.n + s]);
     if (!(fabs(cr) < 1e300)) bad = 1;
     th += fabs(cr);
+    csq += cr * cr;
   }
   th = block_red(th, 0, sh); ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh);
+  if (resto) { csq = block_red(csq, 0, sh); qd = block_red(qd, 0, sh); }
   if (t != 0) return;
   const IpmOpts& op = D.o;
+  if (resto) {                  // Armijo on psi = 1/2 |c|^2 + zeta/2 |D_R (v - v_R)|^2 - mu sum ln
+    const double psit = 0.5 * csq + 0.5 * S.zeta * qd - S.mu * ln;
+    if (bad == 0 && fabs(psit) < 1e300 && psit <= S.psi + 1e-4 * a * S.slope) { S.accepted = 1; return; }
+    S.alpha = 0.5 * a;
+    S.ls += 1;
+    if (S.ls >= op.max_ls) { S.status = 3; return; }
+    atomicAdd(&D.cnt[2], 1);
+    return;
+  }
   const double ft = D.objt[bi];
   if (!(fabs(ft) < 1e300) || !(fabs(ln) < 1e300)) bad = 1;
   const double phit = ft - S.mu * ln;
@@ -757,7 +867,11 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
   if (ok) { S.accepted = 1; return; }
   S.alpha = 0.5 * a;
   S.ls += 1;
-  if (S.alpha < S.alpha_min || S.ls > op.max_ls) { S.status = 3; return; }
+  if (S.alpha < S.alpha_min || S.ls > op.max_ls) {
+    if (op.resto && S.theta > op.tol) S.enter_resto = 1;      // Ipopt switches to its restoration phase here
+    else S.status = 3;
+    return;
+  }
   atomicAdd(&D.cnt[2], 1);
 }
 
@@ -765,8 +879,39 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
 __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
-  if (S.status != 0 || !S.accepted) return;
+  if (S.status != 0) return;
   const size_t o = size_t(bi) * D.nv;
+  if (S.enter_resto) {          // the line search gave up at an infeasible point: start the feasibility restoration from it
+    for (int i = t; i < D.nv; i += blockDim.x) {
+      const double vi = D.v[o + i], sc = fmax(1.0, fabs(vi));
+      D.vR[o + i] = vi;
+      D.dr2[o + i] = 1.0 / (sc * sc);
+    }
+    if (t == 0) {
+      if (S.nfilt < IPM_FMAX) {
+        double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
+        F[2 * S.nfilt] = (1.0 - D.o.gamma_theta) * S.theta;
+        F[2 * S.nfilt + 1] = S.phi - D.o.gamma_phi * S.theta;
+        S.nfilt += 1;
+      }
+      S.th0 = S.theta; S.zeta = sqrt(S.mu); S.mode = 1; S.resto_it = 0; S.enter_resto = 0;
+    }
+    return;
+  }
+  if (!S.accepted) return;
+  if (S.mode == 1) {
+    for (int i = t; i < D.nv; i += blockDim.x)
+      if (D.vl[o + i] != D.vu[o + i]) D.v[o + i] += S.alpha * D.dv[o + i];
+    if (t == 0) {
+      if (D.trace && S.iter < D.trace_cap) {
+        double* R = D.trace + (size_t(bi) * D.trace_cap + S.iter) * IPM_TRACE;
+        R[0] = S.f; R[1] = S.theta; R[2] = S.mu; R[3] = S.alpha; R[4] = 0.0; R[5] = 0.0; R[6] = S.err0; R[7] = -1.0;
+      }
+      S.resto_it += 1;
+      S.iter += 1;
+    }
+    return;
+  }
   const double a = S.alpha, az = S.alpha_z, mu = S.mu, ks = D.o.kappa_sigma;
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
@@ -936,6 +1081,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc(h, &D.g, B * size_t(D.sg))); A_(ipm_alloc(h, &D.jac, B * size_t(D.sv))); A_(ipm_alloc(h, &D.hess, B * size_t(e.nnz_h)));
   A_(ipm_alloc(h, &D.obj, B)); A_(ipm_alloc(h, &D.gt, B * size_t(D.sg))); A_(ipm_alloc(h, &D.objt, B));
   A_(ipm_alloc(h, &D.inst, B)); A_(ipm_alloc(h, &D.cnt, size_t(4)));
+  A_(ipm_alloc(h, &D.vR, B * p.nv)); A_(ipm_alloc(h, &D.dr2, B * p.nv));
 #undef A_
   if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt), 4 * sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc"; return fail(RPM_E_DEVICE); }
   // variable bounds of every instance default to the engine's
@@ -979,6 +1125,8 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "bound_frac") o.bound_frac = value;
   else if (k == "delta_c") o.delta_c = value;
   else if (k == "max_line_search") o.max_ls = int(value);
+  else if (k == "restoration") o.resto = value != 0.0;
+  else if (k == "restoration_max_iter") o.resto_max = int(value);
   else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
     const int cap = int(value);
     if (cap < 0 || cap > 100000) { h->err = "trace: 0 ... 100000 records"; return RPM_E_INVALID; }
@@ -1011,6 +1159,12 @@ int rpm_ipm_get_stats(rpm_ipm* h, int* iterations, int* factorizations, int* tri
   if (iterations) *iterations = h->total_iterations;
   if (factorizations) *factorizations = h->total_factorizations;
   if (trial_points) *trial_points = h->total_trials;
+  return RPM_OK;
+}
+
+int rpm_ipm_get_restorations(rpm_ipm* h, int* per_instance) {
+  if (!h || !per_instance || h->h_inst.empty()) return RPM_E_INVALID;
+  for (int bi = 0; bi < h->D.B; ++bi) per_instance[bi] = h->h_inst[bi].n_resto;
   return RPM_OK;
 }
 

@@ -8,7 +8,8 @@ algorithm for large-scale nonlinear programming", Math. Program. 106 (2006) — 
   optimality error (5)/(6), barrier update (7), tau (8), primal-dual system (13) with dz from (12), fraction to the
   boundary (15), multiplier reset (16), filter acceptance (18)-(20), filter update (22), alpha_min (23), inertia
   correction Algorithm IC, initial point section 3.6 (bound_push / bound_frac), constants = Ipopt 3.12 defaults.
-Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): restoration phase, second-order
+Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): Ipopt's restoration phase (its place is
+taken by a much simpler Gauss-Newton feasibility restoration, _restore below, built from the same KKT kernels), second-order
 correction, adaptive barrier update (the reference sets mu_strategy=adaptive; monotone here), NLP scaling, least-squares
 multiplier initialisation (lambda_0 = 0).  One deviation: the constraint regularisation delta_c = 1e-8 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
@@ -24,7 +25,7 @@ INF = 1e19
 DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, bound_push=1e-2,
                 bound_frac=1e-2, kappa_sigma=1e10, s_max=100.0, gamma_theta=1e-5, gamma_phi=1e-8, eta_phi=1e-8, delta=1.0,
                 s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-8, delta_w_first=1e-4, delta_w_min=1e-20,
-                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40)
+                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=60, kappa_resto=0.9)
 
 
 def _n_positive(K):
@@ -97,6 +98,78 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
 
     def lnsum(vv):
         return np.log(vv[lo] - vl[lo]).sum() + np.log(vu[up] - vv[up]).sum()
+
+    n_resto = 0
+
+    def _restore():
+        """Feasibility restoration (NOT Ipopt's l1 restoration NLP; see the module header): damped Gauss-Newton on
+        psi(v) = 1/2 |c(v)|^2 + zeta/2 |D_R (v - v_R)|^2 - mu sum ln(bound slacks), zeta = sqrt(mu), D_R = diag(1/max(1,|v_R|)),
+        each step from the same KKT matrix with W = zeta D_R^2 + mu/s^2 and -I in the constraint block, until the
+        infeasibility has dropped to kappa_resto = 0.9 of where the line search gave up and the point is acceptable to the
+        filter.  Returns None (back to the regular iteration, lambda = 0, bound multipliers clipped) or status 3."""
+        nonlocal v, lam, zL, zU, it, n_resto
+        filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))
+        vR, th0 = v.copy(), theta
+        Dr2 = 1.0 / np.maximum(1.0, np.abs(vR)) ** 2
+        zeta = np.sqrt(mu)
+        for itr in range(o["resto_max"] + 1):
+            xr = v[:n]
+            gR, jR, fR = orc.eval_g(xr), orc.eval_jac_g(xr), orc.eval_f(xr)
+            cR = cons(v, gR)
+            thR, lnR = np.abs(cR).sum(), lnsum(v)
+            if itr > 0 and thR <= o["kappa_resto"] * th0 and thR <= theta_max and \
+                    not any(thR >= a_ and fR - mu * lnR >= b_ for a_, b_ in filt):
+                lam = np.zeros(m)
+                sl_, su_ = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
+                ks = o["kappa_sigma"]
+                zL = np.where(lo, np.maximum(np.minimum(np.minimum(zL, 1e3), ks * mu / sl_), mu / (ks * sl_)), 0.0)
+                zU = np.where(up, np.maximum(np.minimum(np.minimum(zU, 1e3), ks * mu / su_), mu / (ks * su_)), 0.0)
+                n_resto += 1
+                return None
+            if itr == o["resto_max"]:
+                return 3
+            A = np.zeros((m, nv))
+            A[ji, jj] = jR
+            A[ineq, n + np.arange(ns)] = -1.0
+            sl_, su_ = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
+            Md = zeta * Dr2 + np.where(lo, mu / sl_ ** 2, 0.0) + np.where(up, mu / su_ ** 2, 0.0)
+            gb = zeta * Dr2 * (v - vR) - np.where(lo, mu / sl_, 0.0) + np.where(up, mu / su_, 0.0)
+            K = np.zeros((nv + m, nv + m))
+            K[:nv, :nv] = np.diag(Md)
+            K[nv:, :nv] = A
+            K[:nv, nv:] = A.T
+            K[nv:, nv:] = -np.eye(m)
+            fxi = np.nonzero(~free)[0]
+            K[fxi, :] = 0.0
+            K[:, fxi] = 0.0
+            K[fxi, fxi] = 1.0
+            sol = np.linalg.solve(K, -np.concatenate([np.where(free, gb, 0.0), cR]))
+            d, w = np.where(free, sol[:nv], 0.0), sol[nv:]
+            ar = 1.0
+            k = lo & (d < 0)
+            if k.any():
+                ar = min(ar, np.min(-tau * sl_[k] / d[k]))
+            k = up & (d > 0)
+            if k.any():
+                ar = min(ar, np.min(tau * su_[k] / d[k]))
+            psi = 0.5 * cR @ cR + 0.5 * zeta * np.sum(Dr2 * (v - vR) ** 2) - mu * lnR
+            slope = float((w - cR) @ cR + np.where(free, gb, 0.0) @ d)          # (A d)^T c + g_b^T d,  A d = w - c
+            moved = False
+            for _ in range(o["max_ls"]):
+                vt = v + ar * d
+                with np.errstate(all="ignore"):
+                    ct = cons(vt, orc.eval_g(vt[:n]))
+                    psit = 0.5 * ct @ ct + 0.5 * zeta * np.sum(Dr2 * (vt - vR) ** 2) - mu * lnsum(vt)
+                if np.isfinite(psit) and psit <= psi + 1e-4 * ar * slope:
+                    v = np.where(free, vt, v)
+                    moved = True
+                    break
+                ar *= 0.5
+            trace.append(dict(it=it, f=fR, theta=thR, mu=mu, alpha=ar, alpha_z=0.0, delta_w=0.0, err0=err0, ls=-1))
+            it += 1
+            if not moved:
+                return 3
+        return 3
 
     status = None
     while True:
@@ -222,6 +295,10 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             if a < amin or ls > o["max_ls"]:
                 status = 3
                 break
+        if not accepted and status == 3 and o["resto"] and theta > o["tol"]:
+            status = _restore()
+            if status is None:
+                continue
         if not accepted:
             break
         v = np.where(free, v + a * dv, v)
@@ -234,4 +311,4 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))             # (22)
         trace.append(dict(it=it, f=f, theta=theta, mu=mu, alpha=a, alpha_z=az, delta_w=dw, err0=err0, ls=ls))
         it += 1
-    return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace)
+    return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto)

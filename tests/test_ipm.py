@@ -346,3 +346,33 @@ def test_tiny_and_ragged_layouts(built, name, make):
     assert np.array_equal(r["x"][0], r["x"][1])                 # identical instances take identical paths
     ipm.close()
     eng.close()
+
+
+def test_restatement_restoration_rescues_bryson_denham_on_the_default_mesh():
+    """example/bryson-denham as shipped (default 10 x 4 mesh): the filter line search gives up at an infeasible point
+    (theta ~ 4) where Ipopt would enter its restoration phase; the Gauss-Newton feasibility restoration brings it back."""
+    o = orc.Oracle(problems.bryson_denham(), _exact())
+    off = ipm_oracle.solve(o, o.starting_point(), tol=1e-6, resto=0)
+    on = ipm_oracle.solve(o, o.starting_point(), tol=1e-6)
+    assert off["status"] == 3 and on["status"] == 0 and on["restorations"] >= 1
+    assert abs(on["obj"] - 4.0) < 5e-3                      # coarse mesh
+
+
+@pytest.mark.gpu
+def test_device_restoration_against_restatement(built):
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = problems.bryson_denham()
+    eng = NLPEngine(prob, _exact(), n_instances=2, device=0)
+    o = orc.Oracle(prob, _exact())
+    ref = ipm_oracle.solve(o, o.starting_point(), tol=1e-6)
+    ipm = BatchedIPM(eng, tol=1e-6)
+    r = ipm.solve(np.tile(o.starting_point(), (2, 1)))
+    assert (r["status"] == 0).all() and ref["status"] == 0
+    assert (ipm.restorations() == ref["restorations"]).all() and ref["restorations"] >= 1
+    assert np.max(np.abs(r["obj"] - ref["obj"])) <= 1e-6 * abs(ref["obj"])
+    assert (np.abs(r["iterations"] - ref["iterations"]) <= 2).all()
+    ipm.set_option("restoration", 0)                         # without it: the verdict Ipopt-less code has to give
+    r0 = ipm.solve(np.tile(o.starting_point(), (2, 1)))
+    assert (r0["status"] == 3).all()
+    ipm.close()
+    eng.close()
