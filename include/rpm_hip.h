@@ -215,7 +215,8 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  * The reference hands the TNLP to Ipopt 3.12.3 (NLPSolver::SolveNlp, Core/LpNLPSolver.cpp:13-53: "tol" from the
  * Ipopt-tol option, hessian_approximation from the option list; Ipopt is a third-party dependency that is not in the
  * reference tree).  rpm_ipm restates Ipopt's published algorithm (Waechter & Biegler 2006: primal-dual barrier,
- * fraction-to-the-boundary rule, filter line search, inertia correction; monotone barrier update; no restoration phase,
+ * fraction-to-the-boundary rule, filter line search, inertia correction; monotone barrier update; a Gauss-Newton
+ * feasibility restoration instead of Ipopt's l1 restoration NLP,
  * no second-order correction, no scaling) for the engine's n_instances independent NLPs at once — the MPC sweep —
  * with iterates, multipliers, the band + border KKT matrices and their LDL^T factors resident in HBM; per iteration
  * only three counters cross PCIe.  The engine must be created with hessian_approximation = exact; set the engine's

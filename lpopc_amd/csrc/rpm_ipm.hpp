@@ -3,7 +3,8 @@
 // reference tree, so what is built here is a restatement of its published algorithm (Waechter & Biegler, Math. Program.
 // 106, 2006: primal-dual barrier, fraction-to-the-boundary rule, filter line search, inertia correction) for a batch of
 // independent instances of one transcription — the MPC sweep of BASELINE config 5 — with every iterate, multiplier,
-// KKT matrix and factor resident in HBM.  Not restated: the restoration phase, second-order corrections, the
+// KKT matrix and factor resident in HBM.  Not restated: Ipopt's l1 restoration NLP (a Gauss-Newton feasibility
+// restoration built from the same kernels takes its place), second-order corrections, the
 // adaptive barrier strategy (monotone Fiacco-McCormick here), scaling.  See DESIGN.md §f-2.
 //
 // The KKT matrix of a collocation NLP is banded once the unknowns are ordered along time: node k's states, controls,
