@@ -250,6 +250,9 @@ int rpm_ipm_get_trace(rpm_ipm* s, int instance, int capacity, double* records, i
  * the constraint block, until the infeasibility is 0.9 of where it started and the filter accepts the point; simpler than
  * Ipopt's l1 restoration NLP) */
 int rpm_ipm_get_restorations(rpm_ipm* s, int* per_instance);
+/* device time of the last solve spent in the factorisation and in the substitution kernels (HIP events on the solver's
+ * stream, summed over its iterations), for roofline figures */
+int rpm_ipm_get_kernel_times(rpm_ipm* s, double* factor_ms, double* substitution_ms);
 int rpm_ipm_solve(rpm_ipm* s, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error);
 int rpm_ipm_solve_dev(rpm_ipm* s, double* d_x, double* d_lambda, double* obj, int* status, int* iterations,
                       double* kkt_error);

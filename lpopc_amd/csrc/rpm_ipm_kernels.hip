@@ -961,9 +961,14 @@ struct rpm_ipm {
   std::string err;
   std::vector<IpmInst> h_inst;
   int total_factorizations = 0, total_iterations = 0, total_trials = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // around the factorisation and the substitution of an iteration
+  double factor_ms = 0.0, solve_ms = 0.0;
+  bool solve_pending = false;
   ~rpm_ipm() {
     for (void* p : allocs) (void)hipFree(p);
     if (h_cnt) (void)hipHostFree(h_cnt);
+    for (hipEvent_t e2 : ev)
+      if (e2) (void)hipEventDestroy(e2);
   }
 };
 
@@ -1107,6 +1112,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
       hipFuncSetAttribute(h->factor_mt == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>) : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, int(h->factor_lds)) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
   h->h_inst.resize(B);
+  for (hipEvent_t& e2 : h->ev)
+    if (hipEventCreate(&e2) != hipSuccess) { h->err = "hipEventCreate"; return fail(RPM_E_DEVICE); }
   *out = h;
   return RPM_OK;
 }
@@ -1159,6 +1166,13 @@ int rpm_ipm_get_stats(rpm_ipm* h, int* iterations, int* factorizations, int* tri
   if (iterations) *iterations = h->total_iterations;
   if (factorizations) *factorizations = h->total_factorizations;
   if (trial_points) *trial_points = h->total_trials;
+  return RPM_OK;
+}
+
+int rpm_ipm_get_kernel_times(rpm_ipm* h, double* factor_ms, double* substitution_ms) {
+  if (!h) return RPM_E_INVALID;
+  if (factor_ms) *factor_ms = h->factor_ms;
+  if (substitution_ms) *substitution_ms = h->solve_ms;
   return RPM_OK;
 }
 
@@ -1236,6 +1250,8 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   const dim3 gx((p.n + 255) / 256, B);
   auto eng_fail = [&](int rc) { h->err = e.err; return rc; };
   h->total_factorizations = h->total_iterations = h->total_trials = 0;
+  h->factor_ms = h->solve_ms = 0.0;
+  h->solve_pending = false;
 
   IPM_TRY(h, hipMemcpyAsync(D.xt, d_x, size_t(B) * p.n * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(ipm_init_kernel, dim3(B), dim3(256), 0, st, D, d_x);
@@ -1261,13 +1277,20 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       IPM_TRY(h, hipMemsetAsync(D.cnt + 1, 0, sizeof(int), st));
       hipLaunchKernelGGL(ipm_zero_kernel, dim3(unsigned(zero_blocks), B), dim3(256), 0, st, D);
       hipLaunchKernelGGL(ipm_assemble_kernel, dim3(unsigned(assemble_blocks), B), dim3(256), 0, st, D);
+      IPM_TRY(h, hipEventRecord(h->ev[0], st));
       if ((rc = factor_and_solve_launch(h, st, true, false, 1))) return rc;
+      IPM_TRY(h, hipEventRecord(h->ev[1], st));
       hipLaunchKernelGGL(ipm_inertia_kernel, dim3((B + 255) / 256), dim3(256), 0, st, D);
       h->total_factorizations += 1;
       if ((rc = fetch_counts(h, st))) return rc;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->factor_ms += ms;
       if (h->h_cnt[1] == 0) break;
     }
+    IPM_TRY(h, hipEventRecord(h->ev[2], st));
     if ((rc = factor_and_solve_launch(h, st, false, true, 1))) return rc;
+    IPM_TRY(h, hipEventRecord(h->ev[3], st));
+    h->solve_pending = true;
     IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, sizeof(int), st));
     hipLaunchKernelGGL(ipm_direction_kernel, dim3(B), dim3(256), 0, st, D);
     for (int ls = 0; ls <= D.o.max_ls + 1; ++ls) {
@@ -1278,6 +1301,11 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       hipLaunchKernelGGL(ipm_accept_kernel, dim3(B), dim3(256), 0, st, D);
       h->total_trials += 1;
       if ((rc = fetch_counts(h, st))) return rc;
+      if (h->solve_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->solve_ms += ms;
+        h->solve_pending = false;
+      }
       if (h->h_cnt[2] == 0) break;
     }
     hipLaunchKernelGGL(ipm_update_kernel, dim3(B), dim3(256), 0, st, D);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
     "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_get_info",
-    "rpm_ipm_get_stats", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
+    "rpm_ipm_get_stats", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_get_kernel_times", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
     L.rpm_ipm_get_stats.argtypes = [vp, ip, ip, ip]
     L.rpm_ipm_get_trace.argtypes = [vp, C.c_int, C.c_int, dp, ip]
     L.rpm_ipm_get_restorations.argtypes = [vp, ip]
+    L.rpm_ipm_get_kernel_times.argtypes = [vp, dp, dp]
     L.rpm_ipm_solve.argtypes = [vp, dp, dp, dp, ip, ip, dp]
     L.rpm_ipm_solve_dev.argtypes = [vp, vp, vp, dp, ip, ip, dp]
     L.rpm_ipm_get_permutation.argtypes = [vp, ip, C.c_int]
@@ -469,6 +470,12 @@ class BatchedIPM:
         n = C.c_int()
         self._chk(self._L.rpm_ipm_get_trace(self._h, int(instance), capacity, _dp(rec), C.byref(n)))
         return rec[:n.value].copy()
+
+    def kernel_times(self):
+        """Device milliseconds of the last solve inside the factorisation / the substitution kernels (HIP events)."""
+        f, s = C.c_double(), C.c_double()
+        self._chk(self._L.rpm_ipm_get_kernel_times(self._h, C.byref(f), C.byref(s)))
+        return {"factor_ms": f.value, "substitution_ms": s.value}
 
     def restorations(self):
         out = np.zeros(self._e.n_instances, dtype=np.int32)

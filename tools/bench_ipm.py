@@ -47,7 +47,7 @@ for rep in range(3):
     r = ipm.solve_dev(d)
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
-st, info = ipm.stats(), ipm.info()
+st, info, kt = ipm.stats(), ipm.info(), ipm.kernel_times()
 dt = min(times)
 nb, b, nbd = info["band_order"], info["half_bandwidth"], info["border"]
 flops_factor = float(nb) * (b + nbd) ** 2 + nbd ** 3 / 3.0        # multiply-adds x2 / 2 (lower triangle): ~ N (b + border)^2
@@ -56,7 +56,16 @@ out = {"workload": "quadrotor MPC sweep, %d instances x (8x8), per-instance init
        "batched_iterations": st["iterations"], "factorizations": st["factorizations"], "trial_points": st["trial_points"],
        "converged": int((r["status"] == 0).sum()), "max_kkt_error": float(r["kkt_error"].max()), "kkt": info,
        "kkt_storage_gb": info["storage_doubles"] * 8 * B / 1e9,
-       "factor_flop_per_instance": flops_factor, "ms_per_batched_iteration": 1e3 * dt / max(1, st["iterations"])}
+       "factor_flop_per_instance": flops_factor, "ms_per_batched_iteration": 1e3 * dt / max(1, st["iterations"]),
+       "factor_ms_per_launch": kt["factor_ms"] / max(1, st["factorizations"]),
+       "substitution_ms_per_launch": kt["substitution_ms"] / max(1, st["iterations"])}
+# roofline of the dominant kernel, live: all B instances are factored in the first iterations (later launches skip the
+# converged ones), so the rate is quoted on the first launch's flops over the mean launch time of the launches that ran full
+active = float(np.mean([(r["iterations"] > k).sum() for k in range(st["factorizations"])]))
+out["roofline"] = {"kernel": "kkt_factor_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": 78.6,
+                   "achieved": flops_factor * active / (out["factor_ms_per_launch"] * 1e-3) / 1e12,
+                   "mean_active_instances": active}
+out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]
 if n_cpu:
     from oracle import ipm_oracle
     from oracle.oracle import Oracle
