@@ -622,13 +622,12 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     for (int c = 0; c < W; ++c)
       l[c] = (row >= 0 && c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0;
   };
-  double dg, l[W], dgn = 0.0, ln[W];
+  double dg, l[W];
   fetch(0, dg, l);
   for (int blk = 0; blk < nblk; ++blk) {
     const Blk B = blk_of(blk);
     if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     if (t < W) zs[t] = t < B.w ? r[B.J0 + t] : 0.0;
-    fetch(blk + 1, dgn, ln);
     __syncthreads();
     if (t < W) {                // y = L11^-1 r: 16 lanes, one row each
       double y = zs[t];
@@ -649,10 +648,8 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       }
       r[row] -= acc;
     }
+    fetch(blk + 1, dg, l);      // in flight across the barrier and the next step's diagonal solve
     __syncthreads();
-    dg = dgn;
-#pragma unroll
-    for (int c = 0; c < W; ++c) l[c] = ln[c];
   }
   fetch(nblk - 1, dg, l);
   for (int blk = nblk - 1; blk >= 0; --blk) {
@@ -670,7 +667,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
         p[c] = __builtin_fma(lv, xr, p[c]);
       }
     }
-    fetch(blk - 1, dgn, ln);
+    fetch(blk - 1, dg, l);      // in flight across the reduction and the diagonal solve
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       double sacc = p[c];
@@ -688,9 +685,6 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       r[B.J0 + t] = x;
     }
     __syncthreads();
-    dg = dgn;
-#pragma unroll
-    for (int c = 0; c < W; ++c) l[c] = ln[c];
   }
   if (RL)
     for (int i = t; i < G.Nt; i += nt) rg[i] = rsh[i];
