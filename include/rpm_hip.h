@@ -224,11 +224,11 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
  *                       "delta_c" (1e-8, constraint regularisation that makes the pivot-free LDL^T well defined),
  *                       "max_line_search" (40), "trace" (0; keep the first N accepted steps of every instance),
- *                       "restoration" (1), "restoration_max_iter" (60)
+ *                       "restoration" (1), "restoration_max_iter" (60), "acceptable_tol" (1e-6), "acceptable_iter" (15)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,
- *                       status (0 converged, 2 iteration limit, 3 line search failed where Ipopt would enter
+ *                       status (0 converged, 1 converged to Ipopt's acceptable level, 2 iteration limit, 3 line search failed where Ipopt would enter
  *                       restoration, 4 inertia correction failed, 5 NaN/Inf), iteration count, scaled KKT error
  *   rpm_ipm_get_info:   order of the KKT system, of its banded part, half bandwidth, border size, doubles of storage per
  *                       instance, number of slack variables (one per inequality row) */

@@ -82,7 +82,7 @@ class DeviceIPMSolver:
         finally:
             ipm.close()
         nlp.finalize_solution(int(r["status"][0]), r["x"][0], r["lambda"][0], float(r["obj"][0]))
-        return int(r["status"][0]) == 0
+        return int(r["status"][0]) in (0, 1)      # Solve_Succeeded / Solved_To_Acceptable_Level
 
 
 class LpopcApplication:

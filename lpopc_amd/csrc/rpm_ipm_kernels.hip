@@ -31,6 +31,8 @@ struct IpmOpts {
   double delta_c = 1e-8, delta_w_first = 1e-4, delta_w_min = 1e-20, delta_w_max = 1e40, kw_inc_first = 100.0, kw_inc = 8.0,
          kw_dec = 1.0 / 3.0;
   int max_iter = 3000, max_ls = 40;
+  double acceptable_tol = 1e-6;      // Ipopt: "solved to acceptable level" after acceptable_iter consecutive such iterations
+  int acceptable_iter = 15;
   int resto = 1, resto_max = 60;     // Gauss-Newton feasibility restoration after a failed line search
   double kappa_resto = 0.9;
 };
@@ -38,9 +40,10 @@ struct IpmOpts {
 struct IpmInst {
   double mu, tau, f, theta, lnsum, dinf, cinf, comp_max, comp_min, sum_lam, sum_z, err0;
   double delta_w, delta_w_last, alpha_max, alpha_z, alpha, alpha_min, dphi, phi, theta_max, theta_min;
-  int status;   // 0 running, 1 converged, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
+  int status;   // 0 running, 1 converged, 6 converged to the acceptable level, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
   int iter, nfilt, accepted, refactor, npos, nneg, nbad, ls, armijo, nzb, pad;
   int mode, resto_it, enter_resto, n_resto;   // mode 1: feasibility restoration
+  int n_acc, pad2;                            // consecutive iterations with E_0 <= acceptable_tol
   double th0, zeta, psi, slope;
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
@@ -250,6 +253,8 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmDev D) {
   S.err0 = fmax(fmax(dinf / sd, cinf), nzb > 0 ? cmax / sc : 0.0);
   if (bad != 0) { S.status = 5; return; }
   if (S.err0 <= o.tol) { S.status = 1; return; }
+  S.n_acc = S.err0 <= o.acceptable_tol ? S.n_acc + 1 : 0;
+  if (o.acceptable_iter > 0 && S.n_acc >= o.acceptable_iter) { S.status = 6; return; }
   if (S.iter >= o.max_iter) { S.status = 2; return; }
   if (S.iter == 0) {
     S.theta_max = 1e4 * fmax(1.0, th1);
@@ -862,7 +867,8 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
   S.alpha = 0.5 * a;
   S.ls += 1;
   if (S.alpha < S.alpha_min || S.ls > op.max_ls) {
-    if (op.resto && S.theta > op.tol) S.enter_resto = 1;      // Ipopt switches to its restoration phase here
+    if (S.err0 <= op.acceptable_tol) S.status = 6;             // nothing left to gain: Ipopt reports the acceptable level here too
+    else if (op.resto && S.theta > op.tol) S.enter_resto = 1;  // Ipopt switches to its restoration phase here
     else S.status = 3;
     return;
   }
@@ -1127,6 +1133,8 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "delta_c") o.delta_c = value;
   else if (k == "max_line_search") o.max_ls = int(value);
   else if (k == "restoration") o.resto = value != 0.0;
+  else if (k == "acceptable_tol") o.acceptable_tol = value;
+  else if (k == "acceptable_iter") o.acceptable_iter = int(value);
   else if (k == "restoration_max_iter") o.resto_max = int(value);
   else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
     const int cap = int(value);
@@ -1314,7 +1322,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   for (unsigned bi = 0; bi < B; ++bi) {
     const IpmInst& S = h->h_inst[bi];
     if (obj) obj[bi] = S.f;
-    if (status) status[bi] = S.status == 1 ? 0 : S.status;
+    if (status) status[bi] = S.status == 1 ? 0 : (S.status == 6 ? 1 : S.status);
     if (iterations) iterations[bi] = S.iter;
     if (kkt_error) kkt_error[bi] = S.err0;
   }

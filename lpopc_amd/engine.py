@@ -420,7 +420,7 @@ class BatchedIPM:
     engine's instances at once, iterates and KKT factors resident on the device.  The engine must have been created
     with hessian-approximation=exact."""
 
-    STATUS = {0: "converged", 2: "iteration limit", 3: "line search failed (restoration needed)",
+    STATUS = {0: "converged", 1: "converged to the acceptable level", 2: "iteration limit", 3: "line search failed (restoration needed)",
               4: "inertia correction failed", 5: "NaN/Inf"}
 
     def __init__(self, engine, **options):

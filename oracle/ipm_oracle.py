@@ -25,7 +25,7 @@ INF = 1e19
 DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, bound_push=1e-2,
                 bound_frac=1e-2, kappa_sigma=1e10, s_max=100.0, gamma_theta=1e-5, gamma_phi=1e-8, eta_phi=1e-8, delta=1.0,
                 s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-8, delta_w_first=1e-4, delta_w_min=1e-20,
-                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=60, kappa_resto=0.9)
+                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=60, kappa_resto=0.9, acceptable_tol=1e-6, acceptable_iter=15)
 
 
 def _n_positive(K):
@@ -65,7 +65,7 @@ def _push_body(x, l, u, o, lo, up, both):
 
 
 def solve(orc, x0, x_l=None, x_u=None, **options):
-    """-> dict(x, lambda, obj, status, iterations, kkt_error, trace); status codes as rpm_ipm_solve."""
+    """-> dict(x, lambda, obj, status, iterations, kkt_error, trace); status codes as rpm_ipm_solve (0 converged, 1 acceptable level, ...)."""
     o = dict(DEFAULTS)
     o.update(options)
     n, m = orc.n, orc.m
@@ -99,7 +99,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
     def lnsum(vv):
         return np.log(vv[lo] - vl[lo]).sum() + np.log(vu[up] - vv[up]).sum()
 
-    n_resto = 0
+    n_resto = n_acc = 0
 
     def _restore():
         """Feasibility restoration (NOT Ipopt's l1 restoration NLP; see the module header): damped Gauss-Newton on
@@ -194,8 +194,12 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             status = 5
         elif err0 <= o["tol"]:
             status = 0
-        elif it >= o["max_iter"]:
-            status = 2
+        else:
+            n_acc = n_acc + 1 if err0 <= o["acceptable_tol"] else 0            # Ipopt: acceptable_tol 1e-6, acceptable_iter 15
+            if o["acceptable_iter"] > 0 and n_acc >= o["acceptable_iter"]:
+                status = 1
+            elif it >= o["max_iter"]:
+                status = 2
         if status is not None:
             break
         if it == 0:
@@ -293,7 +297,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             a *= 0.5
             ls += 1
             if a < amin or ls > o["max_ls"]:
-                status = 3
+                status = 1 if err0 <= o["acceptable_tol"] else 3
                 break
         if not accepted and status == 3 and o["resto"] and theta > o["tol"]:
             status = _restore()
