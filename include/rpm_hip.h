@@ -305,6 +305,12 @@ int rpm_synchronize(rpm_engine* e);
  *                    so copies run at PCIe rate; the registrations are released by rpm_destroy.  Set 0 if the
  *                    caller frees and re-allocates these buffers between calls.
  */
+/* Parameter sweeps (n_instances > 1): by default every instance shares the problem functor's constants
+ * (rpm_problem_desc.consts — the reference keeps them in file-scope globals, example/launch/Launch.cpp:47-74).  This
+ * gives instance `instance` its own copy (n = the functor's constant count), e.g. one tracking target per MPC problem;
+ * all batched device-resident entry points and rpm_ipm_* then evaluate every instance with its own constants.  The
+ * one-instance post-solve entry points keep using instance 0's. */
+int rpm_set_instance_constants(rpm_engine* e, int instance, const double* consts, int n);
 int rpm_set_option(rpm_engine* e, const char* key, int value);
 int rpm_get_option(rpm_engine* e, const char* key, int* value);
 

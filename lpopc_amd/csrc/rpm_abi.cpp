@@ -549,6 +549,25 @@ int rpm_synchronize(rpm_engine* h) {
   return rpm::dev_sync(h->e);
 }
 
+// ---- per-instance problem constants (parameter sweeps) -------------------------------------------
+int rpm_set_instance_constants(rpm_engine* h, int instance, const double* consts, int n) {
+  if (!h || !consts) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  Engine& e = h->e;
+  if (instance < 0 || instance >= e.n_instances) return fail(e, RPM_E_INVALID, "rpm_set_instance_constants: instance out of range");
+  if (n != int(e.consts.size())) return fail(e, RPM_E_INVALID, ("rpm_set_instance_constants: the problem functor takes " + std::to_string(e.consts.size()) + " constants").c_str());
+  if (e.shard_world > 1) return fail(e, RPM_E_UNSUPPORTED, "rpm_set_instance_constants: not with interval sharding");
+  if (n == 0) return RPM_OK;
+  if (e.inst_consts.empty()) {
+    e.inst_consts.resize(size_t(e.n_instances) * n);
+    for (int b = 0; b < e.n_instances; ++b) std::copy(e.consts.begin(), e.consts.end(), e.inst_consts.begin() + size_t(b) * n);
+  }
+  std::copy(consts, consts + n, e.inst_consts.begin() + size_t(instance) * n);
+  if (instance == 0) std::copy(consts, consts + n, e.consts.begin());   // what the one-instance (post-solve) entry points use
+  return rpm::dev_update_instance_constants(e);
+  RPM_GUARD_END(h->e)
+}
+
 // ---- options ----------------------------------------------------------------------------------
 int rpm_set_option(rpm_engine* h, const char* key, int value) {
   if (!h || !key) return RPM_E_INVALID;

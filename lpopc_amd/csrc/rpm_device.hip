@@ -22,7 +22,7 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
   const double* __restrict__ x = xall + size_t(inst) * K.n;
   double* grad = GRAD ? gradall + size_t(inst) * K.n : nullptr;
   const PhaseDev ph = K.phases[p];
-  const double* c = K.consts;
+  const double* c = K.consts + size_t(inst) * K.consts_stride;
   const int N = ph.N;
   const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
   const double tspan = tf - t0;
@@ -174,7 +174,7 @@ void device_destroy(Engine& e) {
   }
 #endif
   void* ptrs[] = {d->d_phases, d->d_tiles, d->d_tasks, d->d_nodes, d->d_points, d->d_weights, d->d_diag,
-                  d->d_dvals, d->d_doff, d->d_consts, d->d_alin_v, d->d_links, d->d_alin_j, d->d_x, d->d_g,
+                  d->d_dvals, d->d_doff, d->d_consts, d->d_inst_consts, d->d_alin_v, d->d_links, d->d_alin_j, d->d_x, d->d_g,
                   d->d_values, d->d_grad, d->d_obj, d->d_lambda, d->d_hess, d->d_partial, d->d_hpairs, d->d_hphases,
                   d->d_hends, d->d_hlinks, d->d_htiles, d->d_htmp};
   for (void* p : ptrs)
@@ -253,6 +253,7 @@ int device_init(Engine& e, int device_id) {
   k.dvals = d->d_dvals;
   k.doff_vals = d->d_doff;
   k.consts = d->d_consts;
+  k.consts_stride = 0;
   k.links = d->d_links;
   k.alin_j = d->d_alin_j;
   k.alin_v = d->d_alin_v;
@@ -294,7 +295,7 @@ int device_init(Engine& e, int device_id) {
     return RPM_E_UNSUPPORTED;
   }
   tile_pipeline_setup(e, d, pd, device_id);
-  return RPM_OK;
+  return dev_update_instance_constants(e);
 }
 
 int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream) {
@@ -441,6 +442,19 @@ int dev_upload(Engine& e, double* dev, const double* host, size_t count) {
   HIP_TRY(e, hipMemcpyAsync(dev, host, count * sizeof(double), hipMemcpyHostToDevice, e.dev->stream));
   return RPM_OK;
 }
+int dev_update_instance_constants(Engine& e) {
+  if (!e.dev || e.inst_consts.empty()) return RPM_OK;
+  Device& d = *e.dev;
+  const size_t count = e.inst_consts.size();
+  if (!d.d_inst_consts) HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d.d_inst_consts), count * sizeof(double)));
+  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  HIP_TRY(e, hipMemcpy(d.d_inst_consts, e.inst_consts.data(), count * sizeof(double), hipMemcpyHostToDevice));
+  d.kp.consts = d.d_inst_consts;
+  d.kp.consts_stride = int(e.consts.size());
+  d.cache_valid = false;
+  return RPM_OK;
+}
+
 int dev_sync(Engine& e) {
   if (!e.dev) return RPM_OK;
   HIP_TRY(e, hipStreamSynchronize(e.dev->stream));

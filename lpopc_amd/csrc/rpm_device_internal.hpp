@@ -29,6 +29,7 @@ struct KParams {
   const double* dvals;
   const double* doff_vals;
   const double* consts;
+  int consts_stride;                    // doubles between the constants of consecutive instances (0: shared)
   const LinkDev* links;
   const int* alin_j;     // 2 entries per linear row
   const double* alin_v;
@@ -62,6 +63,7 @@ struct Device {
   TileDev* d_tiles = nullptr;
   TaskDev* d_tasks = nullptr;
   NodeDev* d_nodes = nullptr;
+  double* d_inst_consts = nullptr;   // n_instances x nconst when rpm_set_instance_constants was used
   double *d_points = nullptr, *d_weights = nullptr, *d_diag = nullptr, *d_dvals = nullptr,
          *d_doff = nullptr, *d_consts = nullptr, *d_alin_v = nullptr;
   LinkDev* d_links = nullptr;

@@ -123,6 +123,7 @@ struct Engine {
   // description
   int problem_id = 0, P = 0, L = 0;
   std::vector<double> consts;
+  std::vector<double> inst_consts;   // n_instances x consts.size() once rpm_set_instance_constants was used, else empty (shared)
   double fd_tol = 1e-6;
   int first_derive = 0, hessian_mode = 0;
   int n_instances = 1;
@@ -233,6 +234,7 @@ int dev_upload_x(Engine& e, const double* x);
 int dev_upload(Engine& e, double* dev, const double* host, size_t count);
 int dev_download(Engine& e, double* host, const double* dev, size_t count);
 int dev_sync(Engine& e);
+int dev_update_instance_constants(Engine& e);   // (re)uploads e.inst_consts and points the kernels at it
 double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 lambda, 6 hess
 bool& dev_cache_valid(Engine& e);
 void* dev_stream(Engine& e);

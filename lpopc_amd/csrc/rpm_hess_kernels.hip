@@ -50,7 +50,7 @@ __global__ void rpm_hess_kernel(const KParams K, const HParams Hp, const double*
   const double* __restrict__ lam = lam_all + size_t(inst) * K.m + ph.g0;   // phase_lambda, LpHessian.cpp:84
   double* __restrict__ hv = hv_all + size_t(inst) * Hp.nnz_h + hp.v0;
   double* __restrict__ tmp = tmp_all + size_t(inst) * Hp.tmp_len + hp.tt_tmp;
-  const double* c = K.consts;
+  const double* c = K.consts + size_t(inst) * K.consts_stride;
   const bool act = role < NR && kk < cnt;
   const int k = k0 + (kk < cnt ? kk : cnt - 1);
   const int N = ph.N;
@@ -211,7 +211,7 @@ __global__ void rpm_hess_end_kernel(const KParams K, const HParams Hp, const dou
   const double* __restrict__ x = xall + size_t(inst) * K.n;
   const double* __restrict__ lam = lam_all + size_t(inst) * K.m;
   double* __restrict__ hv = hv_all + size_t(inst) * Hp.nnz_h;
-  const double* c = K.consts;
+  const double* c = K.consts + size_t(inst) * K.consts_stride;
   if (e < Hp.n_ends) {
     const HessEndDev en = Hp.ends[e];
     const PhaseDev ph = K.phases[en.phase];

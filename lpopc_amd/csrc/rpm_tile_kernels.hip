@@ -29,14 +29,14 @@ namespace rpm {
 // workgroup barrier), so a wave of a workgroup that is busy with something else can take it (rpm_tile_pl_kernel).
 template <class Prob, bool WG, bool WJ, bool AN, bool WAVE = false>
 __device__ void endpoint_block(const KParams& K, const TaskDev task, const double* __restrict__ x,
-                               double* __restrict__ g, double* __restrict__ vals, double* lds) {
+                               double* __restrict__ g, double* __restrict__ vals, double* lds, int inst) {
   constexpr int NX = Prob::NX;
   constexpr int NE = Prob::NE_MAX > 0 ? Prob::NE_MAX : 1;
   constexpr int NL = Prob::NLINK_MAX > 0 ? Prob::NLINK_MAX : 1;
   static_assert(!WAVE || 2 * NX + 3 <= 64, "endpoint perturbations must fit one wave");
   const int tid = WAVE ? int(threadIdx.x & 63) : int(threadIdx.x);
   const int nthr = WAVE ? 64 : int(blockDim.x);
-  const double* c = K.consts;
+  const double* c = K.consts + size_t(inst) * K.consts_stride;
   if (task.type == 0) {
     // linear rows  A_lin * x  (LpNLPWrapper.cpp:45; COO loop order of LpSparseMatrix.cpp:142-153) and
     // their constant Jacobian entries (:242)
@@ -196,7 +196,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   if ((K.diag_mask & 1) && int(blockIdx.x) >= K.n_my_tiles) return;
 #endif
   if (int(blockIdx.x) >= K.n_my_tiles) {  // the launch's trailing workgroups: endpoint work items
-    endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
+    endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds, int(blockIdx.y));
     return;
   }
   // XCD-aware tile order: workgroups b, b+8, b+16, ... are dealt to the same XCD, so give each XCD a
@@ -209,7 +209,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
 #ifdef RPM_DIAG
   if (K.diag_mask & 64) { if (tl.cnt < 0) vals[0] = 0; return; }
 #endif
-  const auto c = (const __attribute__((address_space(4))) double*)K.consts;   // constant address space: scalar loads
+  const auto c = (const __attribute__((address_space(4))) double*)(K.consts + size_t(blockIdx.y) * K.consts_stride);   // constant address space: scalar loads
   double* Xs = lds;                          // [NX][max_span]  state-matrix rows the tile's D rows touch
   double* Us = Xs + NX * K.max_span;         // [NU][T]
   double* Ds = Us + NU * T;                  // the tile's D rows, row-major per node
@@ -452,13 +452,13 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
   double* __restrict__ vals = vall + size_t(blockIdx.y) * K.sv;
   RPM_TRC(0);
   if (int(blockIdx.x) >= K.n_my_tiles) {
-    endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds);
+    endpoint_block<Prob, WG, WJ, AN>(K, K.tasks[int(blockIdx.x) - K.n_my_tiles], x, g, vals, lds, int(blockIdx.y));
     return;
   }
   const int nt = K.n_my_tiles, per = nt >> 3, rem = nt & 7, xcd = int(blockIdx.x) & 7, slot = int(blockIdx.x) >> 3;
   const TileDev tl = K.tiles[xcd * per + (xcd < rem ? xcd : rem) + slot];
   const TileDev& ph = tl;
-  const auto c = (const __attribute__((address_space(4))) double*)K.consts;   // constant address space: scalar loads
+  const auto c = (const __attribute__((address_space(4))) double*)(K.consts + size_t(blockIdx.y) * K.consts_stride);   // constant address space: scalar loads
   double* Xs = lds;
   double* Us = Xs + NX * K.max_span;
   double* Ds = Us + NU * T;
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
     for (int it = NDMA * w + dw; it < n_end; it += NDMA * G) {
       const int inst = it / K.n_tasks;
       endpoint_block<Prob, WG, WJ, AN, true>(K, K.tasks[it - inst * K.n_tasks], xall + size_t(inst) * K.n,
-                                             gall + size_t(inst) * K.sg, vall + size_t(inst) * K.sv, nullptr);
+                                             gall + size_t(inst) * K.sg, vall + size_t(inst) * K.sv, nullptr, inst);
     }
     return;
   }
@@ -854,7 +854,6 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
   // the problem constants through the constant address space: scalar loads (s_load, lgkmcnt).  Through a generic
   // pointer they are vector loads here (the kernel has stored by then, so the compiler cannot use the scalar cache),
   // and a vector load's s_waitcnt vmcnt also waits for every Jacobian store issued before it (in-order counter).
-  const auto c4 = (const __attribute__((address_space(4))) double*)K.consts;
   const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
   for (int jt = 0; jt < n_iter_wg; ++jt) {
     const double* cur = lds + (jt & 1) * S_SIZE;
@@ -873,6 +872,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
     const int inst = __builtin_amdgcn_readfirstlane(rec[NREC]);
     double* __restrict__ g = gall + size_t(inst) * K.sg;
     double* __restrict__ vals = vall + size_t(inst) * K.sv;
+    const auto c4 = (const __attribute__((address_space(4))) double*)(K.consts + size_t(inst) * K.consts_stride);
     const double* Xs = cur + S_X;
     const double* Us = cur + S_U;
     const double* Ds = cur + S_D;

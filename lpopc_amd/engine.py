@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "rpm_get_bounds_info", "rpm_get_starting_point", "rpm_eval_f", "rpm_eval_grad_f", "rpm_eval_g",
     "rpm_eval_jac_g", "rpm_eval_h", "rpm_finalize_solution", "rpm_get_solution", "rpm_eval_g_dev",
     "rpm_eval_jac_g_dev", "rpm_eval_pair_dev", "rpm_eval_f_dev", "rpm_eval_grad_f_dev", "rpm_eval_h_dev",
-    "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_get_phase_sizes", "rpm_get_phase_tables",
+    "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_set_instance_constants", "rpm_get_phase_sizes", "rpm_get_phase_tables",
     "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
@@ -83,6 +83,7 @@ def lib():
     L.rpm_eval_h_dev.argtypes = [vp, vp, C.c_double, vp, vp, vp]
     L.rpm_synchronize.argtypes = [vp]
     L.rpm_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.rpm_set_instance_constants.argtypes = [vp, C.c_int, dp, C.c_int]
     L.rpm_get_option.argtypes = [vp, C.c_char_p, ip]
     L.rpm_get_phase_sizes.argtypes = [vp, C.c_int, ip, ip, ip]
     L.rpm_get_phase_tables.argtypes = [vp, C.c_int, dp, dp, ip, ip, dp, dp, ip, ip, dp]
@@ -185,6 +186,11 @@ class NLPEngine:
         v = C.c_int()
         self._check(self._L.rpm_get_option(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    def set_instance_constants(self, instance, consts):
+        """Give one instance of a batched engine its own problem constants (parameter sweeps)."""
+        c = np.ascontiguousarray(consts, dtype=np.float64)
+        self._check(self._L.rpm_set_instance_constants(self._h, int(instance), _dp(c), int(c.size)))
 
     # ---- TNLP surface, host buffers --------------------------------------------------------
     def get_nlp_info(self):
