@@ -171,3 +171,22 @@ def test_auto_scale_is_refused_loudly(built):
     with pytest.raises(LpopcException):
         NLPEngine(problems.bryson_denham(), opts)
 
+
+
+def test_instance_constants_host_validation(built):
+    """rpm_set_instance_constants: count and instance are validated on the host (no device needed); interval-sharded
+    engines refuse it."""
+    from lpopc_amd.engine import NLPEngine, RpmError
+    prob = problems.quadrotor(2, 3)
+    consts = prob.GetOpimalProblemFuns().consts
+    eng = NLPEngine(prob, n_instances=3)
+    eng.set_instance_constants(2, consts)
+    for bad in (lambda: eng.set_instance_constants(3, consts), lambda: eng.set_instance_constants(-1, consts),
+                lambda: eng.set_instance_constants(0, consts[:-1])):
+        with pytest.raises(RpmError):
+            bad()
+    eng.close()
+    sharded = NLPEngine(problems.launch(8, 4), shard_mode=1, shard_rank=0, shard_world=2)
+    with pytest.raises(RpmError):
+        sharded.set_instance_constants(0, problems.launch(8, 4).GetOpimalProblemFuns().consts)
+    sharded.close()
