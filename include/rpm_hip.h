@@ -238,6 +238,7 @@ void rpm_ipm_destroy(rpm_ipm* s);
 const char* rpm_ipm_last_error(const rpm_ipm* s);
 int rpm_ipm_set_option(rpm_ipm* s, const char* key, double value);
 int rpm_ipm_set_bounds(rpm_ipm* s, int instance, const double* x_l, const double* x_u);
+int rpm_ipm_set_all_bounds(rpm_ipm* s, const double* x_l, const double* x_u);   /* n_instances x n each */
 int rpm_ipm_get_info(rpm_ipm* s, int* kkt_order, int* band_order, int* half_bandwidth, int* border,
                      long long* storage_doubles, int* n_slacks);
 int rpm_ipm_get_stats(rpm_ipm* s, int* iterations, int* factorizations, int* trial_points);

@@ -1207,6 +1207,26 @@ int rpm_ipm_set_bounds(rpm_ipm* h, int instance, const double* x_l, const double
   return RPM_OK;
 }
 
+/* variable bounds of all instances at once: x_l, x_u are n_instances x n (host), e.g. the measured initial states of a
+ * receding-horizon sweep; two copies instead of 2 n_instances */
+int rpm_ipm_set_all_bounds(rpm_ipm* h, const double* x_l, const double* x_u) {
+  if (!h || !x_l || !x_u) return RPM_E_INVALID;
+  const IpmPlan& p = h->plan;
+  const size_t B = size_t(h->D.B);
+  for (size_t bi = 0; bi < B; ++bi)
+    for (int i = 0; i < p.n; ++i)
+      if ((x_l[bi * p.n + i] == x_u[bi * p.n + i]) != (p.fixed[i] != 0)) {
+        h->err = "rpm_ipm_set_all_bounds: instance " + std::to_string(bi) + ", variable " + std::to_string(i) +
+                 " changes between fixed and free (the KKT layout is shared by all instances)";
+        return RPM_E_INVALID;
+      }
+  IPM_TRY(h, hipMemcpy2D(h->D.vl, size_t(p.nv) * sizeof(double), x_l, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
+                         hipMemcpyHostToDevice));
+  IPM_TRY(h, hipMemcpy2D(h->D.vu, size_t(p.nv) * sizeof(double), x_u, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
+                         hipMemcpyHostToDevice));
+  return RPM_OK;
+}
+
 /* test hook: factor + solve the caller's matrices (B x storage doubles in the band + border layout, lower triangle)
  * against B right-hand sides in KKT order; returns the solutions and the signs of D */
 int rpm_ipm_debug_solve(rpm_ipm* h, const double* k_storage, const double* rhs, double* sol, int* n_pos, int* n_neg) {

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
-    "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_get_info",
+    "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_set_all_bounds", "rpm_ipm_get_info",
     "rpm_ipm_get_stats", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_get_kernel_times", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
 ]
 
@@ -105,6 +105,7 @@ def lib():
     L.rpm_ipm_last_error.restype = C.c_char_p
     L.rpm_ipm_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.rpm_ipm_set_bounds.argtypes = [vp, C.c_int, dp, dp]
+    L.rpm_ipm_set_all_bounds.argtypes = [vp, dp, dp]
     L.rpm_ipm_get_info.argtypes = [vp, ip, ip, ip, ip, C.POINTER(C.c_longlong), ip]
     L.rpm_ipm_get_stats.argtypes = [vp, ip, ip, ip]
     L.rpm_ipm_get_trace.argtypes = [vp, C.c_int, C.c_int, dp, ip]
@@ -457,6 +458,12 @@ class BatchedIPM:
         x_l, x_u = np.ascontiguousarray(x_l, dtype=np.float64), np.ascontiguousarray(x_u, dtype=np.float64)
         assert x_l.size == self._e.n and x_u.size == self._e.n
         self._chk(self._L.rpm_ipm_set_bounds(self._h, int(instance), _dp(x_l), _dp(x_u)))
+
+    def set_all_bounds(self, x_l, x_u):
+        """x_l, x_u: (n_instances, n)."""
+        x_l, x_u = np.ascontiguousarray(x_l, dtype=np.float64), np.ascontiguousarray(x_u, dtype=np.float64)
+        assert x_l.shape == x_u.shape == (self._e.n_instances, self._e.n)
+        self._chk(self._L.rpm_ipm_set_all_bounds(self._h, _dp(x_l), _dp(x_u)))
 
     def info(self):
         a = [C.c_int() for _ in range(4)]
