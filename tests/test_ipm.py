@@ -402,3 +402,41 @@ def test_sweep_with_per_instance_targets(built):
     assert len(set(np.round(r["obj"], 6))) == B
     ipm.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_all_bounds_equals_per_instance_bounds_and_warm_start(built):
+    """rpm_ipm_set_all_bounds == B calls of rpm_ipm_set_bounds; a solve restarted from its own solution with warm-start
+    options (small mu_init, no bound push) needs fewer iterations and lands on the same optimum."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine, RpmError
+    B = 3
+    prob = problems.quadrotor(2, 4)
+    eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
+    xl, xu, _, _ = eng.get_bounds_info()
+    N1 = 2 * 4 + 1
+    idx = [i * N1 for i in range(12)]
+    rng = np.random.RandomState(8)
+    XL, XU = np.tile(xl, (B, 1)), np.tile(xu, (B, 1))
+    XL[:, idx] = XU[:, idx] = rng.uniform(-0.2, 0.2, size=(B, 12))
+    x0 = np.tile(eng.get_starting_point()[:eng.n], (B, 1))
+    a = BatchedIPM(eng)
+    for b in range(B):
+        a.set_bounds(b, XL[b], XU[b])
+    ra = a.solve(x0)
+    a.close()
+    c = BatchedIPM(eng)
+    c.set_all_bounds(XL, XU)
+    rc = c.solve(x0)
+    assert np.array_equal(ra["x"], rc["x"]) and np.array_equal(ra["iterations"], rc["iterations"])
+    for k, v in (("mu_init", 1e-6), ("bound_push", 1e-9), ("bound_frac", 1e-9)):
+        c.set_option(k, v)
+    rw = c.solve(rc["x"])
+    assert (rw["status"] == 0).all() and (rw["iterations"] < rc["iterations"]).all()
+    assert np.max(np.abs(rw["obj"] - rc["obj"])) <= 1e-7 * np.max(np.abs(rc["obj"]))
+    bad = XL.copy()
+    free = np.nonzero(xl != xu)[0][0]
+    bad[1, free] = XU[1, free]
+    with pytest.raises(RpmError):
+        c.set_all_bounds(bad, XU)
+    c.close()
+    eng.close()
