@@ -440,3 +440,48 @@ def test_all_bounds_equals_per_instance_bounds_and_warm_start(built):
         c.set_all_bounds(bad, XU)
     c.close()
     eng.close()
+
+
+# ---- committed regression fixtures (tests/golden/make_ipm_golden.py) -----------------------------------------------------
+def _ipm_fixtures():
+    import glob
+    import os
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ipm", "*.npz")))
+
+
+def _ipm_case(path):
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_ipm_golden", os.path.join(here, "golden", "make_ipm_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    make, opts = mg.CASES[os.path.basename(path)[:-4]]
+    return make(), opts
+
+
+@pytest.mark.parametrize("path", _ipm_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_restatement_reproduces_ipm_fixture(path):
+    prob, opts = _ipm_case(path)
+    z = np.load(path)
+    o = orc.Oracle(prob, _exact())
+    r = ipm_oracle.solve(o, z["x0"], **opts)
+    assert r["status"] == z["status"][0] and r["iterations"] == z["iterations"][0] and r["restorations"] == z["restorations"][0]
+    assert np.allclose(r["x"], z["x"], rtol=0, atol=1e-9) and abs(r["obj"] - z["obj"][0]) <= 1e-10 * max(1.0, abs(z["obj"][0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", _ipm_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_device_reproduces_ipm_fixture(built, path):
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob, opts = _ipm_case(path)
+    z = np.load(path)
+    eng = NLPEngine(prob, _exact(), device=0)
+    ipm = BatchedIPM(eng, **opts)
+    r = ipm.solve(z["x0"][None, :])
+    assert r["status"][0] == z["status"][0] and ipm.restorations()[0] == z["restorations"][0]
+    assert abs(int(r["iterations"][0]) - int(z["iterations"][0])) <= 2
+    assert abs(r["obj"][0] - z["obj"][0]) <= 1e-6 * max(1.0, abs(z["obj"][0]))
+    assert np.max(np.abs(r["x"][0] - z["x"])) <= 1e-4 * max(1.0, np.max(np.abs(z["x"])))
+    ipm.close()
+    eng.close()
