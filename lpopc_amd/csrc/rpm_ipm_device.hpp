@@ -1,0 +1,80 @@
+// rpm_ipm_device.hpp — what the two HIP translation units of row f-2 share: the parameter blocks of the interior-point
+// kernels (rpm_ipm_kernels.hip) and their launchers, used by the solver loop and the C ABI (rpm_ipm_solver.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rpm_ipm.hpp"
+
+namespace rpm {
+
+constexpr int IPM_W = 16;        // block width of the factorisation
+constexpr int IPM_FMAX = 256;    // filter entries kept per instance
+constexpr int IPM_TRACE = 8;     // doubles per trace record: f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks
+constexpr double IPM_INF = 1e19; // Ipopt's nlp_lower_bound_inf / nlp_upper_bound_inf
+
+struct IpmOpts {
+  double tol = 1e-8, mu_init = 0.1, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99;
+  double bound_push = 1e-2, bound_frac = 1e-2, kappa_sigma = 1e10, s_max = 100.0;
+  double gamma_theta = 1e-5, gamma_phi = 1e-8, eta_phi = 1e-8, delta = 1.0, s_theta = 1.1, s_phi = 2.3, gamma_alpha = 0.05;
+  double delta_c = 1e-8, delta_w_first = 1e-4, delta_w_min = 1e-20, delta_w_max = 1e40, kw_inc_first = 100.0, kw_inc = 8.0,
+         kw_dec = 1.0 / 3.0;
+  int max_iter = 3000, max_ls = 40;
+  double acceptable_tol = 1e-6;      // Ipopt: "solved to acceptable level" after acceptable_iter consecutive such iterations
+  int acceptable_iter = 15;
+  int resto = 1, resto_max = 60;     // Gauss-Newton feasibility restoration after a failed line search
+  double kappa_resto = 0.9;
+};
+
+struct IpmInst {
+  double mu, tau, f, theta, lnsum, dinf, cinf, comp_max, comp_min, sum_lam, sum_z, err0;
+  double delta_w, delta_w_last, alpha_max, alpha_z, alpha, alpha_min, dphi, phi, theta_max, theta_min;
+  int status;   // 0 running, 1 converged, 6 converged to the acceptable level, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
+  int iter, nfilt, accepted, refactor, npos, nneg, nbad, ls, armijo, nzb, pad;
+  int mode, resto_it, enter_resto, n_resto;   // mode 1: feasibility restoration
+  int n_acc, pad2;                            // consecutive iterations with E_0 <= acceptable_tol
+  double th0, zeta, psi, slope;
+  long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
+};
+
+struct IpmDev {
+  int B, n, m, ns, nv, Nt, Nb, nb, b, CS, nnz_jac, nnz_h;
+  long long sg, sv, kstride;
+  // plan tables
+  const int *pos, *row_slack, *slack_row, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
+  const double *gl, *gu;
+  // per-instance state
+  double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
+  double *xe, *xt, *grad, *g, *jac, *hess, *obj, *gt, *objt;
+  double *vR, *dr2;   // restoration: reference point and D_R^2 = 1 / max(1, |v_R|)^2
+  double* trace;   // per instance trace_cap records of IPM_TRACE doubles (one per accepted step), or NULL
+  int trace_cap;
+  IpmInst* inst;
+  int* cnt;     // [0] running, [1] to refactor, [2] line searches pending
+  IpmOpts o;
+};
+
+// band + border storage of one instance (rpm_ipm.hpp): element (i, j), i >= j
+struct KktGeom {
+  int Nt, Nb, nb, b, CS;
+  __device__ size_t at(int i, int j) const { return size_t(j) * CS + (i < Nb ? i - j : b + 1 + i - Nb); }
+};
+constexpr int IPM_MT = 8;   // most 16-row tiles per wave of the factorisation: block columns of up to 4 x 8 x 16 = 512 rows
+
+// launchers (rpm_ipm_kernels.hip); all asynchronous on `st`
+void ipm_launch_init(const IpmDev& D, const double* d_x0, hipStream_t st);
+void ipm_launch_init_slack(const IpmDev& D, hipStream_t st);
+void ipm_launch_pack_x(const IpmDev& D, hipStream_t st);
+void ipm_launch_residual(const IpmDev& D, hipStream_t st);
+void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st);          // zero + scatter + right-hand side
+void ipm_launch_inertia(const IpmDev& D, hipStream_t st);
+void ipm_launch_direction(const IpmDev& D, hipStream_t st);
+void ipm_launch_trial(const IpmDev& D, hipStream_t st);
+void ipm_launch_accept(const IpmDev& D, hipStream_t st);
+void ipm_launch_update(const IpmDev& D, hipStream_t st);
+// factorisation / substitution of every running instance; tiles_per_wave 4 or IPM_MT
+size_t kkt_factor_lds_bytes(const IpmPlan& p);
+hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes);
+void kkt_launch_factor(const IpmDev& D, const KktGeom& G, int tiles_per_wave, size_t lds_bytes, hipStream_t st);
+void kkt_launch_solve(const IpmDev& D, const KktGeom& G, int check_status, hipStream_t st);
+
+}  // namespace rpm

@@ -15,55 +15,10 @@
 #include <new>
 
 #include "rpm_device_internal.hpp"
-#include "rpm_ipm.hpp"
+#include "rpm_ipm_device.hpp"
 
 namespace rpm {
 
-constexpr int IPM_W = 16;        // block width of the factorisation
-constexpr int IPM_FMAX = 256;    // filter entries kept per instance
-constexpr int IPM_TRACE = 8;     // doubles per trace record: f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks
-constexpr double IPM_INF = 1e19; // Ipopt's nlp_lower_bound_inf / nlp_upper_bound_inf
-
-struct IpmOpts {
-  double tol = 1e-8, mu_init = 0.1, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99;
-  double bound_push = 1e-2, bound_frac = 1e-2, kappa_sigma = 1e10, s_max = 100.0;
-  double gamma_theta = 1e-5, gamma_phi = 1e-8, eta_phi = 1e-8, delta = 1.0, s_theta = 1.1, s_phi = 2.3, gamma_alpha = 0.05;
-  double delta_c = 1e-8, delta_w_first = 1e-4, delta_w_min = 1e-20, delta_w_max = 1e40, kw_inc_first = 100.0, kw_inc = 8.0,
-         kw_dec = 1.0 / 3.0;
-  int max_iter = 3000, max_ls = 40;
-  double acceptable_tol = 1e-6;      // Ipopt: "solved to acceptable level" after acceptable_iter consecutive such iterations
-  int acceptable_iter = 15;
-  int resto = 1, resto_max = 60;     // Gauss-Newton feasibility restoration after a failed line search
-  double kappa_resto = 0.9;
-};
-
-struct IpmInst {
-  double mu, tau, f, theta, lnsum, dinf, cinf, comp_max, comp_min, sum_lam, sum_z, err0;
-  double delta_w, delta_w_last, alpha_max, alpha_z, alpha, alpha_min, dphi, phi, theta_max, theta_min;
-  int status;   // 0 running, 1 converged, 6 converged to the acceptable level, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
-  int iter, nfilt, accepted, refactor, npos, nneg, nbad, ls, armijo, nzb, pad;
-  int mode, resto_it, enter_resto, n_resto;   // mode 1: feasibility restoration
-  int n_acc, pad2;                            // consecutive iterations with E_0 <= acceptable_tol
-  double th0, zeta, psi, slope;
-  long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
-};
-
-struct IpmDev {
-  int B, n, m, ns, nv, Nt, Nb, nb, b, CS, nnz_jac, nnz_h;
-  long long sg, sv, kstride;
-  // plan tables
-  const int *pos, *row_slack, *slack_row, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
-  const double *gl, *gu;
-  // per-instance state
-  double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
-  double *xe, *xt, *grad, *g, *jac, *hess, *obj, *gt, *objt;
-  double *vR, *dr2;   // restoration: reference point and D_R^2 = 1 / max(1, |v_R|)^2
-  double* trace;   // per instance trace_cap records of IPM_TRACE doubles (one per accepted step), or NULL
-  int trace_cap;
-  IpmInst* inst;
-  int* cnt;     // [0] running, [1] to refactor, [2] line searches pending
-  IpmOpts o;
-};
 
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ inline double block_red(double v, int kind, double* sh) {   // 0 sum, 1 max, 2 min; result on every thread
@@ -332,10 +287,6 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
 // IPM_W columns at a time: the diagonal block is factored in LDS, each panel row is solved by the thread that owns it.
 // No pivoting: with dw large enough and dc > 0 the matrix is symmetric quasi-definite, whose LDL^T exists for every
 // ordering (Vanderbei 1995); the signs of D give the inertia Algorithm IC asks for.
-struct KktGeom {
-  int Nt, Nb, nb, b, CS;
-  __device__ size_t at(int i, int j) const { return size_t(j) * CS + (i < Nb ? i - j : b + 1 + i - Nb); }
-};
 __device__ inline void block_range(const KktGeom& G, int J0, int* J1, int* nrb, int* nr) {
   if (J0 < G.Nb) {
     *J1 = min(J0 + IPM_W, G.Nb);
@@ -364,7 +315,6 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
 #ifndef IPM_LB
 #define IPM_LB 3   // waves per SIMD the 4-tile factorisation is compiled for
 #endif
-constexpr int IPM_MT = 8;   // most 16-row tiles per wave: block columns of up to 4 x 8 x 16 = 512 rows
 template <int MT>           // 16-row tiles per wave: 4 (block columns of up to 256 rows, 4 workgroups per CU) or 8
 __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(double* Kall, long long kstride, KktGeom G, IpmInst* inst) {
   typedef double d4 __attribute__((ext_vector_type(4)));
@@ -943,432 +893,63 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ launchers
+void ipm_launch_init(const IpmDev& D, const double* d_x0, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_init_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D, d_x0);
+}
+void ipm_launch_init_slack(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_init_slack_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_pack_x(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_pack_x_kernel, dim3(unsigned((D.n + 255) / 256), unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_residual_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
+  const int assemble_blocks = std::max(1, std::min(64, (nnz_max + 255) / 256));
+  const int zero_blocks = int(std::max<long long>(1, std::min<long long>(256, D.kstride / 2 / 256 + 1)));
+  hipLaunchKernelGGL(ipm_zero_kernel, dim3(unsigned(zero_blocks), unsigned(D.B)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_assemble_kernel, dim3(unsigned(assemble_blocks), unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_inertia(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_inertia_kernel, dim3(unsigned((D.B + 255) / 256)), dim3(256), 0, st, D);
+}
+void ipm_launch_direction(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_direction_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_trial(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_trial_kernel, dim3(unsigned((D.n + 255) / 256), unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_accept(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_accept_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_update(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_update_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+}
+size_t kkt_factor_lds_bytes(const IpmPlan& p) {
+  return (size_t(p.b + 8) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
+          size_t(p.nb) * p.nb) * sizeof(double);
+}
+hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
+  if (lds_bytes <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(tiles_per_wave == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>)
+                                                 : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+}
+void kkt_launch_factor(const IpmDev& D, const KktGeom& G, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
+  if (tiles_per_wave == 4)
+    hipLaunchKernelGGL(kkt_factor_kernel<4>, dim3(unsigned(D.B)), dim3(256), lds_bytes, st, D.K, D.kstride, G, D.inst);
+  else
+    hipLaunchKernelGGL(kkt_factor_kernel<IPM_MT>, dim3(unsigned(D.B)), dim3(256), lds_bytes, st, D.K, D.kstride, G, D.inst);
+}
+void kkt_launch_solve(const IpmDev& D, const KktGeom& G, int check_status, hipStream_t st) {
+  if (size_t(D.Nt) * sizeof(double) <= 48 * 1024)
+    hipLaunchKernelGGL(kkt_solve_kernel<true>, dim3(unsigned(D.B)), dim3(256), size_t(D.Nt) * sizeof(double), st, D.K, D.kstride, G,
+                       D.inst, D.rhs, check_status);
+  else
+    hipLaunchKernelGGL(kkt_solve_kernel<false>, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, G, D.inst, D.rhs, check_status);
+}
+
 }  // namespace rpm
-
-// =================================================================================================== host side + ABI
-using namespace rpm;
-
-struct rpm_engine { rpm::Engine e; };
-
-struct rpm_ipm {
-  rpm_engine* eng = nullptr;
-  IpmPlan plan;
-  IpmDev D{};
-  std::vector<void*> allocs;
-  int* h_cnt = nullptr;           // page-locked mirror of D.cnt
-  size_t factor_lds = 0;
-  int factor_mt = IPM_MT;
-  std::string err;
-  std::vector<IpmInst> h_inst;
-  int total_factorizations = 0, total_iterations = 0, total_trials = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // around the factorisation and the substitution of an iteration
-  double factor_ms = 0.0, solve_ms = 0.0;
-  bool solve_pending = false;
-  ~rpm_ipm() {
-    for (void* p : allocs) (void)hipFree(p);
-    if (h_cnt) (void)hipHostFree(h_cnt);
-    for (hipEvent_t e2 : ev)
-      if (e2) (void)hipEventDestroy(e2);
-  }
-};
-
-#define IPM_TRY(h, call)                                                      \
-  do {                                                                        \
-    hipError_t _s = (call);                                                   \
-    if (_s != hipSuccess) {                                                   \
-      (h)->err = std::string(#call) + ": " + hipGetErrorString(_s);          \
-      return RPM_E_DEVICE;                                                    \
-    }                                                                         \
-  } while (0)
-
-namespace {
-template <class T>
-int ipm_alloc(rpm_ipm* h, T** dst, size_t count, const T* src = nullptr) {
-  void* p = nullptr;
-  IPM_TRY(h, hipMalloc(&p, (count ? count : 1) * sizeof(T)));
-  h->allocs.push_back(p);
-  *dst = static_cast<T*>(p);
-  if (src && count) IPM_TRY(h, hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
-  return RPM_OK;
-}
-template <class T>
-int ipm_alloc_c(rpm_ipm* h, const T** dst, const std::vector<T>& src) {
-  T* p = nullptr;
-  int rc = ipm_alloc(h, &p, src.size(), src.data());
-  *dst = p;
-  return rc;
-}
-KktGeom geom_of(const IpmPlan& p) { return KktGeom{p.Nt, p.Nb, p.nb, p.b, p.CS}; }
-
-int fetch_counts(rpm_ipm* h, hipStream_t st) {
-  IPM_TRY(h, hipMemcpyAsync(h->h_cnt, h->D.cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  IPM_TRY(h, hipStreamSynchronize(st));
-  return RPM_OK;
-}
-int launch_check(rpm_ipm* h, const char* what) {
-  hipError_t s = hipGetLastError();
-  if (s != hipSuccess) {
-    h->err = std::string(what) + ": " + hipGetErrorString(s);
-    return RPM_E_DEVICE;
-  }
-  return RPM_OK;
-}
-int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve, int check_status) {
-  const IpmDev& D = h->D;
-  if (factor) {
-    if (h->factor_mt == 4)
-      hipLaunchKernelGGL(kkt_factor_kernel<4>, dim3(unsigned(D.B)), dim3(256), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan), D.inst);
-    else
-      hipLaunchKernelGGL(kkt_factor_kernel<IPM_MT>, dim3(unsigned(D.B)), dim3(256), h->factor_lds, st, D.K, D.kstride, geom_of(h->plan),
-                         D.inst);
-  }
-  if (solve) {
-    if (size_t(D.Nt) * sizeof(double) <= 48 * 1024)
-      hipLaunchKernelGGL(kkt_solve_kernel<true>, dim3(unsigned(D.B)), dim3(256), size_t(D.Nt) * sizeof(double), st, D.K, D.kstride,
-                         geom_of(h->plan), D.inst, D.rhs, check_status);
-    else
-      hipLaunchKernelGGL(kkt_solve_kernel<false>, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, geom_of(h->plan), D.inst, D.rhs,
-                         check_status);
-  }
-  return launch_check(h, "kkt kernels");
-}
-}  // namespace
-
-extern "C" {
-
-int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
-  if (!eng || !out) return RPM_E_INVALID;
-  *out = nullptr;
-  Engine& e = eng->e;
-  if (e.hessian_mode != RPM_HESSIAN_EXACT) {
-    e.err = "rpm_ipm_create: the engine must be created with hessian-approximation=exact";
-    return RPM_E_UNSUPPORTED;
-  }
-  if (e.shard_world > 1) {
-    e.err = "rpm_ipm_create: interval-sharded engines are not supported (shard instances across ranks instead)";
-    return RPM_E_UNSUPPORTED;
-  }
-  if (!e.dev) {
-    int rc = device_init(e, 0);
-    if (rc) return rc;
-  }
-  int rc = ensure_hessian(e);
-  if (rc) return rc;
-  rpm_ipm* h = new (std::nothrow) rpm_ipm;
-  if (!h) return RPM_E_INVALID;
-  h->eng = eng;
-  std::string why;
-  rc = build_ipm_plan(e, h->plan, &why);
-  if (rc) {
-    e.err = "rpm_ipm_create: " + why;
-    delete h;
-    return rc;
-  }
-  const IpmPlan& p = h->plan;
-  IpmDev& D = h->D;
-  const size_t B = size_t(e.n_instances);
-  D.B = int(B); D.n = p.n; D.m = p.m; D.ns = p.ns; D.nv = p.nv; D.Nt = p.Nt; D.Nb = p.Nb; D.nb = p.nb; D.b = p.b; D.CS = p.CS;
-  D.nnz_jac = e.nnz_jac; D.nnz_h = e.nnz_h;
-  D.sg = e.stride_g(); D.sv = e.stride_values(); D.kstride = p.storage();
-  auto fail = [&](int code) { e.err = "rpm_ipm_create: " + h->err; delete h; return code; };
-#define A_(call) do { int _r = (call); if (_r) return fail(_r); } while (0)
-  A_(ipm_alloc_c(h, &D.pos, p.pos)); A_(ipm_alloc_c(h, &D.row_slack, p.row_slack)); A_(ipm_alloc_c(h, &D.slack_row, p.slack_row));
-  A_(ipm_alloc_c(h, &D.jac_dst, p.jac_dst)); A_(ipm_alloc_c(h, &D.hes_dst, p.hes_dst));
-  A_(ipm_alloc_c(h, &D.diag_dst, p.diag_dst)); A_(ipm_alloc_c(h, &D.slk_dst, p.slk_dst)); A_(ipm_alloc_c(h, &D.jt_ptr, p.jt_ptr));
-  A_(ipm_alloc_c(h, &D.jt_ent, p.jt_ent)); A_(ipm_alloc_c(h, &D.jt_row, p.jt_row));
-  A_(ipm_alloc_c(h, &D.gl, e.gl)); A_(ipm_alloc_c(h, &D.gu, e.gu));
-  A_(ipm_alloc(h, &D.v, B * p.nv)); A_(ipm_alloc(h, &D.vl, B * p.nv)); A_(ipm_alloc(h, &D.vu, B * p.nv));
-  A_(ipm_alloc(h, &D.zL, B * p.nv)); A_(ipm_alloc(h, &D.zU, B * p.nv)); A_(ipm_alloc(h, &D.lam, B * p.m));
-  A_(ipm_alloc(h, &D.dv, B * p.nv)); A_(ipm_alloc(h, &D.dlam, B * p.m)); A_(ipm_alloc(h, &D.dzL, B * p.nv));
-  A_(ipm_alloc(h, &D.dzU, B * p.nv)); A_(ipm_alloc(h, &D.glag, B * p.nv)); A_(ipm_alloc(h, &D.c, B * p.m));
-  A_(ipm_alloc(h, &D.rhs, B * p.Nt)); A_(ipm_alloc(h, &D.K, B * size_t(p.storage()))); A_(ipm_alloc(h, &D.filt, B * 2 * IPM_FMAX));
-  A_(ipm_alloc(h, &D.xe, B * p.n)); A_(ipm_alloc(h, &D.xt, B * p.n)); A_(ipm_alloc(h, &D.grad, B * p.n));
-  A_(ipm_alloc(h, &D.g, B * size_t(D.sg))); A_(ipm_alloc(h, &D.jac, B * size_t(D.sv))); A_(ipm_alloc(h, &D.hess, B * size_t(e.nnz_h)));
-  A_(ipm_alloc(h, &D.obj, B)); A_(ipm_alloc(h, &D.gt, B * size_t(D.sg))); A_(ipm_alloc(h, &D.objt, B));
-  A_(ipm_alloc(h, &D.inst, B)); A_(ipm_alloc(h, &D.cnt, size_t(4)));
-  A_(ipm_alloc(h, &D.vR, B * p.nv)); A_(ipm_alloc(h, &D.dr2, B * p.nv));
-#undef A_
-  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt), 4 * sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc"; return fail(RPM_E_DEVICE); }
-  // variable bounds of every instance default to the engine's
-  {
-    std::vector<double> l(B * p.nv, 0.0), u(B * p.nv, 0.0);
-    for (size_t bi = 0; bi < B; ++bi)
-      for (int i = 0; i < p.n; ++i) { l[bi * p.nv + i] = e.xl[i]; u[bi * p.nv + i] = e.xu[i]; }
-    if (hipMemcpy(D.vl, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(D.vu, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy"; return fail(RPM_E_DEVICE); }
-  }
-  h->factor_mt = IPM_W + p.b + p.nb <= 256 ? 4 : IPM_MT;
-  if (IPM_W + p.b + p.nb > 4 * IPM_MT * 16) {
-    h->err = "band + border of " + std::to_string(p.b + p.nb) + " rows exceeds the factorisation's 512 rows per block column";
-    return fail(RPM_E_UNSUPPORTED);
-  }
-  h->factor_lds = (size_t(p.b + 8) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
-                   size_t(p.nb) * p.nb) * sizeof(double);
-  if (h->factor_lds > 150 * 1024) {
-    h->err = "band of " + std::to_string(p.b) + " and border of " + std::to_string(p.nb) + " rows do not fit the factorisation's LDS";
-    return fail(RPM_E_UNSUPPORTED);
-  }
-  if (h->factor_lds > 48 * 1024 &&
-      hipFuncSetAttribute(h->factor_mt == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>) : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, int(h->factor_lds)) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
-  h->h_inst.resize(B);
-  for (hipEvent_t& e2 : h->ev)
-    if (hipEventCreate(&e2) != hipSuccess) { h->err = "hipEventCreate"; return fail(RPM_E_DEVICE); }
-  *out = h;
-  return RPM_OK;
-}
-
-void rpm_ipm_destroy(rpm_ipm* h) { delete h; }
-const char* rpm_ipm_last_error(const rpm_ipm* h) { return h ? h->err.c_str() : "null solver"; }
-
-int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
-  if (!h || !key) return RPM_E_INVALID;
-  IpmOpts& o = h->D.o;
-  const std::string k(key);
-  if (k == "tol") o.tol = value;
-  else if (k == "max_iter") o.max_iter = int(value);
-  else if (k == "mu_init") o.mu_init = value;
-  else if (k == "bound_push") o.bound_push = value;
-  else if (k == "bound_frac") o.bound_frac = value;
-  else if (k == "delta_c") o.delta_c = value;
-  else if (k == "max_line_search") o.max_ls = int(value);
-  else if (k == "restoration") o.resto = value != 0.0;
-  else if (k == "acceptable_tol") o.acceptable_tol = value;
-  else if (k == "acceptable_iter") o.acceptable_iter = int(value);
-  else if (k == "restoration_max_iter") o.resto_max = int(value);
-  else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
-    const int cap = int(value);
-    if (cap < 0 || cap > 100000) { h->err = "trace: 0 ... 100000 records"; return RPM_E_INVALID; }
-    h->D.trace = nullptr;
-    h->D.trace_cap = 0;
-    if (cap > 0) {
-      int rc = ipm_alloc(h, &h->D.trace, size_t(h->D.B) * cap * IPM_TRACE);
-      if (rc) return rc;
-      h->D.trace_cap = cap;
-    }
-  }
-  else { h->err = "unknown option " + k; return RPM_E_INVALID; }
-  return RPM_OK;
-}
-
-int rpm_ipm_get_info(rpm_ipm* h, int* kkt_order, int* band_order, int* half_bandwidth, int* border, long long* storage_doubles,
-                     int* n_slacks) {
-  if (!h) return RPM_E_INVALID;
-  if (kkt_order) *kkt_order = h->plan.Nt;
-  if (band_order) *band_order = h->plan.Nb;
-  if (half_bandwidth) *half_bandwidth = h->plan.b;
-  if (border) *border = h->plan.nb;
-  if (storage_doubles) *storage_doubles = h->plan.storage();
-  if (n_slacks) *n_slacks = h->plan.ns;
-  return RPM_OK;
-}
-
-int rpm_ipm_get_stats(rpm_ipm* h, int* iterations, int* factorizations, int* trial_points) {
-  if (!h) return RPM_E_INVALID;
-  if (iterations) *iterations = h->total_iterations;
-  if (factorizations) *factorizations = h->total_factorizations;
-  if (trial_points) *trial_points = h->total_trials;
-  return RPM_OK;
-}
-
-int rpm_ipm_get_kernel_times(rpm_ipm* h, double* factor_ms, double* substitution_ms) {
-  if (!h) return RPM_E_INVALID;
-  if (factor_ms) *factor_ms = h->factor_ms;
-  if (substitution_ms) *substitution_ms = h->solve_ms;
-  return RPM_OK;
-}
-
-int rpm_ipm_get_restorations(rpm_ipm* h, int* per_instance) {
-  if (!h || !per_instance || h->h_inst.empty()) return RPM_E_INVALID;
-  for (int bi = 0; bi < h->D.B; ++bi) per_instance[bi] = h->h_inst[bi].n_resto;
-  return RPM_OK;
-}
-
-int rpm_ipm_get_trace(rpm_ipm* h, int instance, int capacity, double* records, int* n_records) {
-  if (!h || instance < 0 || instance >= h->D.B || !records || !n_records) return RPM_E_INVALID;
-  if (!h->D.trace || h->h_inst.empty()) { *n_records = 0; return RPM_OK; }
-  const int n = std::min(std::min(h->h_inst[instance].iter, h->D.trace_cap), capacity);
-  IPM_TRY(h, hipMemcpy(records, h->D.trace + size_t(instance) * h->D.trace_cap * IPM_TRACE, size_t(n) * IPM_TRACE * sizeof(double),
-                       hipMemcpyDeviceToHost));
-  *n_records = n;
-  return RPM_OK;
-}
-
-int rpm_ipm_set_bounds(rpm_ipm* h, int instance, const double* x_l, const double* x_u) {
-  if (!h || !x_l || !x_u || instance < 0 || instance >= h->D.B) return RPM_E_INVALID;
-  const IpmPlan& p = h->plan;
-  for (int i = 0; i < p.n; ++i)
-    if ((x_l[i] == x_u[i]) != (p.fixed[i] != 0)) {
-      h->err = "rpm_ipm_set_bounds: variable " + std::to_string(i) + " changes between fixed and free (the KKT layout is shared by all instances)";
-      return RPM_E_INVALID;
-    }
-  IPM_TRY(h, hipMemcpy(h->D.vl + size_t(instance) * p.nv, x_l, p.n * sizeof(double), hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy(h->D.vu + size_t(instance) * p.nv, x_u, p.n * sizeof(double), hipMemcpyHostToDevice));
-  return RPM_OK;
-}
-
-/* variable bounds of all instances at once: x_l, x_u are n_instances x n (host), e.g. the measured initial states of a
- * receding-horizon sweep; two copies instead of 2 n_instances */
-int rpm_ipm_set_all_bounds(rpm_ipm* h, const double* x_l, const double* x_u) {
-  if (!h || !x_l || !x_u) return RPM_E_INVALID;
-  const IpmPlan& p = h->plan;
-  const size_t B = size_t(h->D.B);
-  for (size_t bi = 0; bi < B; ++bi)
-    for (int i = 0; i < p.n; ++i)
-      if ((x_l[bi * p.n + i] == x_u[bi * p.n + i]) != (p.fixed[i] != 0)) {
-        h->err = "rpm_ipm_set_all_bounds: instance " + std::to_string(bi) + ", variable " + std::to_string(i) +
-                 " changes between fixed and free (the KKT layout is shared by all instances)";
-        return RPM_E_INVALID;
-      }
-  IPM_TRY(h, hipMemcpy2D(h->D.vl, size_t(p.nv) * sizeof(double), x_l, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
-                         hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy2D(h->D.vu, size_t(p.nv) * sizeof(double), x_u, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
-                         hipMemcpyHostToDevice));
-  return RPM_OK;
-}
-
-/* test hook: factor + solve the caller's matrices (B x storage doubles in the band + border layout, lower triangle)
- * against B right-hand sides in KKT order; returns the solutions and the signs of D */
-int rpm_ipm_debug_solve(rpm_ipm* h, const double* k_storage, const double* rhs, double* sol, int* n_pos, int* n_neg) {
-  if (!h || !k_storage || !rhs || !sol) return RPM_E_INVALID;
-  const IpmPlan& p = h->plan;
-  IpmDev& D = h->D;
-  hipStream_t st = static_cast<hipStream_t>(dev_stream(h->eng->e));
-  std::vector<IpmInst> inst(D.B);
-  for (auto& s : inst) { s = IpmInst{}; s.refactor = 1; }
-  IPM_TRY(h, hipMemcpy(D.inst, inst.data(), inst.size() * sizeof(IpmInst), hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy(D.K, k_storage, size_t(D.B) * p.storage() * sizeof(double), hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy(D.rhs, rhs, size_t(D.B) * p.Nt * sizeof(double), hipMemcpyHostToDevice));
-  int rc = factor_and_solve_launch(h, st, true, true, 0);
-  if (rc) return rc;
-  IPM_TRY(h, hipStreamSynchronize(st));
-  IPM_TRY(h, hipMemcpy(sol, D.rhs, size_t(D.B) * p.Nt * sizeof(double), hipMemcpyDeviceToHost));
-  IPM_TRY(h, hipMemcpy(inst.data(), D.inst, inst.size() * sizeof(IpmInst), hipMemcpyDeviceToHost));
-#ifdef IPM_TIMING
-  fprintf(stderr, "factor phases of instance 0 [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld\n",
-          inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[5]);
-#endif
-  for (int bi = 0; bi < D.B; ++bi) {
-    if (n_pos) n_pos[bi] = inst[bi].npos;
-    if (n_neg) n_neg[bi] = inst[bi].nneg;
-  }
-  return RPM_OK;
-}
-
-/* KKT position of every unknown ([0,n) variables, then the slacks, then the m multipliers) — for tests and tools */
-int rpm_ipm_get_permutation(rpm_ipm* h, int* pos, int capacity) {
-  if (!h || !pos || capacity < h->plan.Nt) return RPM_E_INVALID;
-  std::memcpy(pos, h->plan.pos.data(), sizeof(int) * h->plan.Nt);
-  return RPM_OK;
-}
-
-int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, int* status, int* iterations, double* kkt_error) {
-  if (!h || !d_x) return RPM_E_INVALID;
-  Engine& e = h->eng->e;
-  IpmDev& D = h->D;
-  const IpmPlan& p = h->plan;
-  hipStream_t st = static_cast<hipStream_t>(dev_stream(e));
-  const unsigned B = unsigned(D.B);
-  const dim3 gx((p.n + 255) / 256, B);
-  auto eng_fail = [&](int rc) { h->err = e.err; return rc; };
-  h->total_factorizations = h->total_iterations = h->total_trials = 0;
-  h->factor_ms = h->solve_ms = 0.0;
-  h->solve_pending = false;
-
-  IPM_TRY(h, hipMemcpyAsync(D.xt, d_x, size_t(B) * p.n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(ipm_init_kernel, dim3(B), dim3(256), 0, st, D, d_x);
-  hipLaunchKernelGGL(ipm_pack_x_kernel, gx, dim3(256), 0, st, D);
-  int rc = dev_eval_cons(e, D.xe, D.g, nullptr, 1 | 4, st);
-  if (rc) return eng_fail(rc);
-  hipLaunchKernelGGL(ipm_init_slack_kernel, dim3(B), dim3(256), 0, st, D);
-  if ((rc = launch_check(h, "ipm_init"))) return rc;
-
-  const int assemble_blocks = std::max(1, std::min(64, (std::max(e.nnz_jac, e.nnz_h) + 255) / 256));
-  const int zero_blocks = int(std::max<long long>(1, std::min<long long>(256, p.storage() / 2 / 256 + 1)));
-  for (;;) {
-    hipLaunchKernelGGL(ipm_pack_x_kernel, gx, dim3(256), 0, st, D);
-    if ((rc = dev_eval_obj(e, D.xe, D.obj, D.grad, st))) return eng_fail(rc);
-    if ((rc = dev_eval_cons(e, D.xe, D.g, D.jac, 3 | 4, st))) return eng_fail(rc);
-    IPM_TRY(h, hipMemsetAsync(D.cnt, 0, 4 * sizeof(int), st));
-    hipLaunchKernelGGL(ipm_residual_kernel, dim3(B), dim3(256), 0, st, D);
-    if ((rc = fetch_counts(h, st))) return rc;
-    if (h->h_cnt[0] == 0) break;
-    h->total_iterations += 1;
-    if ((rc = dev_eval_h(e, D.xe, 1.0, D.lam, D.hess, st))) return eng_fail(rc);
-    for (int tries = 0; tries < 80; ++tries) {
-      IPM_TRY(h, hipMemsetAsync(D.cnt + 1, 0, sizeof(int), st));
-      hipLaunchKernelGGL(ipm_zero_kernel, dim3(unsigned(zero_blocks), B), dim3(256), 0, st, D);
-      hipLaunchKernelGGL(ipm_assemble_kernel, dim3(unsigned(assemble_blocks), B), dim3(256), 0, st, D);
-      IPM_TRY(h, hipEventRecord(h->ev[0], st));
-      if ((rc = factor_and_solve_launch(h, st, true, false, 1))) return rc;
-      IPM_TRY(h, hipEventRecord(h->ev[1], st));
-      hipLaunchKernelGGL(ipm_inertia_kernel, dim3((B + 255) / 256), dim3(256), 0, st, D);
-      h->total_factorizations += 1;
-      if ((rc = fetch_counts(h, st))) return rc;
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->factor_ms += ms;
-      if (h->h_cnt[1] == 0) break;
-    }
-    IPM_TRY(h, hipEventRecord(h->ev[2], st));
-    if ((rc = factor_and_solve_launch(h, st, false, true, 1))) return rc;
-    IPM_TRY(h, hipEventRecord(h->ev[3], st));
-    h->solve_pending = true;
-    IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, sizeof(int), st));
-    hipLaunchKernelGGL(ipm_direction_kernel, dim3(B), dim3(256), 0, st, D);
-    for (int ls = 0; ls <= D.o.max_ls + 1; ++ls) {
-      hipLaunchKernelGGL(ipm_trial_kernel, gx, dim3(256), 0, st, D);
-      if ((rc = dev_eval_obj(e, D.xt, D.objt, nullptr, st))) return eng_fail(rc);
-      if ((rc = dev_eval_cons(e, D.xt, D.gt, nullptr, 1 | 4, st))) return eng_fail(rc);
-      IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, sizeof(int), st));
-      hipLaunchKernelGGL(ipm_accept_kernel, dim3(B), dim3(256), 0, st, D);
-      h->total_trials += 1;
-      if ((rc = fetch_counts(h, st))) return rc;
-      if (h->solve_pending) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->solve_ms += ms;
-        h->solve_pending = false;
-      }
-      if (h->h_cnt[2] == 0) break;
-    }
-    hipLaunchKernelGGL(ipm_update_kernel, dim3(B), dim3(256), 0, st, D);
-    if ((rc = launch_check(h, "ipm iteration"))) return rc;
-  }
-  // results: x back into the caller's array, multipliers, per-instance verdicts
-  hipLaunchKernelGGL(ipm_pack_x_kernel, gx, dim3(256), 0, st, D);
-  IPM_TRY(h, hipMemcpyAsync(d_x, D.xe, size_t(B) * p.n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  if (d_lambda) IPM_TRY(h, hipMemcpyAsync(d_lambda, D.lam, size_t(B) * p.m * sizeof(double), hipMemcpyDeviceToDevice, st));
-  IPM_TRY(h, hipMemcpyAsync(h->h_inst.data(), D.inst, size_t(B) * sizeof(IpmInst), hipMemcpyDeviceToHost, st));
-  IPM_TRY(h, hipStreamSynchronize(st));
-  for (unsigned bi = 0; bi < B; ++bi) {
-    const IpmInst& S = h->h_inst[bi];
-    if (obj) obj[bi] = S.f;
-    if (status) status[bi] = S.status == 1 ? 0 : (S.status == 6 ? 1 : S.status);
-    if (iterations) iterations[bi] = S.iter;
-    if (kkt_error) kkt_error[bi] = S.err0;
-  }
-  return RPM_OK;
-}
-
-int rpm_ipm_solve(rpm_ipm* h, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error) {
-  if (!h || !x) return RPM_E_INVALID;
-  IpmDev& D = h->D;
-  const IpmPlan& p = h->plan;
-  double *d_x = nullptr, *d_l = nullptr;
-  IPM_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_x), size_t(D.B) * p.n * sizeof(double)));
-  if (hipMalloc(reinterpret_cast<void**>(&d_l), size_t(D.B) * std::max(p.m, 1) * sizeof(double)) != hipSuccess) {
-    (void)hipFree(d_x);
-    h->err = "hipMalloc";
-    return RPM_E_DEVICE;
-  }
-  int rc = RPM_OK;
-  if (hipMemcpy(d_x, x, size_t(D.B) * p.n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = RPM_E_DEVICE;
-  if (!rc) rc = rpm_ipm_solve_dev(h, d_x, d_l, obj, status, iterations, kkt_error);
-  if (!rc && hipMemcpy(x, d_x, size_t(D.B) * p.n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RPM_E_DEVICE;
-  if (!rc && lambda && hipMemcpy(lambda, d_l, size_t(D.B) * p.m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RPM_E_DEVICE;
-  (void)hipFree(d_x);
-  (void)hipFree(d_l);
-  if (rc == RPM_E_DEVICE && h->err.empty()) h->err = "hip copy failed";
-  return rc;
-}
-
-}  // extern "C"
