@@ -19,13 +19,15 @@ Dense linear algebra (numpy solve + eigenvalue inertia), one instance at a time;
 """
 import numpy as np
 import scipy.linalg
+import scipy.sparse
+import scipy.sparse.linalg
 
 INF = 1e19
 
 DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, bound_push=1e-2,
                 bound_frac=1e-2, kappa_sigma=1e10, s_max=100.0, gamma_theta=1e-5, gamma_phi=1e-8, eta_phi=1e-8, delta=1.0,
                 s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-8, delta_w_first=1e-4, delta_w_min=1e-20,
-                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=60, kappa_resto=0.9, acceptable_tol=1e-6, acceptable_iter=15)
+                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=60, kappa_resto=0.9, acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense")
 
 
 def _n_positive(K):
@@ -226,7 +228,19 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         rd = glag - np.where(lo, mu / dl, 0.0) + np.where(up, mu / du, 0.0)
         fxi = np.nonzero(~free)[0]
         dw = 0.0
-        while True:                                                                               # Algorithm IC
+        Ksp = None
+        if o["linear_solver"] == "sparse-lu-no-inertia":
+            # timing variant for bench cpu_baseline legs ONLY: sparse LU of the same matrix, inertia taken on trust (valid on
+            # problems that need no inertia correction, e.g. the quadrotor sweep; results are then the dense path's to rounding)
+            Ws = scipy.sparse.coo_matrix((hv, (hi, hj)), shape=(nv, nv)).tocsr()
+            Ws = Ws + scipy.sparse.tril(Ws, -1).T + scipy.sparse.diags(sigma)
+            As = scipy.sparse.coo_matrix((np.concatenate([jv, -np.ones(ns)]), (np.concatenate([ji, ineq]), np.concatenate([jj, n + np.arange(ns)]))),
+                                         shape=(m, nv)).tocsr()
+            keep = scipy.sparse.diags(free.astype(float))
+            Ks = scipy.sparse.bmat([[keep @ Ws @ keep + scipy.sparse.diags((~free).astype(float)), keep @ As.T],
+                                    [As @ keep, -o["delta_c"] * scipy.sparse.identity(m)]], format="csc")
+            Ksp = scipy.sparse.linalg.splu(Ks)
+        while Ksp is None:                                                                        # Algorithm IC
             K = np.zeros((nv + m, nv + m))
             K[:nv, :nv] = W + np.diag(sigma + dw)
             K[nv:, :nv] = A
@@ -249,7 +263,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         if status is not None:
             break
         rhs = -np.concatenate([np.where(free, rd, 0.0), c])
-        sol = np.linalg.solve(K, rhs)
+        sol = np.linalg.solve(K, rhs) if Ksp is None else Ksp.solve(rhs)
         dv, dlam = np.where(free, sol[:nv], 0.0), sol[nv:]
         dzL = np.where(lo, mu / dl - zL - zL / dl * dv, 0.0)                                      # (12)
         dzU = np.where(up, mu / du - zU + zU / du * dv, 0.0)

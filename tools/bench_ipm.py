@@ -76,4 +76,9 @@ if n_cpu:
         assert ref["status"] == 0 and abs(ref["obj"] - r["obj"][bi]) < 1e-7 * max(1, abs(ref["obj"])), (ref["obj"], r["obj"][bi])
     out["cpu_restatement_dense_numpy_s_per_solve"] = (time.perf_counter() - t0) / n_cpu
     out["cpu_instances_checked"] = n_cpu
+    t0 = time.perf_counter()
+    for bi in range(n_cpu):          # the same restatement with a sparse LU (SuperLU) of the same KKT matrices, one core
+        ref = ipm_oracle.solve(orc, x0[bi], x_l=bounds[bi][0], x_u=bounds[bi][1], linear_solver="sparse-lu-no-inertia")
+        assert ref["status"] == 0 and abs(ref["obj"] - r["obj"][bi]) < 1e-7 * max(1, abs(ref["obj"]))
+    out["cpu_restatement_sparse_lu_s_per_solve"] = (time.perf_counter() - t0) / n_cpu
 print(json.dumps(out))
