@@ -47,3 +47,37 @@ class IntervalGather:
             self.eng.shard_pack_dev(which, full, self.send[which])
             self.dist.all_gather_into_tensor(self.recv[which], self.send[which])
             self.eng.shard_unpack_dev(which, self.recv[which], self.stride[which], full)
+
+
+# ---- sweeps of independent instances (bench.py default; the device NLP solver rpm_ipm_*) -------------------------------------
+def shard_instances(total, rank, world):
+    """Contiguous share [start, start + count) of `total` independent instances for `rank`: sizes differ by at most one,
+    nothing is exchanged on the data path."""
+    base, extra = divmod(int(total), int(world))
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+class SweepShard:
+    """One rank's part of a sweep: solve its instances with `solve_local(start, count) -> dict of per-instance numpy arrays`
+    (on a GPU: a BatchedIPM over an engine with `count` instances), then gather the per-instance verdicts — a few numbers
+    per instance, not iterates — so that every rank can report on the whole sweep.  The only collective is this gather."""
+
+    def __init__(self, dist, total):
+        self.dist, self.total = dist, int(total)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.start, self.count = shard_instances(self.total, self.rank, self.world)
+
+    def gather(self, local, keys=("obj", "status", "iterations")):
+        import torch
+        out = {}
+        longest = shard_instances(self.total, 0, self.world)[1]
+        for k in keys:
+            a = np.asarray(local[k], dtype=np.float64).reshape(-1)
+            assert a.size == self.count, "solve_local returned %d entries for %d instances" % (a.size, self.count)
+            send = torch.zeros(longest, dtype=torch.float64)
+            send[:a.size] = torch.from_numpy(a)
+            recv = [torch.zeros(longest, dtype=torch.float64) for _ in range(self.world)]
+            self.dist.all_gather(recv, send)
+            out[k] = np.concatenate([recv[r][:shard_instances(self.total, r, self.world)[1]].numpy() for r in range(self.world)])
+        return out

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from lpopc_amd import problems  # noqa: E402
-from lpopc_amd.dist import pack_host, unpack_host  # noqa: E402
+from lpopc_amd.dist import SweepShard, pack_host, shard_instances, unpack_host  # noqa: E402
 from lpopc_amd.engine import NLPEngine  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
@@ -49,6 +49,28 @@ def main():
     cnt = torch.tensor([7.0])
     dist.all_reduce(cnt)
     assert cnt.item() == 7.0 * world
+    # a sweep of independent NLP solves (row f-2) sharded by instance: every rank solves its share — here with the CPU
+    # restatement standing in for the device solver — and only the per-instance verdicts are gathered
+    from lpopc_amd.problem import Options
+    from oracle import ipm_oracle
+    assert [shard_instances(5, r, 2) for r in range(2)] == [(0, 3), (3, 2)] and shard_instances(4, 1, 4) == (1, 1)
+    opts = Options()
+    opts.SetStringValue("hessian-approximation", "exact")
+    qp = problems.quadrotor(1, 3)
+    qo = Oracle(qp, opts)
+    total = 5
+    rng = np.random.RandomState(0)
+    starts = qo.starting_point()[None, :] * (1 + 1e-2 * rng.uniform(-1, 1, size=(total, qo.n)))
+
+    def solve_local(start, count):
+        rs = [ipm_oracle.solve(qo, starts[start + k]) for k in range(count)]
+        return {"obj": [r["obj"] for r in rs], "status": [r["status"] for r in rs], "iterations": [r["iterations"] for r in rs]}
+
+    shard = SweepShard(dist, total)
+    whole = shard.gather(solve_local(shard.start, shard.count))
+    serial = solve_local(0, total)
+    for k in ("obj", "status", "iterations"):
+        assert np.array_equal(whole[k], np.asarray(serial[k], dtype=np.float64)), k
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)
