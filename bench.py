@@ -63,10 +63,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--iterates", type=int, default=256,
-                    help="distinct NLP iterates resident in HBM: 256 x 7.1 MB = 1.8 GB of outputs, of which the 0.77 GB written "
-                         "with ordinary (cacheable) stores alone are 3x the 256 MiB Infinity Cache; with 64 the Jacobian blocks "
-                         "of a cycle fit it and the kernel reads 13 %% faster than HBM allows")
+    ap.add_argument("--iterates", type=int, default=384,
+                    help="distinct NLP iterates resident in HBM: 384 x 7.1 MB = 2.7 GB of outputs, ten times the 256 MiB Infinity "
+                         "Cache (with 64 resident iterates and 16 per launch the Jacobian blocks of a cycle fit it and the kernel "
+                         "runs 13 %% faster than HBM allows)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--unfused", action="store_true", help="separate eval_g and eval_jac_g kernels per step")
     ap.add_argument("--shard", choices=["instances", "intervals"], default="instances")
@@ -81,8 +81,9 @@ def main():
     ap.add_argument("--instance-align", type=int, default=16,
                     help="doubles; start of every instance's g / values array inside a batch (1 = packed back to back)")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 role-looped kernel only, 1 force the pipelined kernel")
-    ap.add_argument("--batch", type=int, default=16,
-                    help="NLP iterates evaluated per launch (independent instances of the same problem)")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="NLP iterates evaluated per launch (independent instances of the same problem): 64 amortise the\n"
+                         "persistent kernel's prologue and tail (0.68 of the HBM peak; 16 per launch: 0.55-0.56)")
     ap.add_argument("--intervals", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=16)
     args = ap.parse_args()
@@ -217,7 +218,7 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this
         # exact command, committed under profiles/ (tools/collect_profiles.sh regenerates it)
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp) and B == 16 and not args.unfused and args.intervals == 64 and args.nodes == 16:
+        if os.path.exists(tp) and B == 64 and not args.unfused and args.intervals == 64 and args.nodes == 16:   # the default command
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:

@@ -22,7 +22,7 @@ def one(pattern):
 
 stats = one("%s_stats/*/*kernel_stats.csv" % tag)
 shutil.copy(stats, os.path.join(out, "%s_kernel_stats.csv" % tag))
-summary = {"tag": tag, "command": "python3 bench.py --profile --steps 200 --warmup 20 (default workload: 16 iterates per launch)"}
+summary = {"tag": tag, "command": "python3 bench.py --profile --steps 200 --warmup 20 (default workload: 64 iterates per launch, 384 resident)"}
 for r in csv.DictReader(open(stats)):
     if "rpm_tile" in r["Name"]:   # rpm_tile_kernel or its role-looped layout rpm_tile_rl_kernel
         summary["dominant_kernel"] = r["Name"].split("<")[0].split("::")[-1]
