@@ -291,7 +291,7 @@ int rpm_synchronize(rpm_engine* e);
  *                    persistent pipelined kernel (4 compute waves + 1 DMA wave per workgroup; inputs of the next tile
  *                    prefetched, constant block written by the DMA wave); automatic = every resident workgroup has
  *                    at least two tiles.  get-only "pipeline_active": 1 if the next launch uses it
- * "instance_align"   1 (default) | 2 | 4 | 8 | 16 | 32 doubles: in the device-resident calls with n_instances > 1 the g /
+ * "instance_align"   1 (default) or any power of two up to 65536 doubles: in the device-resident calls with n_instances > 1 the g /
  *                    values arrays of consecutive instances are rpm_get_option "stride_g" / "stride_values" doubles
  *                    apart (m, nnz_jac rounded up to this multiple) instead of packed back to back, so that every
  *                    instance starts on a 64/128-byte boundary like a separately allocated array; x stays packed; the

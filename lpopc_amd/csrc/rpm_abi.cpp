@@ -590,7 +590,7 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
       rpm::build_tiles(e, value);
     }
   } else if (k == "instance_align") {
-    if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) return fail(e, RPM_E_INVALID, "instance_align must be 1, 2, 4, 8, 16 or 32 doubles");
+    if (value < 1 || value > 65536 || (value & (value - 1))) return fail(e, RPM_E_INVALID, "instance_align must be a power of two between 1 and 65536 doubles");
     e.opt_instance_align = value;
   } else if (k == "const_once") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "const_once must be 0 or 1");
