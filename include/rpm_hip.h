@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RPM_ABI_VERSION 1
+#define RPM_ABI_VERSION 2
 
 /* ---- error codes -------------------------------------------------------- */
 enum {
@@ -255,8 +255,12 @@ int rpm_ipm_get_restorations(rpm_ipm* s, int* per_instance);
  * stream, summed over its iterations), for roofline figures */
 int rpm_ipm_get_kernel_times(rpm_ipm* s, double* factor_ms, double* substitution_ms);
 int rpm_ipm_solve(rpm_ipm* s, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error);
+/* Ordering contract of the device-resident form: the interior-point loop runs on the engine's private stream.  Before its
+ * first read of d_x (and first write of d_lambda) it waits for everything the caller has queued on `stream` (a hipStream_t,
+ * NULL = the legacy default stream) up to this call; it returns only after its own stream has drained, so on return the
+ * results in d_x / d_lambda are complete for the host and for work queued later on any stream. */
 int rpm_ipm_solve_dev(rpm_ipm* s, double* d_x, double* d_lambda, double* obj, int* status, int* iterations,
-                      double* kkt_error);
+                      double* kkt_error, void* stream);
 /* test hooks: KKT position of every unknown ([0,n) variables, slacks, then the m multipliers); factor + solve the
  * caller's matrices given in the band + border storage (host pointers, n_instances of each) */
 int rpm_ipm_get_permutation(rpm_ipm* s, int* pos, int capacity);

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-RPM_ABI_VERSION = 1
+RPM_ABI_VERSION = 2
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

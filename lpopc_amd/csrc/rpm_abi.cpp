@@ -88,6 +88,7 @@ int rpm_device_init(rpm_engine* h, int device_id) {
 int rpm_get_nlp_info(rpm_engine* h, int* n, int* m, int* nnz_jac_g, int* nnz_h_lag, int* index_style) {
   if (!h) return RPM_E_INVALID;
   Engine& e = h->e;
+  RPM_GUARD_BEGIN
   if (e.hessian_mode == RPM_HESSIAN_EXACT && nnz_h_lag) {
     // the Hessian pattern comes from a NaN-propagation probe of the device functor (LpDerivDependciesChecker.cpp),
     // so in exact mode the structure needs the GPU once per mesh
@@ -100,6 +101,7 @@ int rpm_get_nlp_info(rpm_engine* h, int* n, int* m, int* nnz_jac_g, int* nnz_h_l
   if (nnz_h_lag) *nnz_h_lag = e.nnz_h;
   if (index_style) *index_style = 0;  // TNLP::C_STYLE, LpopcIpopt.cpp:22
   return RPM_OK;
+  RPM_GUARD_END(e)
 }
 
 int rpm_get_bounds_info(rpm_engine* h, int n, double* x_l, double* x_u, int m, double* g_l, double* g_u) {
@@ -591,6 +593,8 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
     }
   } else if (k == "instance_align") {
     if (value < 1 || value > 65536 || (value & (value - 1))) return fail(e, RPM_E_INVALID, "instance_align must be a power of two between 1 and 65536 doubles");
+    if (e.ipm_attached > 0 && value != e.opt_instance_align)
+      return fail(e, RPM_E_INVALID, "instance_align cannot change while an rpm_ipm solver is attached to the engine (its buffers are sized from the strides)");
     e.opt_instance_align = value;
   } else if (k == "const_once") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "const_once must be 0 or 1");

@@ -181,7 +181,7 @@ void device_destroy(Engine& e) {
     if (p) (void)hipFree(p);
   if (d->d_flag) (void)hipFree(d->d_flag);
   if (d->h_flags2) (void)hipHostFree(d->h_flags2);   // d_flags2 is its device alias
-  for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.first));
+  for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.ptr));
   (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
   for (auto& row : d->segtab)
     for (auto& t : row)
@@ -404,22 +404,48 @@ int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t coun
 
 // Page-lock the caller's buffer once (Ipopt hands the same x / g / values arrays every iteration) so that
 // the copies are direct DMA at PCIe rate instead of staged pageable copies.  Best effort: failures are ignored.
-void dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
-  if (!e.opt_pin_host || !ptr || bytes < (64u << 10)) return;
+// At most PIN_MAX registrations are kept (least recently used goes first), so a caller that passes many distinct
+// buffers cannot accumulate page-locked memory; a range that overlaps a new one is dropped first (the caller freed
+// and re-allocated there).  The caller must keep a registered buffer mapped until rpm_destroy or until it has been
+// evicted (rpm_hip.h, option "pin_host").  Returns the device-visible alias of `ptr`, or nullptr when it is not pinned.
+void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
+  constexpr size_t PIN_MAX = 8;
+  if (!e.opt_pin_host || !ptr || bytes < (64u << 10)) return nullptr;
   Device& d = *e.dev;
-  for (auto& p : d.pinned)
-    if (p.first == ptr && p.second >= bytes) return;
-  for (auto it = d.pinned.begin(); it != d.pinned.end(); ++it)
-    if (it->first == ptr) {   // same address, grew: re-register
-      (void)hipHostUnregister(const_cast<void*>(it->first));
-      (void)hipGetLastError();
-      d.pinned.erase(it);
-      break;
+  const char* lo = static_cast<const char*>(ptr);
+  for (size_t i = 0; i < d.pinned.size(); ++i)
+    if (d.pinned[i].ptr == ptr && d.pinned[i].bytes >= bytes) {
+      Device::Pinned hit = d.pinned[i];
+      d.pinned.erase(d.pinned.begin() + i);
+      d.pinned.push_back(hit);            // most recently used last
+      return hit.dptr;
     }
-  if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
-    d.pinned.emplace_back(ptr, bytes);
-  else
+  for (size_t i = 0; i < d.pinned.size();) {   // overlapping older registration: the range was re-allocated
+    const char* plo = static_cast<const char*>(d.pinned[i].ptr);
+    if (lo < plo + d.pinned[i].bytes && plo < lo + bytes) {
+      (void)hipHostUnregister(const_cast<void*>(d.pinned[i].ptr));
+      (void)hipGetLastError();
+      d.pinned.erase(d.pinned.begin() + i);
+    } else {
+      ++i;
+    }
+  }
+  while (d.pinned.size() >= PIN_MAX) {
+    (void)hipHostUnregister(const_cast<void*>(d.pinned.front().ptr));
     (void)hipGetLastError();
+    d.pinned.erase(d.pinned.begin());
+  }
+  if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  void* dptr = nullptr;
+  if (hipHostGetDevicePointer(&dptr, const_cast<void*>(ptr), 0) != hipSuccess) {
+    (void)hipGetLastError();
+    dptr = nullptr;
+  }
+  d.pinned.push_back(Device::Pinned{ptr, bytes, dptr});
+  return dptr;
 }
 
 // ---- small helpers used by the C ABI (rpm_abi.cpp) ---------------------------------------------

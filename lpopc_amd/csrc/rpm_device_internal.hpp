@@ -73,7 +73,8 @@ struct Device {
          *d_lambda = nullptr, *d_hess = nullptr;
   double* d_partial = nullptr;  // objective partial sums
   int* d_flag = nullptr;        // non-finite flag of the host-pointer path
-  std::vector<std::pair<const void*, size_t>> pinned;   // caller buffers registered with hipHostRegister
+  struct Pinned { const void* ptr; size_t bytes; void* dptr; };
+  std::vector<Pinned> pinned;   // caller buffers registered with hipHostRegister (LRU order, capped), with their device aliases
   bool cache_valid = false;     // d_g / d_values hold the pair of the x last uploaded
   size_t lds_bytes = 0;
   int pl_slots = 0;             // resident workgroups the pipelined kernel is launched with (2 per CU)

@@ -166,6 +166,7 @@ struct Engine {
   int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
   const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)
   int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
+  int ipm_attached = 0;          // rpm_ipm solvers built on this engine: they size their buffers from stride_g/values
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
   std::vector<double> sol_x, sol_lambda;
   double sol_obj = 0.0;
@@ -243,6 +244,6 @@ int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b
 int dev_flags_fetch(Engine& e);
 int dev_flag_value(Engine& e, int slot);
 int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count);
-void dev_pin_host(Engine& e, const void* ptr, size_t bytes);       // page-lock a caller buffer once (best effort)            // the engine's own stream (host-pointer TNLP path)
+void* dev_pin_host(Engine& e, const void* ptr, size_t bytes);      // page-lock a caller buffer once (best effort); its device alias or nullptr
 
 }  // namespace rpm

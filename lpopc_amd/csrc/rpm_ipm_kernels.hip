@@ -829,9 +829,14 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
 __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
-  if (S.status != 0) return;
+  // every thread reads the instance's verdicts BEFORE thread 0 changes any of them (a late wave must not see
+  // enter_resto already cleared, or mode already switched, and skip its slice)
+  const int s_status = S.status, s_enter = S.enter_resto, s_accepted = S.accepted, s_mode = S.mode;
+  const double s_alpha = S.alpha, s_alpha_z = S.alpha_z, s_mu = S.mu;
+  __syncthreads();
+  if (s_status != 0) return;
   const size_t o = size_t(bi) * D.nv;
-  if (S.enter_resto) {          // the line search gave up at an infeasible point: start the feasibility restoration from it
+  if (s_enter) {          // the line search gave up at an infeasible point: start the feasibility restoration from it
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double vi = D.v[o + i], sc = fmax(1.0, fabs(vi));
       D.vR[o + i] = vi;
@@ -848,10 +853,10 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
     }
     return;
   }
-  if (!S.accepted) return;
-  if (S.mode == 1) {
+  if (!s_accepted) return;
+  if (s_mode == 1) {
     for (int i = t; i < D.nv; i += blockDim.x)
-      if (D.vl[o + i] != D.vu[o + i]) D.v[o + i] += S.alpha * D.dv[o + i];
+      if (D.vl[o + i] != D.vu[o + i]) D.v[o + i] += s_alpha * D.dv[o + i];
     if (t == 0) {
       if (D.trace && S.iter < D.trace_cap) {
         double* R = D.trace + (size_t(bi) * D.trace_cap + S.iter) * IPM_TRACE;
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
     }
     return;
   }
-  const double a = S.alpha, az = S.alpha_z, mu = S.mu, ks = D.o.kappa_sigma;
+  const double a = s_alpha, az = s_alpha_z, mu = s_mu, ks = D.o.kappa_sigma;
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
     if (l == u) continue;

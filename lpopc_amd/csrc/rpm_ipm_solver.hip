@@ -27,7 +27,9 @@ struct rpm_ipm {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // around the factorisation and the substitution of an iteration
   double factor_ms = 0.0, solve_ms = 0.0;
   bool solve_pending = false;
+  bool attached = false;
   ~rpm_ipm() {
+    if (attached && eng && eng->e.ipm_attached > 0) eng->e.ipm_attached -= 1;
     for (void* p : allocs) (void)hipFree(p);
     if (h_cnt) (void)hipHostFree(h_cnt);
     for (hipEvent_t e2 : ev)
@@ -106,6 +108,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   rpm_ipm* h = new (std::nothrow) rpm_ipm;
   if (!h) return RPM_E_INVALID;
   h->eng = eng;
+  e.ipm_attached += 1;   // freezes the engine's instance strides (rpm_set_option "instance_align"); released by ~rpm_ipm
+  h->attached = true;
   std::string why;
   rc = build_ipm_plan(e, h->plan, &why);
   if (rc) {
@@ -308,7 +312,8 @@ int rpm_ipm_get_permutation(rpm_ipm* h, int* pos, int capacity) {
   return RPM_OK;
 }
 
-int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, int* status, int* iterations, double* kkt_error) {
+int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, int* status, int* iterations, double* kkt_error,
+                      void* stream) {
   if (!h || !d_x) return RPM_E_INVALID;
   Engine& e = h->eng->e;
   IpmDev& D = h->D;
@@ -319,6 +324,15 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   h->total_factorizations = h->total_iterations = h->total_trials = 0;
   h->factor_ms = h->solve_ms = 0.0;
   h->solve_pending = false;
+  if (D.sg != e.stride_g() || D.sv != e.stride_values()) {   // rpm_set_option refuses this while a solver is attached; belt and braces
+    h->err = "rpm_ipm_solve_dev: the engine's instance strides changed after rpm_ipm_create";
+    return RPM_E_INVALID;
+  }
+  // Ordering contract (rpm_hip.h): the loop runs on the engine's private stream.  Its first read of d_x / its first write of
+  // d_lambda wait for everything the caller queued on `stream` before this call; the call returns after the solver's stream
+  // has drained, so the results are complete for every stream and for the host.
+  IPM_TRY(h, hipEventRecord(h->ev[0], static_cast<hipStream_t>(stream)));
+  IPM_TRY(h, hipStreamWaitEvent(st, h->ev[0], 0));
 
   IPM_TRY(h, hipMemcpyAsync(D.xt, d_x, size_t(B) * p.n * sizeof(double), hipMemcpyDeviceToDevice, st));
   ipm_launch_init(D, d_x, st);
@@ -404,7 +418,7 @@ int rpm_ipm_solve(rpm_ipm* h, double* x, double* lambda, double* obj, int* statu
   }
   int rc = RPM_OK;
   if (hipMemcpy(d_x, x, size_t(D.B) * p.n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = RPM_E_DEVICE;
-  if (!rc) rc = rpm_ipm_solve_dev(h, d_x, d_l, obj, status, iterations, kkt_error);
+  if (!rc) rc = rpm_ipm_solve_dev(h, d_x, d_l, obj, status, iterations, kkt_error, nullptr);   // blocking copies above: nothing in flight
   if (!rc && hipMemcpy(x, d_x, size_t(D.B) * p.n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RPM_E_DEVICE;
   if (!rc && lambda && hipMemcpy(lambda, d_l, size_t(D.B) * p.m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RPM_E_DEVICE;
   (void)hipFree(d_x);

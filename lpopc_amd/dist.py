@@ -72,12 +72,17 @@ class SweepShard:
         import torch
         out = {}
         longest = shard_instances(self.total, 0, self.world)[1]
-        for k in keys:
+        # RCCL ("nccl") moves device memory only: stage the few verdict numbers on this rank's GPU; gloo takes host tensors
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend() == "nccl" else torch.device("cpu")
+        send = torch.zeros(len(keys) * longest, dtype=torch.float64)
+        for j, k in enumerate(keys):
             a = np.asarray(local[k], dtype=np.float64).reshape(-1)
             assert a.size == self.count, "solve_local returned %d entries for %d instances" % (a.size, self.count)
-            send = torch.zeros(longest, dtype=torch.float64)
-            send[:a.size] = torch.from_numpy(a)
-            recv = [torch.zeros(longest, dtype=torch.float64) for _ in range(self.world)]
-            self.dist.all_gather(recv, send)
-            out[k] = np.concatenate([recv[r][:shard_instances(self.total, r, self.world)[1]].numpy() for r in range(self.world)])
+            send[j * longest:j * longest + a.size] = torch.from_numpy(a)
+        send = send.to(dev)
+        recv = torch.zeros(self.world * len(keys) * longest, dtype=torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(recv, send)    # ONE collective for all keys
+        recv = recv.cpu().numpy().reshape(self.world, len(keys), longest)
+        for j, k in enumerate(keys):
+            out[k] = np.concatenate([recv[r, j, :shard_instances(self.total, r, self.world)[1]] for r in range(self.world)])
         return out

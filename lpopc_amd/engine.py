@@ -112,7 +112,7 @@ def lib():
     L.rpm_ipm_get_restorations.argtypes = [vp, ip]
     L.rpm_ipm_get_kernel_times.argtypes = [vp, dp, dp]
     L.rpm_ipm_solve.argtypes = [vp, dp, dp, dp, ip, ip, dp]
-    L.rpm_ipm_solve_dev.argtypes = [vp, vp, vp, dp, ip, ip, dp]
+    L.rpm_ipm_solve_dev.argtypes = [vp, vp, vp, dp, ip, ip, dp, vp]
     L.rpm_ipm_get_permutation.argtypes = [vp, ip, C.c_int]
     L.rpm_ipm_debug_solve.argtypes = [vp, dp, dp, dp, ip, ip]
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
@@ -521,11 +521,13 @@ class BatchedIPM:
         self._chk(self._L.rpm_ipm_solve(self._h, _dp(x), _dp(lam), _dp(obj), _ip(status), _ip(iters), _dp(err)))
         return {"x": x, "lambda": lam, "obj": obj, "status": status, "iterations": iters, "kkt_error": err}
 
-    def solve_dev(self, d_x, d_lambda=None):
-        """d_x: torch CUDA tensor (n_instances, n), overwritten with the solutions; d_lambda: optional (n_instances, m)."""
+    def solve_dev(self, d_x, d_lambda=None, stream=None):
+        """d_x: torch CUDA tensor (n_instances, n), overwritten with the solutions; d_lambda: optional (n_instances, m).
+        The solver waits for what is queued on `stream` (default: torch's current stream) before it touches the arrays."""
         B = self._e.n_instances
         obj, err = np.zeros(B), np.zeros(B)
         status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
         lp = C.c_void_p(d_lambda.data_ptr()) if d_lambda is not None else None
-        self._chk(self._L.rpm_ipm_solve_dev(self._h, C.c_void_p(d_x.data_ptr()), lp, _dp(obj), _ip(status), _ip(iters), _dp(err)))
+        self._chk(self._L.rpm_ipm_solve_dev(self._h, C.c_void_p(d_x.data_ptr()), lp, _dp(obj), _ip(status), _ip(iters), _dp(err),
+                                            NLPEngine._stream(stream)))
         return {"obj": obj, "status": status, "iterations": iters, "kkt_error": err}

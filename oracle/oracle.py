@@ -27,9 +27,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liborpm.so")
-        if not os.path.exists(so):
-            build()
+        so = build()   # mtime check against the C sources: a stale liborpm.so is rebuilt, never silently loaded
         L = C.CDLL(so)
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
         L.orpm_create.restype = C.c_void_p
