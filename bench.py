@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — eval_g+eval_jac_g throughput on the 4-phase, 4096-LGR-point Delta-III problem.
+"""bench.py — eval_g+eval_jac_g throughput on the 4-phase, 4096-LGR-point Delta-III problem (BASELINE.json's metric).
 
-A "step" is one (eval_g, eval_jac_g) pair at a fresh NLP iterate x_k (new_x = true), evaluated by the
-fused HIP pair kernel with x already resident in HBM.  R distinct seeded iterates are kept in HBM and
-cycled.  At --gpus N > 1 every rank evaluates its own stream of iterates (independent problem
-instances: multi-start / MPC-sweep sharding, no data-path collective), so the scaling is weak and
-`value` is N*K pairs over the max-over-ranks time.  `--shard intervals` instead splits ONE problem's
-mesh intervals over the ranks and all-gathers g / values with RCCL (strong scaling).
+A "step" is one fused (eval_g, eval_jac_g) launch over one batch of B distinct NLP iterates x_k (new_x = true for each)
+already resident in HBM; R iterates are kept resident and cycled so that the outputs do not live in the Infinity Cache.
+The K steps are captured in one hipGraph.  ONE timed region = exactly K steps bracketed by barrier + synchronize; the
+region is repeated until at least 0.25 s have been timed and `value` / `ms_per_step` come from the MEDIAN region (p10 / p90
+beside it) — a single 20-step region is 2 ms and scatters by 15 %.  Per-rank times are reduced with MAX over ranks.
 
-Contract line (one JSON object on stdout, rank 0):
-  metric/unit  BASELINE.json's metric: eval_g+eval_jac_g pairs per second
-  roofline     HBM roofline of the dominant kernel rpm_tile_kernel: algorithmic bytes per launch
-               (8(2n+m+nnz)+8 sum N_k(N_k+1)) / average launch duration measured with HIP
-               events on the launch stream over the timed region
-  cpu_baseline the CPU oracle (a C port of lpopc's algorithm, oracle/) timed on one host core on a
-               bounded sample of the same workload
+At --gpus N > 1 `value` is the instance-sharded (weak-scaling) rate of that workload: every rank evaluates its own
+stream of iterates, no data-path collective.  The SAME invocation also measures, with all N ranks on the data path:
+  strong_scaling   mesh intervals of ONE config-3 / config-4 problem sharded over the ranks, ONE packed RCCL all-gather of
+                   the g + Jacobian segments per step, pack / all-gather / unpack captured in the step's hipGraph;
+  host_consumer    the same sharding with a host-side consumer (Ipopt's position): every rank stores its runs of g / values
+                   into one shared page-locked host array over its own PCIe link, no GPU-to-GPU traffic;
+  config5          the 1024-instance quadrotor sweep sharded by instance.
+
+Extra first-class sections on rank 0 at N = 1 (what a TNLP caller can consume):
+  sequential       B = 1 device-resident pairs/s (a sequential solver loop on the device)
+  host_pointer     PCIe-inclusive pairs/s through rpm_eval_g / rpm_eval_jac_g / rpm_eval_pair on caller-owned arrays
+  ms_per_ipopt_iter  eval_f + eval_grad_f + eval_g + eval_jac_g at ONE iterate, device-resident and host-pointer
+  roofline         HBM roofline of the dominant kernel: algorithmic bytes per launch / launch duration from HIP events
+  cpu_baseline     the CPU oracle (a C port of lpopc's algorithm, oracle/) on one host core, bounded sample
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,15 +33,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MIN_TIMED_S = 0.25
+
+
+def d_tile_doubles(eng):
+    return sum(eng.phase_tables(p)["d_vals"].size for p in range(eng.n_phases))
 
 
 def algorithmic_bytes(eng):
     """read x once per callback, write g, write every Jacobian value, read each D tile once."""
-    d_tiles = 0
-    for p in range(eng.n_phases):
-        t = eng.phase_tables(p)
-        d_tiles += t["d_vals"].size
-    return 8 * (2 * eng.n + eng.m + eng.nnz_jac) + 8 * d_tiles
+    return 8 * (2 * eng.n + eng.m + eng.nnz_jac) + 8 * d_tile_doubles(eng)
+
+
+def fused_bytes(eng):
+    """What the fused pair launch moves: x once."""
+    return 8 * (eng.n + eng.m + eng.nnz_jac) + 8 * d_tile_doubles(eng)
 
 
 def cpu_baseline(prob, xs, budget_s):
@@ -58,6 +71,289 @@ def cpu_baseline(prob, xs, budget_s):
                       % (pairs, el)}
 
 
+class Ctx:
+    """Process-wide handles: rank / world, torch, torch.distributed (or None)."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        self.dist = None
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1 or "RANK" in os.environ:   # under torch.distributed.run: always go through the RCCL path
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def barrier_sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+
+def timed_regions(ctx, step, K, warmup, use_graph=True, min_s=None, max_regions=400):
+    """W warm-up steps, then regions of EXACTLY K steps each (one hipGraph replay when the steps can be captured), each
+    bracketed by barrier + synchronize, repeated until min_s seconds have been timed.  Returns wall seconds and device
+    milliseconds per region (MAX over ranks), and how the steps were launched."""
+    torch = ctx.torch
+    min_s = MIN_TIMED_S if min_s is None else min_s
+    for k in range(warmup):
+        step(k)
+    ctx.barrier_sync()
+    graph, how = None, "eager launches"
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step(0)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(K):
+                    step(k)
+            graph.replay()  # one untimed replay (graph upload)
+            how = "hipGraph replay of the K steps"
+        except Exception as ex:   # e.g. a collective that cannot be captured: measure eagerly and say so
+            graph = None
+            how = "eager launches (graph capture failed: %s)" % str(ex).splitlines()[0][:120]
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def region():
+        ctx.barrier_sync()
+        t0 = time.perf_counter()
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for k in range(K):
+                step(k)
+        ev1.record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return el, ev0.elapsed_time(ev1)
+
+    first = region()
+    n = int(min(max_regions, max(5, math.ceil(min_s / max(first[0], 1e-6)))))
+    n = int(ctx.max_over_ranks([float(n)])[0])   # the same count on every rank
+    wall, dev = [first[0]], [first[1]]
+    for _ in range(n - 1):
+        a, b = region()
+        wall.append(a)
+        dev.append(b)
+    ctx.barrier_sync()
+    wall = ctx.max_over_ranks(wall)
+    dev = ctx.max_over_ranks(dev)
+    return {"wall_s": wall, "dev_ms": dev, "launch": how, "graph": graph}
+
+
+def pct(sorted_vals, q):
+    return sorted_vals[min(len(sorted_vals) - 1, int(q * len(sorted_vals)))]
+
+
+def summarize(regions, K, units_per_step):
+    w = sorted(regions["wall_s"])
+    d = sorted(regions["dev_ms"])
+    med = w[len(w) // 2]
+    return {"pairs_per_s": K * units_per_step / med, "ms_per_step": med * 1e3 / K,
+            "ms_per_step_p10": pct(w, 0.1) * 1e3 / K, "ms_per_step_p90": pct(w, 0.9) * 1e3 / K,
+            "dev_ms_per_step": d[len(d) // 2] / K, "timed_regions": len(w), "timed_seconds": sum(w),
+            "first_region_ms_per_step": regions["wall_s"][0] * 1e3 / K, "launch": regions["launch"]}
+
+
+def make_iterates(problems, eng, count, seed0, mode="perturb"):
+    xl, xu, _, _ = eng.get_bounds_info()
+    x0 = eng.get_starting_point()
+    return [problems.seeded_iterate(x0, xl, xu, seed0 + r, mode) for r in range(count)]
+
+
+def device_workload(ctx, args, prob, B, R, K, warmup, sharded, seed0, mode="perturb", align=16, use_graph=True,
+                    role_loop=-1, pipeline=-1, dx_mode=0, tile_nodes=0, unfused=False, keep=False):
+    """The fused pair kernel over R resident iterates, B per step; with `sharded` the mesh intervals of every iterate are split
+    over the ranks and the results exchanged with ONE packed all-gather per step."""
+    import numpy as np
+    from lpopc_amd import problems
+    from lpopc_amd.engine import NLPEngine
+    torch = ctx.torch
+    sh = sharded and ctx.world > 1
+    eng = NLPEngine(prob, n_instances=B, shard_mode=1 if sh else 0, shard_rank=ctx.rank if sh else 0,
+                    shard_world=ctx.world if sh else 1, tile_nodes=tile_nodes, device=ctx.local_rank, role_loop=role_loop)
+    if dx_mode:
+        eng.set_option("dx_mode", dx_mode)
+    if pipeline != -1:
+        eng.set_option("pipeline", pipeline)
+    eng.set_option("instance_align", align)   # every iterate's g / values array starts on a 128-byte line (DESIGN.md §4)
+    R = max(R, 2 * B)
+    R -= R % B
+    xs = make_iterates(problems, eng, R, seed0, mode)
+    d_x = torch.from_numpy(np.stack(xs)).cuda()
+    sg, sv = eng.get_option("stride_g"), eng.get_option("stride_values")
+    d_g = torch.empty((R, sg), dtype=torch.float64, device="cuda")
+    d_v = torch.empty((R, sv), dtype=torch.float64, device="cuda")
+    xch = None
+    if sh:
+        from lpopc_amd.dist import IntervalExchange
+        xch = IntervalExchange(eng, ctx.dist, ctx.world, ctx.rank)
+
+    def step(k):
+        r = (k * B) % R          # this step's batch of B consecutive resident iterates
+        if unfused:
+            eng.eval_g_dev(d_x[r], d_g[r])
+            eng.eval_jac_g_dev(d_x[r], d_v[r])
+        else:
+            eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
+        if xch is not None:
+            xch.exchange(d_g[r], d_v[r])
+
+    regions = timed_regions(ctx, step, K, warmup, use_graph=use_graph)
+    regions.pop("graph", None)
+    out = summarize(regions, K, B)
+    out.update({"iterates_per_step": B, "resident_iterates": R, "n": eng.n, "m": eng.m, "nnz_jac": eng.nnz_jac,
+                "kernel": ("rpm_tile_pl_kernel" if eng.get_option("pipeline_active") else
+                           "rpm_tile_rl_kernel" if eng.get_option("role_loop") else "rpm_tile_kernel"),
+                "tile_nodes": eng.get_option("tile_nodes")})
+    if xch is not None:
+        out["allgather_bytes_received_per_step"] = xch.bytes_received_per_step()
+        out["collective"] = "one in-place RCCL all_gather_into_tensor of the packed [world][slot] buffer per step"
+    if keep:
+        return out, eng, xs, d_x, d_g, d_v
+    eng.close()
+    return out
+
+
+def check_against_single_evaluation(ctx, args, prob, eng, d_x, d_g, d_v, R):
+    """Results of the timed region are finite and equal to a fresh single evaluation."""
+    from lpopc_amd.engine import NLPEngine
+    torch = ctx.torch
+    one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=ctx.local_rank)
+    if args.dx_mode:
+        one.set_option("dx_mode", args.dx_mode)
+    chk_g = torch.empty(eng.m, dtype=torch.float64, device="cuda")
+    chk_v = torch.empty(eng.nnz_jac, dtype=torch.float64, device="cuda")
+    for r in (0, R - 1):
+        one.eval_pair_dev(d_x[r], chk_g, chk_v)
+        torch.cuda.synchronize()
+        assert torch.equal(chk_g, d_g[r, :eng.m]) and torch.equal(chk_v, d_v[r, :eng.nnz_jac]) and bool(torch.isfinite(chk_v).all())
+    one.close()
+
+
+def sequential_section(ctx, args, prob, xs):
+    """B = 1: what a sequential solver loop on the device sees (latency-bound), and one synthetic Ipopt iteration
+    (eval_f + eval_grad_f + eval_g + eval_jac_g at ONE iterate) with everything resident in HBM."""
+    import numpy as np
+    from lpopc_amd.engine import NLPEngine
+    torch = ctx.torch
+    one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=ctx.local_rank)
+    R1 = min(len(xs), 256)
+    d_x = torch.from_numpy(np.stack(xs[:R1])).cuda()
+    d_g = torch.empty((R1, one.m), dtype=torch.float64, device="cuda")
+    d_v = torch.empty((R1, one.nnz_jac), dtype=torch.float64, device="cuda")
+    d_f = torch.empty(1, dtype=torch.float64, device="cuda")
+    d_grad = torch.empty((R1, one.n), dtype=torch.float64, device="cuda")
+    K1 = 256
+    reg = timed_regions(ctx, lambda k: one.eval_pair_dev(d_x[k % R1], d_g[k % R1], d_v[k % R1]), K1, 20)
+    reg.pop("graph", None)
+    s = summarize(reg, K1, 1)
+    us = s["dev_ms_per_step"] * 1e3
+    seq = {"pairs_per_s": s["pairs_per_s"], "us_per_pair": s["ms_per_step"] * 1e3, "launch_us": us,
+           "hbm_frac": algorithmic_bytes(one) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "hbm_frac_fused_bytes": fused_bytes(one) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "kernel": "rpm_tile_kernel (one role per thread, one iterate per launch)", "timed_regions": s["timed_regions"],
+           "launch": s["launch"]}
+
+    def it(k):
+        r = k % R1
+        one.eval_f_dev(d_x[r], d_f)
+        one.eval_grad_f_dev(d_x[r], d_grad[r])
+        one.eval_pair_dev(d_x[r], d_g[r], d_v[r])
+    reg = timed_regions(ctx, it, 64, 10)
+    reg.pop("graph", None)
+    s2 = summarize(reg, 64, 1)
+    one.close()
+    return seq, s2["ms_per_step"]
+
+
+def host_section(ctx, args, prob, xs):
+    from lpopc_amd.engine import NLPEngine
+    from lpopc_amd.hostbench import time_host_path, time_ipopt_iteration
+    mk = lambda: NLPEngine(prob, device=ctx.local_rank)   # noqa: E731
+    res = time_host_path(mk, xs[:4], seconds=0.4)
+    it_plain = time_ipopt_iteration(mk, xs[:4], options={"pin_host": 1})
+    it_delta = time_ipopt_iteration(mk, xs[:4], options={"pin_host": 1, "delta_values": 1})
+    note = ("PCIe-inclusive, wall clock around the C-ABI calls on caller-owned arrays handed again and again (as Ipopt's "
+            "TNLPAdapter does); never `value`.  two_calls = rpm_eval_g(new_x=1) + rpm_eval_jac_g(new_x=0); pair_call = "
+            "rpm_eval_pair; const_once / delta = only the part of `values` that changed crosses PCIe (rpm_hip.h)")
+    return {"note": note, "variants": res}, it_plain, it_delta
+
+
+def host_consumer_section(ctx, args, prob, B=1):
+    """All ranks store their interval shares of g / values into ONE shared page-locked host array (no GPU-to-GPU traffic)."""
+    import numpy as np
+    from lpopc_amd import problems
+    from lpopc_amd.dist import HostConsumerGroup
+    from lpopc_amd.engine import NLPEngine
+    sh = ctx.world > 1
+    eng = NLPEngine(prob, n_instances=B, shard_mode=1 if sh else 0, shard_rank=ctx.rank if sh else 0,
+                    shard_world=ctx.world if sh else 1, device=ctx.local_rank)
+    grp = None
+    try:
+        if ctx.dist is None:
+            raise RuntimeError("needs torch.distributed")
+        grp = HostConsumerGroup(eng, ctx.dist, eng.n, eng.m, eng.nnz_jac, n_instances=B)
+        xs = make_iterates(problems, eng, 4 * B, 3)
+        if ctx.rank == 0:
+            for i in range(4):
+                grp.x[i][:] = np.concatenate(xs[i * B:(i + 1) * B])
+        ctx.dist.barrier()
+        for k in range(10):
+            grp.step(k & 3)
+        K = 200
+        ts = []
+        for rep in range(6):
+            ctx.dist.barrier()
+            t0 = time.perf_counter()
+            for k in range(K):
+                grp.step(k & 3)
+            ts.append(time.perf_counter() - t0)
+        ts = sorted(ctx.max_over_ranks(ts))
+        med = ts[len(ts) // 2]
+        ok = True
+        if ctx.rank == 0:   # the assembled arrays equal a single-GPU evaluation of the last iterate
+            ref = NLPEngine(prob, n_instances=B, device=ctx.local_rank)
+            g_ref, v_ref = ref.eval_pair(np.array(grp.x[(K - 1) & 3]))
+            ok = bool(np.array_equal(g_ref, np.array(grp.g)) and np.array_equal(v_ref, np.array(grp.values)))
+            ref.close()
+        return {"pairs_per_s": K * B / med, "us_per_pair": med * 1e6 / (K * B), "iterates_per_call": B,
+                "equals_single_gpu_result": ok, "timed_regions": len(ts),
+                "how": "interval-sharded engines, x read from / g stored into / changed runs of values stored into one shared "
+                       "page-locked host segment, every rank over its own PCIe link; go/done words in the same segment"}
+    finally:
+        eng.close()          # releases its page-locked registrations of the segment before the segment is unmapped
+        if grp is not None:
+            grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,11 +365,13 @@ def main():
                          "runs 13 %% faster than HBM allows)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--unfused", action="store_true", help="separate eval_g and eval_jac_g kernels per step")
-    ap.add_argument("--shard", choices=["instances", "intervals"], default="instances")
+    ap.add_argument("--shard", choices=["instances", "intervals"], default="instances",
+                    help="what `value` measures at --gpus N > 1 (the other split is reported in its own section either way)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-main", action="store_true", help="skip every section but the main metric")
     ap.add_argument("--profile", action="store_true",
-                    help="profiling run: only the warm-up and the timed launches (no extra checks/sections), so that\n"
+                    help="profiling run: only the warm-up and ONE timed region (no extra checks/sections), so that\n"
                          "rocprofv3 --stats averages exactly the launches bench.py times")
     ap.add_argument("--dx-mode", type=int, default=0, help="0: scalar D.X in the reference's order, 1: FP64 MFMA tiles")
     ap.add_argument("--tile-nodes", type=int, default=0)
@@ -88,149 +386,59 @@ def main():
     ap.add_argument("--nodes", type=int, default=16)
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
     from lpopc_amd import problems
-    from lpopc_amd.engine import NLPEngine
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    dist = None
-    if world > 1 or "RANK" in os.environ:   # under torch.distributed.run: always go through the RCCL path
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+    ctx = Ctx(args)
+    rank, world = ctx.rank, ctx.world
+    global MIN_TIMED_S
+    if args.profile:
+        MIN_TIMED_S = 0.0
+    errors = {}
 
     prob = problems.launch(args.intervals, args.nodes)
     sharded = args.shard == "intervals" and world > 1
     B = max(1, args.batch)
-    if sharded and B != 1:
-        raise SystemExit("--shard intervals evaluates one iterate per launch")
-    eng = NLPEngine(prob, n_instances=B, shard_mode=1 if sharded else 0, shard_rank=rank if sharded else 0,
-                    shard_world=world if sharded else 1, tile_nodes=args.tile_nodes, device=local_rank, role_loop=args.role_loop)
-    if args.dx_mode:
-        eng.set_option("dx_mode", args.dx_mode)
-    if args.pipeline != -1:
-        eng.set_option("pipeline", args.pipeline)
-    xl, xu, _, _ = eng.get_bounds_info()
-    x0 = eng.get_starting_point()
-    R = max(args.iterates, 2 * B)
-    R -= R % B
     # rank-specific iterates in the weak-scaling mode, identical ones when one problem is sharded
     seed0 = 3 if sharded else 3 + 1000 * rank
-    xs = [problems.seeded_iterate(x0, xl, xu, seed0 + r) for r in range(R)]
-    d_x = torch.from_numpy(np.stack(xs)).cuda()
-    # every iterate's g / values array starts on a 128-byte boundary, as separately allocated arrays would: packed
-    # back to back (m and nnz_jac are not multiples of 8) three quarters of the store runs would straddle 64-byte
-    # granules, which costs the HBM write path a third of its rate (tools/ubench/store_pattern.py)
-    if not sharded:
-        eng.set_option("instance_align", args.instance_align)
-    sg, sv = eng.get_option("stride_g"), eng.get_option("stride_values")
-    d_g = torch.empty((R, sg), dtype=torch.float64, device="cuda")
-    d_v = torch.empty((R, sv), dtype=torch.float64, device="cuda")
-    comm = None
-    if sharded:
-        from lpopc_amd.dist import IntervalGather
-        comm = IntervalGather(eng, dist, world)
+    main_res, eng, xs, d_x, d_g, d_v = device_workload(
+        ctx, args, prob, B, args.iterates, args.steps, args.warmup, sharded, seed0, align=args.instance_align,
+        use_graph=not args.no_graph, role_loop=args.role_loop, pipeline=args.pipeline, dx_mode=args.dx_mode,
+        tile_nodes=args.tile_nodes, unfused=args.unfused, keep=True)
+    R = main_res["resident_iterates"]
+    if not sharded and not os.environ.get("RPM_DIAG_MASK") and not args.profile:
+        check_against_single_evaluation(ctx, args, prob, eng, d_x, d_g, d_v, R)
 
-    def step(k):
-        r = (k * B) % R          # this step's batch of B consecutive resident iterates
-        if args.unfused:
-            eng.eval_g_dev(d_x[r], d_g[r])
-            eng.eval_jac_g_dev(d_x[r], d_v[r])
-        else:
-            eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
-        if comm is not None:
-            comm.all_gather(d_g[r], d_v[r])
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for k in range(args.warmup):
-        step(k)
-    sync_all()
-
-    use_graph = not args.no_graph and comm is None
-    graph = None
-    if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step(0)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for k in range(args.steps):
-                step(k)
-        graph.replay()  # one untimed replay (graph upload)
-        sync_all()
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    sync_all()
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for k in range(args.steps):
-            step(k)
-    ev1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
-
-    # sanity: results of the timed region are finite and equal to a fresh single evaluation
-    if comm is None and not os.environ.get("RPM_DIAG_MASK") and not args.profile:
-        one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
-        if args.dx_mode:
-            one.set_option("dx_mode", args.dx_mode)
-        chk_g = torch.empty(eng.m, dtype=torch.float64, device="cuda")
-        chk_v = torch.empty(eng.nnz_jac, dtype=torch.float64, device="cuda")
-        for r in (0, R - 1):
-            one.eval_pair_dev(d_x[r], chk_g, chk_v)
-            torch.cuda.synchronize()
-            assert torch.equal(chk_g, d_g[r, :eng.m]) and torch.equal(chk_v, d_v[r, :eng.nnz_jac]) and bool(torch.isfinite(chk_v).all())
-        one.close()
-
+    out = None
     if rank == 0:
-        units_per_step = B * (1 if sharded else world)
-        pairs = args.steps * units_per_step
-        value = pairs / elapsed
-        bytes_per_launch = algorithmic_bytes(eng) * B
+        units = B * (1 if sharded else world)
         launches_per_step = 2 if args.unfused else 1
-        launch_us = dev_ms * 1e3 / (args.steps * launches_per_step)
-        achieved = bytes_per_launch / (dev_ms * 1e-3 / args.steps) / 1e9
-        traffic = None
-        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this
-        # exact command, committed under profiles/ (tools/collect_profiles.sh regenerates it)
+        dev_ms_per_step = main_res["dev_ms_per_step"]
+        bytes_per_launch = algorithmic_bytes(eng) * B
+        achieved = bytes_per_launch / (dev_ms_per_step * 1e-3) / 1e9   # algorithmic bytes of a step / device time of a step
+        achieved_fused = fused_bytes(eng) * B / (dev_ms_per_step * 1e-3) / 1e9
+        traffic, traffic_source = None, None
+        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this exact
+        # command, committed under profiles/ (tools/collect_profiles.sh regenerates it): STATIC, not measured in this run
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp) and B == 64 and not args.unfused and args.intervals == 64 and args.nodes == 16:   # the default command
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "static: profiles/pmc_traffic.json (%s), rocprofv3 --pmc passes of this command, not measured in this run" % tj.get("tag", "r01")
             except Exception:
                 traffic = None
         out = {
             "metric": "eval_g+eval_jac_g calls/sec, 4-phase 4096-LGR-pt problem",
-            "value": value,
+            "value": main_res["pairs_per_s"] * (1 if sharded else world),
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
+            "ms_per_step": main_res["ms_per_step"],
+            "ms_per_step_p10": main_res["ms_per_step_p10"],
+            "ms_per_step_p90": main_res["ms_per_step_p90"],
+            "timed_regions": main_res["timed_regions"],
+            "timed_seconds": main_res["timed_seconds"],
+            "first_region_ms_per_step": main_res["first_region_ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
@@ -242,69 +450,105 @@ def main():
                             % (args.intervals, args.nodes, eng.n, eng.m, eng.nnz_jac, R, B),
                 "pair": "unfused: eval_g kernel + eval_jac_g kernel" if args.unfused else
                         "fused: one tile-kernel launch writes g and all Jacobian values of the step's iterates",
-                "launch": "hipGraph replay of the K steps" if graph is not None else "eager launches",
-                "tile_nodes": eng.get_option("tile_nodes"),
-                "thread_layout": ("persistent workgroups of two halves, each 4 compute waves + 2 DMA waves (rpm_tile_pl_kernel)" if eng.get_option("pipeline_active")
-                                  else "64 nodes x 4 role groups (roles looped)" if eng.get_option("role_loop") else "16 nodes x (nx+nu+2) roles"),
+                "timing": "each timed region = exactly `steps` steps between barrier+synchronize; regions repeated until >= %.2f s; "
+                          "value and ms_per_step are the median region (max over ranks per region)" % MIN_TIMED_S,
+                "launch": main_res["launch"],
+                "tile_nodes": main_res["tile_nodes"],
+                "thread_layout": ("persistent workgroups of two halves, each 4 compute waves + 2 DMA waves (rpm_tile_pl_kernel)" if main_res["kernel"] == "rpm_tile_pl_kernel"
+                                  else "64 nodes x 4 role groups (roles looped)" if main_res["kernel"] == "rpm_tile_rl_kernel" else "16 nodes x (nx+nu+2) roles"),
                 "dx_mode": "mfma_f64_16x16x4" if args.dx_mode else "scalar, reference summation order",
-                "parallelism": ("intervals sharded x%d + RCCL all-gather" % world) if sharded else
+                "parallelism": ("intervals sharded x%d + one packed RCCL all-gather per step" % world) if sharded else
                                ("independent instances x%d" % world),
-                "ms_per_ipopt_iter_synthetic": None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("rpm_tile_pl_kernel" if eng.get_option("pipeline_active") else
-                           "rpm_tile_rl_kernel" if eng.get_option("role_loop") else "rpm_tile_kernel"),
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_fused_bytes": achieved_fused / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": main_res["kernel"],
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_pair": bytes_per_launch // B,
-                "avg_launch_us": launch_us,
+                "fused_bytes_per_pair": fused_bytes(eng),
+                "avg_launch_us": dev_ms_per_step * 1e3 / launches_per_step,
+                "how": "median over the timed regions of (HIP-event time of the region / launches in it)",
             },
         }
-        # synthetic "ms per IPOPT iteration": one each of eval_f, eval_grad_f, eval_g, eval_jac_g at one x
-        d_obj = torch.empty(B, dtype=torch.float64, device="cuda")
-        d_grad = torch.empty((B, eng.n), dtype=torch.float64, device="cuda")
-        if comm is None and not args.profile:
-            torch.cuda.synchronize()
-            ti = time.perf_counter()
-            nit = 200
-            for k in range(nit):
-                r = (k * B) % R
-                eng.eval_f_dev(d_x[r], d_obj)
-                eng.eval_grad_f_dev(d_x[r], d_grad)
-                eng.eval_pair_dev(d_x[r], d_g[r], d_v[r])
-            torch.cuda.synchronize()
-            out["config"]["ms_per_ipopt_iter_synthetic"] = (time.perf_counter() - ti) * 1e3 / (nit * B)
-        if comm is None and B > 1 and not args.profile:
-            # the same kernel with ONE iterate per launch (what a sequential Ipopt loop sees): latency-bound
-            one = NLPEngine(prob, tile_nodes=args.tile_nodes, device=local_rank)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g1 = torch.cuda.CUDAGraph()
-            for k in range(20):
-                one.eval_pair_dev(d_x[k % R], d_g[k % R], d_v[k % R])
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g1):
-                for k in range(256):
-                    one.eval_pair_dev(d_x[k % R], d_g[k % R], d_v[k % R])
-            g1.replay()
-            torch.cuda.synchronize()
-            e0.record()
-            g1.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            us1 = e0.elapsed_time(e1) * 1e3 / 256
-            out["config"]["single_iterate_per_launch"] = {
-                "pairs_per_s": 1e6 / us1, "launch_us": us1,
-                "hbm_frac": algorithmic_bytes(one) / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS}
-            one.close()
-        if not args.no_cpu_baseline and not args.profile:
-            out["cpu_baseline"] = cpu_baseline(prob, xs, args.cpu_seconds)
+    xs_main = xs
+    eng.close()
+    del d_x, d_g, d_v
+    ctx.torch.cuda.empty_cache()
+
+    extras = not args.profile and not args.only_main
+    # ---- rank 0 alone, N = 1: what a TNLP caller can consume --------------------------------------------------------
+    if extras and world == 1 and rank == 0:
+        try:
+            seq, it_dev_ms = sequential_section(ctx, args, prob, xs_main)
+            out["sequential"] = seq
+            out["ms_per_ipopt_iter"] = {"device_resident_b1": it_dev_ms,
+                                        "what": "eval_f + eval_grad_f + eval_g + eval_jac_g at ONE iterate (Core/LpopcIpopt.cpp:106-181), "
+                                                "median; Ipopt itself is absent, so no linear-solver time is in it"}
+        except Exception as ex:
+            errors["sequential"] = repr(ex)
+        try:
+            hp, it_plain, it_delta = host_section(ctx, args, prob, xs_main)
+            out["host_pointer"] = hp
+            out.setdefault("ms_per_ipopt_iter", {})["host_pointer_pinned"] = it_plain
+            out["ms_per_ipopt_iter"]["host_pointer_pinned_delta"] = it_delta
+        except Exception as ex:
+            errors["host_pointer"] = repr(ex)
+
+    # ---- every rank: the other splits, so that at N > 1 the collective path is measured too ----------------------------
+    if extras:
+        secs = {}
+        K2 = max(20, min(args.steps, 200))
+        plan = [
+            ("config3_intervals_b1", lambda: problems.launch(args.intervals, args.nodes), 1, 128, "perturb"),
+            ("config3_intervals_b16", lambda: problems.launch(args.intervals, args.nodes), 16, 256, "perturb"),
+            ("config4_hypersensitive_hp_intervals_b1", lambda: problems.config("hypersensitive"), 1, 256, "uniform"),
+            ("config4_hypersensitive_hp_intervals_b64", lambda: problems.config("hypersensitive"), 64, 1024, "uniform"),
+        ]
+        for name, mk, b, r, mode in plan:
+            try:
+                secs[name] = device_workload(ctx, args, mk(), b, r, K2, 10, True, 3, mode=mode, use_graph=not args.no_graph)
+            except Exception as ex:
+                errors[name] = repr(ex)
+        if out is not None:
+            out["strong_scaling"] = {
+                "what": "ONE problem's mesh intervals sharded over the %d rank(s); every rank ends each step with the complete g and "
+                        "Jacobian of every iterate (device consumer); pairs_per_s is whole-job" % world,
+                "workloads": secs}
+        # config 5: the 1024-instance MPC sweep sharded by instance (fixed total work)
+        try:
+            from lpopc_amd.dist import shard_instances
+            _, cnt = shard_instances(1024, rank, world)
+            c5 = device_workload(ctx, args, problems.quadrotor(8, 8), cnt, 4 * cnt, K2, 10, False, 5 + 100000 * rank,
+                                 use_graph=not args.no_graph)
+            # whole-job rate: all ranks' instances over the max-over-ranks time
+            c5["pairs_per_s_whole_job"] = 1024 * 1e3 / c5["ms_per_step"]
+            c5["instances_total"] = 1024
+            if out is not None:
+                out["config5_mpc_sweep_instances_sharded"] = c5
+        except Exception as ex:
+            errors["config5"] = repr(ex)
+        if world > 1:
+            try:
+                hc = host_consumer_section(ctx, args, prob, 1)
+                if out is not None:
+                    out["host_consumer"] = hc
+            except Exception as ex:
+                errors["host_consumer"] = repr(ex)
+
+    if rank == 0:
+        if extras and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, xs_main, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if errors:
+            out["errors"] = errors
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

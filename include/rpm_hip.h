@@ -147,6 +147,12 @@ int rpm_eval_g(rpm_engine* e, int n, const double* x, int new_x, int m, double* 
  * 0-based), else values pass -> GetConsJacbi, LpNLPWrapper.cpp:230 */
 int rpm_eval_jac_g(rpm_engine* e, int n, const double* x, int new_x, int m, int nele_jac, int* iRow,
                    int* jCol, double* values);
+/* Both constraint callbacks in one call (host pointers): what Ipopt's back-to-back eval_g(x, new_x = true) +
+ * eval_jac_g(x, new_x = false) pair (LpopcIpopt.cpp:135-181) asks for, for callers that can take both results at once
+ * (an SQP / own interior-point loop, the MPC sweep's host driver): one launch writes g straight into the caller's
+ * page-locked array and the Jacobian values into HBM, a second queue operation delivers `values`, ONE synchronisation.
+ * Same results as the two calls, same options ("pin_host", "zero_copy", "const_once", "delta_values"). */
+int rpm_eval_pair(rpm_engine* e, int n, const double* x, int m, double* g, int nele_jac, double* values);
 /* LpopcIpopt::eval_h, LpopcIpopt.cpp:183-218 -> LpHessianCalculator::GetHessian, LpHessian.cpp:878 */
 int rpm_eval_h(rpm_engine* e, int n, const double* x, int new_x, double obj_factor, int m,
                const double* lambda, int new_lambda, int nele_hess, int* iRow, int* jCol,
@@ -304,11 +310,27 @@ int rpm_synchronize(rpm_engine* e);
  *                    (they never change, LpNLPWrapper.cpp:242, :715-718) only into a buffer it did not fill on the
  *                    previous call, afterwards just the NL prefix — for callers that hand the same array every
  *                    iteration and leave it alone in between (Ipopt's TNLPAdapter does); one instance per engine
+ * "delta_values"     0 (default) | 1: host-pointer rpm_eval_jac_g / rpm_eval_pair deliver `values` by difference: a kernel
+ *                    compares the fresh values with a device-side mirror of what this engine last stored into the SAME
+ *                    host array and stores only the 512-double runs in which a bit changed — the constant Doffdiag block, the
+ *                    linear entries and every finite-difference block that does not depend on x (LpNLPWrapper.cpp:722-728 stores
+ *                    them although `dependencies` is all ones, :291) cross PCIe once.  Contract as for "const_once": the caller
+ *                    hands the same array and leaves it alone between calls (Ipopt's TNLPAdapter does); the engine checks 64
+ *                    sampled entries of the array before every delivery and falls back to a full delivery when one differs or
+ *                    the array is a different one.  Needs "pin_host" (the array is page-locked and mapped).  Results are
+ *                    bit-identical to a full delivery.  get-only "delta_total_runs": runs this engine owns; "delta_sent_runs": runs
+ *                    stored since the previous query of this option (blocking; for tests and reports).
+ *                    Interval-sharded engines deliver only the runs they own (host-consumer multi-GPU mode).
+ * "zero_copy"        1 (default): with page-locked caller arrays the tile kernel reads x straight from the caller's array and
+ *                    stores g straight into it (no copy operations: one launch + one synchronisation per rpm_eval_g);
+ *                    0: staged through the engine's HBM buffers with copy-engine transfers
  * "check_finite"     1 (default): NaN/Inf in a result -> RPM_E_NONFINITE (checked on the device); 0: lpopc's behaviour
  * "pin_host"         1 (default): the host-pointer entry points page-lock (hipHostRegister) the caller's x / g /
  *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —
- *                    so copies run at PCIe rate; the registrations are released by rpm_destroy.  Set 0 if the
- *                    caller frees and re-allocates these buffers between calls.
+ *                    so copies run at PCIe rate and the kernels can address them.  At most 8 registrations are kept
+ *                    (least recently used is released first; a new range that overlaps an old one replaces it); all are
+ *                    released by rpm_destroy.  LIFETIME: a registered array must stay mapped until rpm_destroy or until it
+ *                    has been evicted; set 0 if the caller frees and re-allocates these buffers between calls.
  */
 /* Parameter sweeps (n_instances > 1): by default every instance shares the problem functor's constants
  * (rpm_problem_desc.consts — the reference keeps them in file-scope globals, example/launch/Launch.cpp:47-74).  This
@@ -340,6 +362,17 @@ int rpm_shard_segments(rpm_engine* e, int which, int rank, rpm_segment* seg, int
 int rpm_shard_pack_dev(rpm_engine* e, int which, const double* d_full, double* d_packed, void* stream);
 int rpm_shard_unpack_dev(rpm_engine* e, int which, const double* d_gathered, int stride,
                          double* d_full, void* stream);
+
+/* ONE collective per step: the runs of g AND of the Jacobian values of ALL the engine's instances that this rank owns go
+ * into one slot of rpm_shard_slot_len doubles (the same for every rank, whole 128-byte lines); the caller all-gathers the
+ * [world][slot] buffer in place (RCCL; bench.py captures pack, all-gather and unpack in the step's hipGraph) and
+ * rpm_shard_unpack_all_dev scatters it into TNLP order (skip_own = 1: this rank's own runs are in place already).  Instance
+ * b's share of rank r's slot is [g runs | values runs] at offset b * (packed_len_g(r) + packed_len_values(r)); d_g / d_values
+ * use the engine's instance strides ("instance_align").  Bit-identical to the single-GPU vectors (no reductions). */
+int rpm_shard_slot_len(rpm_engine* e, long long* slot_doubles);
+int rpm_shard_pack_all_dev(rpm_engine* e, const double* d_g, const double* d_values, double* d_slot, void* stream);
+int rpm_shard_unpack_all_dev(rpm_engine* e, const double* d_gathered, double* d_g, double* d_values, int skip_own,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,12 +35,6 @@ static int fail(Engine& e, int code, const char* msg) {
   return code;
 }
 
-static bool all_finite(const double* v, size_t n) {
-  for (size_t i = 0; i < n; ++i)
-    if (!std::isfinite(v[i])) return false;
-  return true;
-}
-
 extern "C" {
 
 int rpm_create(const rpm_problem_desc* desc, rpm_engine** out) {
@@ -127,20 +121,15 @@ int rpm_get_starting_point(rpm_engine* h, int n, int init_x, double* x, int init
   return RPM_OK;
 }
 
-// ---- host-pointer evaluations (Ipopt owns every buffer; x/g/values cross PCIe each call) --------
-static int stage_x(Engine& e, int n, const double* x, int new_x) {
+// ---- host-pointer evaluations (Ipopt owns every buffer; x/g/values cross PCIe each call): rpm_host_path.hip ----
+static int stage_x(Engine& e, int n, const double* x) {   // x into the engine's HBM copy (eval_h)
   if (n != e.n || !x) return fail(e, RPM_E_INVALID, "x size mismatch");
   if (!e.dev) {
     int rc = rpm::device_init(e, 0);
     if (rc) return rc;
-    new_x = 1;
   }
-  if (new_x) {
-    rpm::dev_cache_valid(e) = false;
-    rpm::dev_pin_host(e, x, size_t(e.n_instances) * e.n * sizeof(double));
-    return rpm::dev_upload_x(e, x);
-  }
-  return RPM_OK;
+  (void)rpm::dev_pin_host(e, x, size_t(e.n_instances) * e.n * sizeof(double));
+  return rpm::dev_upload_x(e, x);
 }
 
 int rpm_eval_f(rpm_engine* h, int n, const double* x, int new_x, double* obj_value) {
@@ -148,15 +137,8 @@ int rpm_eval_f(rpm_engine* h, int n, const double* x, int new_x, double* obj_val
   Engine& e = h->e;
   RPM_GUARD_BEGIN
   if (!obj_value) return fail(e, RPM_E_INVALID, "eval_f: obj_value is NULL");
-  int rc = stage_x(e, n, x, 1);
-  (void)new_x;
-  if (rc) return rc;
-  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), nullptr, rpm::dev_stream(e));
-  if (rc) return rc;
-  rc = rpm::dev_download(e, obj_value, rpm::dev_buf(e, 4), size_t(e.n_instances));
-  if (rc) return rc;
-  if (e.opt_check_finite && !all_finite(obj_value, size_t(e.n_instances))) return fail(e, RPM_E_NONFINITE, "eval_f: non-finite objective");
-  return RPM_OK;
+  if (n != e.n || !x) return fail(e, RPM_E_INVALID, "x size mismatch");
+  return rpm::host_eval_f(e, x, new_x, obj_value);
   RPM_GUARD_END(e)
 }
 
@@ -165,16 +147,8 @@ int rpm_eval_grad_f(rpm_engine* h, int n, const double* x, int new_x, double* gr
   Engine& e = h->e;
   RPM_GUARD_BEGIN
   if (!grad_f) return fail(e, RPM_E_INVALID, "eval_grad_f: grad_f is NULL");
-  int rc = stage_x(e, n, x, 1);
-  (void)new_x;
-  if (rc) return rc;
-  rc = rpm::dev_eval_obj(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 4), rpm::dev_buf(e, 3), rpm::dev_stream(e));
-  if (rc) return rc;
-  rpm::dev_pin_host(e, grad_f, size_t(e.n_instances) * e.n * sizeof(double));
-  rc = rpm::dev_download(e, grad_f, rpm::dev_buf(e, 3), size_t(e.n_instances) * e.n);
-  if (rc) return rc;
-  if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 3), size_t(e.n_instances) * e.n) != 0) return fail(e, RPM_E_NONFINITE, "eval_grad_f: non-finite gradient");
-  return RPM_OK;
+  if (n != e.n || !x) return fail(e, RPM_E_INVALID, "x size mismatch");
+  return rpm::host_eval_grad_f(e, x, new_x, grad_f);
   RPM_GUARD_END(e)
 }
 
@@ -182,35 +156,12 @@ int rpm_eval_g(rpm_engine* h, int n, const double* x, int new_x, int m, double* 
   if (!h) return RPM_E_INVALID;
   Engine& e = h->e;
   RPM_GUARD_BEGIN
+  if (n != e.n || !x) return fail(e, RPM_E_INVALID, "x size mismatch");
   if (m != e.m || !g) return fail(e, RPM_E_INVALID, "eval_g: size mismatch");
-  // x is re-uploaded on every eval_g: Ipopt may call eval_g(new_x=false) after eval_f(new_x=true) on the
-  // same x, but the upload is cheap next to the D2H of the results and keeps the cache logic simple.
-  int rc = stage_x(e, n, x, 1);
-  (void)new_x;
-  if (rc) return rc;
-  const int flags = e.opt_fuse_pair ? 3 : 1;  // fused: the Jacobian of the same x is produced by the same launch
-  rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), flags, rpm::dev_stream(e));
-  if (rc) return rc;
-  rpm::dev_pin_host(e, g, size_t(e.n_instances) * e.m * sizeof(double));
-  // one round trip for the call: the download of g, the NaN/Inf scan of g and — when the launch was the fused pair —
-  // of the Jacobian that the following eval_jac_g(new_x = false) will only have to copy
-  rc = rpm::dev_download_enqueue(e, g, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m);
-  if (rc) return rc;
-  e.jac_nonfinite = -1;
-  if (e.opt_check_finite) {
-    rc = rpm::dev_nonfinite_enqueue(e, rpm::dev_buf(e, 1), size_t(e.n_instances) * e.m, rpm::dev_buf(e, 2),
-                                    flags == 3 ? size_t(e.n_instances) * e.nnz_jac : 0);
-    if (rc == RPM_OK) rc = rpm::dev_flags_fetch(e);
-    if (rc) return rc;
-  }
-  rc = rpm::dev_sync(e);
-  if (rc) return rc;
-  rpm::dev_cache_valid(e) = (flags == 3);
-  if (e.opt_check_finite) {
-    if (flags == 3) e.jac_nonfinite = rpm::dev_flag_value(e, 1);
-    if (rpm::dev_flag_value(e, 0) != 0) return fail(e, RPM_E_NONFINITE, "eval_g: non-finite constraint value");
-  }
-  return RPM_OK;
+  // x is re-read on every eval_g: Ipopt may call eval_g(new_x=false) after eval_f(new_x=true) on the same x, but
+  // the read is cheap next to the results' trip back and keeps the cache logic simple.
+  // (new_x only tells the objective's cache whether it is still valid)
+  return rpm::host_eval_g(e, x, new_x, g);
   RPM_GUARD_END(e)
 }
 
@@ -227,34 +178,22 @@ int rpm_eval_jac_g(rpm_engine* h, int n, const double* x, int new_x, int m, int 
     return RPM_OK;
   }
   if (!x) return fail(e, RPM_E_INVALID, "eval_jac_g: x is NULL");
-  int rc = RPM_OK;
-  const bool cached = e.dev && !new_x && rpm::dev_cache_valid(e);
-  if (!cached) {
-    rc = stage_x(e, n, x, 1);
-    if (rc) return rc;
-    rc = rpm::dev_eval_cons(e, rpm::dev_buf(e, 0), rpm::dev_buf(e, 1), rpm::dev_buf(e, 2), 2, rpm::dev_stream(e));
-    if (rc) return rc;
-  }
-  rpm::dev_pin_host(e, values, size_t(e.n_instances) * e.nnz_jac * sizeof(double));
-  // values = [NL | LIN | CONST]: with "const_once" the constant tail (54 % of the entries at the metric problem) crosses
-  // PCIe only when the caller hands a buffer this engine did not fill last time
-  size_t count = size_t(e.n_instances) * e.nnz_jac;
-  if (e.opt_const_once && e.n_instances == 1 && values == e.const_filled) count = size_t(e.nnz_nl);
-  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 2), count);
-  if (rc) return rc;
-  e.const_filled = values;
-  if (e.opt_check_finite) {
-    const int bad = (cached && e.jac_nonfinite >= 0) ? e.jac_nonfinite   // scanned with the pair launch already
-                                                      : rpm::dev_nonfinite(e, rpm::dev_buf(e, 2), size_t(e.n_instances) * e.nnz_jac);
-    if (bad != 0) return fail(e, RPM_E_NONFINITE, "eval_jac_g: non-finite Jacobian value");
-  }
-  return RPM_OK;
+  return rpm::host_eval_jac_values(e, x, new_x, values);
+  RPM_GUARD_END(e)
+}
+
+int rpm_eval_pair(rpm_engine* h, int n, const double* x, int m, double* g, int nele_jac, double* values) {
+  if (!h) return RPM_E_INVALID;
+  Engine& e = h->e;
+  RPM_GUARD_BEGIN
+  if (n != e.n || m != e.m || nele_jac != e.nnz_jac || !x || !g || !values) return fail(e, RPM_E_INVALID, "eval_pair: size mismatch or NULL pointer");
+  return rpm::host_eval_pair(e, x, g, values);
   RPM_GUARD_END(e)
 }
 
 int rpm_eval_h(rpm_engine* h, int n, const double* x, int new_x, double obj_factor, int m, const double* lambda,
                int new_lambda, int nele_hess, int* iRow, int* jCol, double* values) {
-  (void)new_x; (void)new_lambda;
+  (void)new_lambda;
   if (!h) return RPM_E_INVALID;
   Engine& e = h->e;
   RPM_GUARD_BEGIN
@@ -270,7 +209,8 @@ int rpm_eval_h(rpm_engine* h, int n, const double* x, int new_x, double obj_fact
     return RPM_OK;
   }
   if (!x || !lambda) return fail(e, RPM_E_INVALID, "eval_h: x or lambda is NULL");
-  rc = stage_x(e, n, x, 1);
+  if (new_x) rpm::host_new_x(e);
+  rc = stage_x(e, n, x);
   if (rc) return rc;
   // the reference copies only m-1 multipliers (LpopcIpopt.cpp:205-208); the last one belongs to a linear row and
   // never enters the Hessian, so all m are uploaded here
@@ -600,6 +540,12 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "const_once must be 0 or 1");
     e.opt_const_once = value;
     e.const_filled = nullptr;
+  } else if (k == "delta_values") {
+    if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "delta_values must be 0 or 1");
+    e.opt_delta_values = value;
+  } else if (k == "zero_copy") {
+    if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "zero_copy must be 0 or 1");
+    e.opt_zero_copy = value;
   } else if (k == "pipeline") {
     if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "pipeline must be -1 (auto), 0 or 1");
     e.opt_pipeline = value;
@@ -631,6 +577,11 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "pipeline") *value = e.opt_pipeline;
   else if (k == "const_once") *value = e.opt_const_once;
   else if (k == "instance_align") *value = e.opt_instance_align;
+  else if (k == "delta_values") *value = e.opt_delta_values;
+  else if (k == "zero_copy") *value = e.opt_zero_copy;
+  else if (k == "pin_host") *value = e.opt_pin_host;
+  else if (k == "delta_sent_runs") return rpm::host_delta_sent_runs(e, value);
+  else if (k == "delta_total_runs") *value = e.last_delta_total;
   else if (k == "stride_g") *value = int(e.stride_g());
   else if (k == "stride_values") *value = int(e.stride_values());
   else if (k == "pipeline_active") *value = rpm::dev_pipeline_active(e);
@@ -698,6 +649,27 @@ int rpm_shard_unpack_dev(rpm_engine* h, int which, const double* d_gathered, int
   RPM_GUARD_BEGIN
   if (!d_gathered || !d_full || which < 0 || which > 1) return fail(h->e, RPM_E_INVALID, "shard_unpack_dev: bad argument");
   return rpm::dev_shard_copy(h->e, which, false, d_gathered, stride, d_full, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_shard_slot_len(rpm_engine* h, long long* slot_doubles) {
+  if (!h || !slot_doubles) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  *slot_doubles = rpm::shard_slot_len(h->e);
+  return RPM_OK;
+  RPM_GUARD_END(h->e)
+}
+int rpm_shard_pack_all_dev(rpm_engine* h, const double* d_g, const double* d_values, double* d_slot, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_g || !d_values || !d_slot) return fail(h->e, RPM_E_INVALID, "shard_pack_all_dev: NULL pointer");
+  return rpm::dev_shard_pack_all(h->e, d_g, d_values, d_slot, stream);
+  RPM_GUARD_END(h->e)
+}
+int rpm_shard_unpack_all_dev(rpm_engine* h, const double* d_gathered, double* d_g, double* d_values, int skip_own, void* stream) {
+  if (!h) return RPM_E_INVALID;
+  RPM_GUARD_BEGIN
+  if (!d_g || !d_values || !d_gathered) return fail(h->e, RPM_E_INVALID, "shard_unpack_all_dev: NULL pointer");
+  return rpm::dev_shard_unpack_all(h->e, d_gathered, d_g, d_values, skip_own, stream);
   RPM_GUARD_END(h->e)
 }
 }  // extern "C"

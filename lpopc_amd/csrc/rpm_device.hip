@@ -24,6 +24,7 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
   const PhaseDev ph = K.phases[p];
   const double* c = K.consts + size_t(inst) * K.consts_stride;
   const int N = ph.N;
+  bool bad = false;   // NaN/Inf among the gradient entries this thread stores (host-pointer path, K.chk)
   const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
   const double tspan = tf - t0;
   double s_wl = 0.0, s_t0 = 0.0;   // sum w_k L_k ; sum (w_k dt/2 dL/dt)_k (1-tau_k)/2
@@ -43,10 +44,10 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
       if constexpr (AN) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
-          grad[ph.x_state0 + i * (N + 1) + k] = wk * Prob::lagrange_grad_col(ph.phase_num, i, tk, xs, us, c);
+          { const double gv_ = wk * Prob::lagrange_grad_col(ph.phase_num, i, tk, xs, us, c); grad[ph.x_state0 + i * (N + 1) + k] = gv_; chk_note(bad, gv_); }
 #pragma unroll
         for (int j = 0; j < NU; ++j)
-          grad[ph.x_control0 + j * N + k] = wk * Prob::lagrange_grad_col(ph.phase_num, NX + j, tk, xs, us, c);
+          { const double gv_ = wk * Prob::lagrange_grad_col(ph.phase_num, NX + j, tk, xs, us, c); grad[ph.x_control0 + j * N + k] = gv_; chk_note(bad, gv_); }
         dLt = Prob::lagrange_grad_col(ph.phase_num, NX + NU, tk, xs, us, c);
       } else {
         // LpFDderive::DerivLagrange, LpFiniteDifferenceDerive.cpp:100-192
@@ -56,7 +57,7 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
           xs[i] = b + hh;
           const double Lp = Prob::lagrange(ph.phase_num, tk, xs, us, c);
           xs[i] = b;
-          grad[ph.x_state0 + i * (N + 1) + k] = wk * ((Lp - L0) / hh);
+          { const double gv_ = wk * ((Lp - L0) / hh); grad[ph.x_state0 + i * (N + 1) + k] = gv_; chk_note(bad, gv_); }
         }
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -64,7 +65,7 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
           us[j] = b + hh;
           const double Lp = Prob::lagrange(ph.phase_num, tk, xs, us, c);
           us[j] = b;
-          grad[ph.x_control0 + j * N + k] = wk * ((Lp - L0) / hh);
+          { const double gv_ = wk * ((Lp - L0) / hh); grad[ph.x_control0 + j * N + k] = gv_; chk_note(bad, gv_); }
         }
         const double ht = K.tol * (1 + fabs(tk));
         dLt = (Prob::lagrange(ph.phase_num, tk + ht, xs, us, c) - L0) / ht;
@@ -116,9 +117,9 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
       }
       // terminal-state entries (:1054).  The initial-state Mayer entry is overwritten by the Lagrange
       // run in the reference (:1050-1053) — kept, it is zero in every supported problem anyway.
-      for (int i = 0; i < NX; ++i) grad[ph.x_state0 + i * (N + 1) + N] = dM[NX + 1 + i];
+      for (int i = 0; i < NX; ++i) { const double gv_ = dM[NX + 1 + i]; grad[ph.x_state0 + i * (N + 1) + N] = gv_; chk_note(bad, gv_); }
       // d/dt0 (:1069-1078) and d/dtf (:1081-1087, which keeps only node 0 of the dL/dt term)
-      grad[ph.x_t0] = (red[1][0] + dM[NX]) + (-0.5) * wl;
+      { const double gv_ = (red[1][0] + dM[NX]) + (-0.5) * wl; grad[ph.x_t0] = gv_; chk_note(bad, gv_); }
       double dLt0;
       {
         double xs[NXs], us[NUs];
@@ -133,11 +134,12 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
           dLt0 = (Prob::lagrange(ph.phase_num, tk + ht, xs, us, c) - Prob::lagrange(ph.phase_num, tk, xs, us, c)) / ht;
         }
         const double r2 = (K.weights[ph.node0] * (tspan / 2.0)) * dLt0;
-        grad[ph.x_t0 + 1] = (dM[2 * NX + 1] + 0.5 * wl) + (tau * 0.5 + 0.5) * r2;
+        { const double gv_ = (dM[2 * NX + 1] + 0.5 * wl) + (tau * 0.5 + 0.5) * r2; grad[ph.x_t0 + 1] = gv_; chk_note(bad, gv_); }
       }
     }
   }
   (void)objall;
+  if (GRAD && K.chk != nullptr && bad) atomicOr_system(K.chk + 3, 1);
 }
 
 // sum the per-phase costs in phase order (GetObjFun's `cost +=` loop, :872-937)
@@ -181,6 +183,8 @@ void device_destroy(Engine& e) {
     if (p) (void)hipFree(p);
   if (d->d_flag) (void)hipFree(d->d_flag);
   if (d->h_flags2) (void)hipHostFree(d->h_flags2);   // d_flags2 is its device alias
+  host_path_destroy(d);
+  exchange_destroy(d);
   for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.ptr));
   (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
   for (auto& row : d->segtab)
@@ -278,6 +282,7 @@ int device_init(Engine& e, int device_id) {
   k.n_tasks = (!sharded || e.shard_rank == 0) ? int(e.tasks.size()) : 0;  // rank 0 owns the endpoint rows
   k.diag_mask = 0;
   k.trace = nullptr;
+  k.chk = nullptr;
 #ifdef RPM_DIAG
   if (getenv("RPM_DIAG_TRACE")) {
     size_t words = size_t(e.tiles.size() * 2 + e.tasks.size() + 64) * size_t(e.n_instances) * 8;
@@ -298,12 +303,14 @@ int device_init(Engine& e, int device_id) {
   return dev_update_instance_constants(e);
 }
 
-int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream) {
+int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream, bool host_chk) {
   if (!e.dev) {
     int rc = device_init(e, 0);
     if (rc) return rc;
   }
-  Device& d = *e.dev;
+  Device& dd = *e.dev;
+  struct { KParams kp; double* d_partial; } d{dd.kp, dd.d_partial};
+  d.kp.chk = host_chk ? dd.d_flags2 : nullptr;   // host-pointer path: word 3 receives "a gradient entry is NaN/Inf"
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool an = e.first_derive == RPM_DERIVE_ANALYTIC;
   hipError_t s = hipSuccess;
@@ -381,7 +388,8 @@ __global__ void rpm_finite2_kernel(const double* __restrict__ a, size_t na, cons
 int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b, size_t nb) {
   Device& d = *e.dev;
   if (!d.h_flags2) {   // the two words live in page-locked host memory the device can write: no memset, no copy back
-    if (hipHostMalloc(reinterpret_cast<void**>(&d.h_flags2), 2 * sizeof(int), hipHostMallocMapped) != hipSuccess) return RPM_E_DEVICE;
+    if (hipHostMalloc(reinterpret_cast<void**>(&d.h_flags2), 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) return RPM_E_DEVICE;
+    d.h_flags2[2] = d.h_flags2[3] = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_flags2), d.h_flags2, 0) != hipSuccess) return RPM_E_DEVICE;
   }
   d.h_flags2[0] = d.h_flags2[1] = 0;   // the previous scan was synchronised before its words were read
@@ -410,7 +418,7 @@ int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t coun
 // evicted (rpm_hip.h, option "pin_host").  Returns the device-visible alias of `ptr`, or nullptr when it is not pinned.
 void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
   constexpr size_t PIN_MAX = 8;
-  if (!e.opt_pin_host || !ptr || bytes < (64u << 10)) return nullptr;
+  if (!e.opt_pin_host || !ptr || bytes == 0) return nullptr;   // small arrays too: a pageable copy costs ~20 us each way
   Device& d = *e.dev;
   const char* lo = static_cast<const char*>(ptr);
   for (size_t i = 0; i < d.pinned.size(); ++i)

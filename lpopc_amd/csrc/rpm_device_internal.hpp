@@ -40,6 +40,7 @@ struct KParams {
   int max_cshare;                       // largest constant-block share of a tile (c_cnt)
   int diag_mask;                        // ablation mask, only honoured by the -DRPM_DIAG diagnostic build
   unsigned long long* trace;            // per-workgroup timestamps (diagnostic build with RPM_DIAG_TRACE set), else NULL
+  int* chk;                             // host-pointer path: two host-visible words ORed with "a stored g / Jacobian value is NaN/Inf"; else NULL
 };
 
 struct HParams {
@@ -90,6 +91,8 @@ struct Device {
   HParams hp{};
   size_t hess_lds = 0;
   int hess_threads = 0;
+  void* host_path = nullptr;    // state of the host-pointer delivery (rpm_host_path.hip)
+  void* exchange = nullptr;     // pack / unpack tables of the interval-sharded exchange (rpm_peer.hip)
   struct SegTable { void* ptr = nullptr; int count = 0; int stride = -1; };
   SegTable segtab[2][2];        // [g|values][pack|unpack] run tables of the interval sharding
 };
@@ -102,6 +105,16 @@ struct Device {
       return RPM_E_DEVICE;                                                                 \
     }                                                                                      \
   } while (0)
+
+// Host-pointer path (K.chk != nullptr): every thread remembers whether a value it stored was NaN/Inf; the verdicts are
+// ORed into host-visible words (word 0: g, word 1: Jacobian values, word 3: objective gradient) — no separate scan
+// kernel, no extra launch.  An atomic is issued only when something is wrong.
+__device__ __forceinline__ void chk_note(bool& bad, double v) { bad |= !(fabs(v) <= 1.7976931348623157e308); }
+__device__ __forceinline__ void chk_report(int* chk, bool bad_g, bool bad_j) {
+  if (chk == nullptr) return;
+  if (bad_g) atomicOr_system(chk, 1);
+  if (bad_j) atomicOr_system(chk + 1, 1);
+}
 
 // ------------------------------------------------------------------------------------------
 // problem registry: calls fn with a value of the functor type registered under `id`
@@ -128,6 +141,9 @@ inline hipError_t upload(T** dst, const std::vector<T>& src) {
   return s;
 }
 
+
+void host_path_destroy(Device* d);   // rpm_host_path.hip
+void exchange_destroy(Device* d);    // rpm_peer.hip
 
 // rpm_tile_kernels.hip: occupancy, LDS size and eligibility of the pipelined kernel for this engine (device_init)
 void tile_pipeline_setup(Engine& e, Device* d, const ProblemDims& pd, int device_id);

@@ -166,6 +166,9 @@ struct Engine {
   int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
   const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)
   int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
+  int opt_zero_copy = 1;         // host-pointer path: the kernel reads x from / stores g into the caller's page-locked arrays
+  int opt_delta_values = 0;      // host-pointer path: deliver only the runs of `values` that changed since the last delivery into the same array
+  int last_delta_total = 0;      // runs of `values` this engine owns (rpm_get_option "delta_total_runs")
   int ipm_attached = 0;          // rpm_ipm solvers built on this engine: they size their buffers from stride_g/values
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)
   std::vector<double> sol_x, sol_lambda;
@@ -218,6 +221,10 @@ int dev_solution_error(Engine& e, int phase, const double* x, double* rel_err);
 // rpm_shard.cpp: rank's contiguous runs of g (which=0) or of the Jacobian values (which=1)
 std::vector<rpm_segment> shard_segments(const Engine& e, int which, int rank, int* packed_len);
 int dev_shard_copy(Engine& e, int which, bool pack, const double* src, int stride, double* dst, void* stream);
+// rpm_peer.hip: ONE packed slot per rank for g + values of all instances (one collective per step)
+long long shard_slot_len(const Engine& e);
+int dev_shard_pack_all(Engine& e, const double* d_g, const double* d_values, double* d_slot, void* stream);
+int dev_shard_unpack_all(Engine& e, const double* d_gathered, double* d_g, double* d_values, int skip_own, void* stream);
 
 // problem registry (rpm_device.hip): static dimensions of a functor, for validation on the host
 struct ProblemDims { int nx, nu, nc, ne_max, nlink_max, nconst; bool has_analytic; };
@@ -229,7 +236,16 @@ void device_destroy(Engine& e);
 // flags: bit0 = constraint vector g, bit1 = Jacobian values.  Pointers are device pointers.
 int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, int flags, void* stream);
 // objective (d_obj, one per instance) and, when d_grad != nullptr, its gradient
-int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream);
+int dev_eval_obj(Engine& e, const double* d_x, double* d_obj, double* d_grad, void* stream, bool host_chk = false);
+bool dev_cons_is_one_role(const Engine& e);  // the next constraint launch is rpm_tile_kernel (carries the fused NaN/Inf check)
+// rpm_host_path.hip: the host-pointer TNLP path (x, g, values are the caller's arrays)
+int host_eval_f(Engine& e, const double* x, int new_x, double* obj);
+int host_eval_grad_f(Engine& e, const double* x, int new_x, double* grad);
+int host_eval_g(Engine& e, const double* x, int new_x, double* g);
+void host_new_x(Engine& e);   // a callback received new_x = true: drop what the other callbacks cached
+int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values);
+int host_eval_pair(Engine& e, const double* x, double* g, double* values);
+int host_delta_sent_runs(Engine& e, int* sent);   // runs delivered since the previous query
 int dev_pipeline_active(const Engine& e);   // 1 when the next constraint launch uses rpm_tile_pl_kernel
 int dev_upload_x(Engine& e, const double* x);
 int dev_upload(Engine& e, double* dev, const double* host, size_t count);

@@ -1,0 +1,384 @@
+// rpm_host_path.hip — the host-pointer (Ipopt-facing) evaluation path behind rpm_eval_g / rpm_eval_jac_g / rpm_eval_pair:
+// what LpopcIpopt::eval_g and eval_jac_g (Core/LpopcIpopt.cpp:135-181) do with their `new double[n]` copy, the
+// NLPWrapper call and the element-wise copy-out, done here with as few PCIe round trips and queue operations as the
+// TNLP protocol allows.  Measured floors on this box (tools/ubench/pcie_paths.hip, profiles/r02_pcie_paths.jsonl):
+// one queue operation + hipStreamSynchronize 10.2 us, PCIe 57 GB/s marginal for a copy-engine D2H (47.9 GB/s at the
+// NL prefix's 3.1 MB), 46 GB/s for stores a kernel makes straight into page-locked host memory.
+//
+//   * x is read by the tile kernel straight from the caller's page-locked array, g is stored straight into the
+//     caller's page-locked array (no copy operations, ONE launch + ONE synchronisation per rpm_eval_g);
+//   * NaN/Inf detection is fused into the kernel that produces the values (K.chk; two host-visible words);
+//   * the Jacobian of the same x is produced by the same launch into HBM (fused pair) and delivered by
+//     rpm_eval_jac_g(new_x = 0) either by one copy-engine transfer (default; option "const_once": NL prefix only) or,
+//     with option "delta_values", by a kernel that stores only the 4-KB runs whose bits differ from what this engine
+//     last delivered into the same array (the constant Doffdiag block, the linear entries and every block of the
+//     finite-difference Jacobian that does not depend on x never cross PCIe again);
+//   * rpm_eval_pair is both callbacks in one call: one launch for g + Jacobian, one delivery kernel, one
+//     synchronisation.
+// There is no CPU arithmetic here and no fallback: without a device every entry point fails with RPM_E_DEVICE.
+#include "rpm_device_internal.hpp"
+
+namespace rpm {
+
+void host_new_x(Engine& e);
+
+// ------------------------------------------------------------------------------------------------------------------
+// Delivery of `values` by difference.  runs[r] = {off, len} (doubles, len <= DELTA_RUN) tile the part of the flat
+// values array this engine owns.  One workgroup per run: compare the fresh values with the mirror of what the host
+// array holds; if any bit differs (or `force`), store the run into the host array and refresh the mirror.
+constexpr int DELTA_RUN = 512;
+struct RunDev { long long off; int len, pad; };
+
+__global__ __launch_bounds__(256) void rpm_delta_copy_kernel(const RunDev* __restrict__ runs, const double* __restrict__ fresh,
+                                                             unsigned long long* __restrict__ mirror,
+                                                             double* __restrict__ host, int force,
+                                                             unsigned* __restrict__ sent_runs) {
+  const RunDev r = runs[blockIdx.x];
+  const int t = threadIdx.x;
+  const unsigned long long* f = reinterpret_cast<const unsigned long long*>(fresh) + r.off;
+  unsigned long long* mi = mirror + r.off;
+  const bool in0 = t < r.len, in1 = t + 256 < r.len;
+  const unsigned long long a0 = in0 ? f[t] : 0ull, a1 = in1 ? f[t + 256] : 0ull;
+  int differ = force;
+  if (!force) {
+    const unsigned long long m0 = in0 ? mi[t] : 0ull, m1 = in1 ? mi[t + 256] : 0ull;
+    differ = (a0 != m0) || (a1 != m1);
+  }
+  if (!__syncthreads_or(differ)) return;
+  unsigned long long* h = reinterpret_cast<unsigned long long*>(host) + r.off;
+  if (in0) { h[t] = a0; mi[t] = a0; }
+  if (in1) { h[t + 256] = a1; mi[t + 256] = a1; }
+  if (sent_runs && t == 0) atomicAdd(sent_runs, 1u);
+}
+
+struct HostPath {
+  // delta delivery
+  RunDev* d_runs = nullptr;
+  int n_runs = 0;
+  unsigned long long* d_mirror = nullptr;
+  const double* delta_host = nullptr;      // host array whose content the mirror describes
+  std::vector<long long> sample_idx;       // positions (inside the owned ranges) checked before every delta delivery
+  std::vector<unsigned long long> sample_val;
+  unsigned* d_sent = nullptr;              // statistics: runs stored so far (device counter, read on request only)
+  unsigned sent_read = 0;                  // its value at the last query
+  long long owned = 0;                     // doubles this engine owns in `values`
+  // objective: the value(s) land in page-locked host memory straight from the summing kernel
+  double* h_obj = nullptr;
+  double* d_obj_alias = nullptr;
+  bool obj_valid = false;                  // h_obj and the engine's gradient buffer hold f and grad f of the current x
+};
+
+static HostPath& host_path(Engine& e) {
+  Device& d = *e.dev;
+  if (!d.host_path) d.host_path = new HostPath();
+  return *static_cast<HostPath*>(d.host_path);
+}
+void host_path_destroy(Device* d) {
+  if (!d->host_path) return;
+  HostPath* h = static_cast<HostPath*>(d->host_path);
+  if (h->d_runs) (void)hipFree(h->d_runs);
+  if (h->d_mirror) (void)hipFree(h->d_mirror);
+  if (h->d_sent) (void)hipFree(h->d_sent);
+  if (h->h_obj) (void)hipHostFree(h->h_obj);
+  delete h;
+  d->host_path = nullptr;
+}
+
+static int ensure_flags(Engine& e) {
+  Device& d = *e.dev;
+  if (!d.h_flags2) {   // two words in page-locked host memory the device can write: no memset, no copy back
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&d.h_flags2), 4 * sizeof(int), hipHostMallocMapped));
+    HIP_TRY(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_flags2), d.h_flags2, 0));
+    d.h_flags2[0] = d.h_flags2[1] = d.h_flags2[2] = d.h_flags2[3] = 0;   // words: g, Jacobian, (unused), objective gradient
+  }
+  return RPM_OK;
+}
+
+static int delta_setup(Engine& e) {
+  HostPath& h = host_path(e);
+  if (h.d_runs) return RPM_OK;
+  const long long nnz = e.nnz_jac, B = e.n_instances;
+  std::vector<std::pair<long long, long long>> ranges;   // owned ranges of one instance
+  if (e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1) {
+    for (const rpm_segment& s : shard_segments(e, 1, e.shard_rank, nullptr)) ranges.emplace_back(s.off, s.len);
+  } else {
+    ranges.emplace_back(0, nnz);
+  }
+  std::vector<RunDev> runs;
+  h.owned = 0;
+  for (long long b = 0; b < B; ++b)
+    for (auto& rg : ranges)
+      for (long long o = 0; o < rg.second; o += DELTA_RUN) {
+        const int len = int(std::min<long long>(DELTA_RUN, rg.second - o));
+        runs.push_back(RunDev{b * nnz + rg.first + o, len, 0});
+        h.owned += len;
+      }
+  h.n_runs = int(runs.size());
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&h.d_runs), (runs.size() ? runs.size() : 1) * sizeof(RunDev)));
+  if (!runs.empty()) HIP_TRY(e, hipMemcpy(h.d_runs, runs.data(), runs.size() * sizeof(RunDev), hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&h.d_mirror), size_t(B) * nnz * sizeof(double)));
+  // the counter lives in HBM: an atomic per stored run into HOST memory is a PCIe round trip each (337 of them made a
+  // delivery take 340 us instead of 40)
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&h.d_sent), sizeof(unsigned)));
+  HIP_TRY(e, hipMemset(h.d_sent, 0, sizeof(unsigned)));
+  // 64 sample positions spread over the owned runs (first and last element included)
+  const int NS = 64;
+  h.sample_idx.clear();
+  if (!runs.empty())
+    for (int k = 0; k < NS; ++k) {
+      const RunDev& r = runs[size_t((long long)k * (runs.size() - 1) / (NS - 1))];
+      h.sample_idx.push_back(r.off + ((k & 1) ? r.len - 1 : 0));
+    }
+  h.sample_val.assign(h.sample_idx.size(), 0ull);
+  return RPM_OK;
+}
+
+// deliver the Jacobian values in the engine's staging buffer into the caller's array `values` (host pointer), `va` its
+// device alias.  Queues one kernel on the engine's stream; the caller synchronises and then calls delta_commit.
+static int delta_enqueue(Engine& e, const double* values, double* va) {
+  int rc = delta_setup(e);
+  if (rc) return rc;
+  HostPath& h = host_path(e);
+  Device& d = *e.dev;
+  int force = 1;
+  if (h.delta_host == values) {   // same array as last time: has the caller left it alone?
+    force = 0;
+    const unsigned long long* hv = reinterpret_cast<const unsigned long long*>(values);
+    for (size_t k = 0; k < h.sample_idx.size(); ++k)
+      if (hv[h.sample_idx[k]] != h.sample_val[k]) { force = 1; break; }
+  }
+  h.delta_host = nullptr;   // not trusted again until this delivery has completed (delta_commit)
+  if (h.n_runs)
+    hipLaunchKernelGGL(rpm_delta_copy_kernel, dim3(unsigned(h.n_runs)), dim3(256), 0, d.stream, h.d_runs, d.d_values, h.d_mirror, va,
+                       force, h.d_sent);
+  HIP_TRY(e, hipGetLastError());
+  return RPM_OK;
+}
+static void delta_commit(Engine& e, const double* values) {
+  HostPath& h = host_path(e);
+  const unsigned long long* hv = reinterpret_cast<const unsigned long long*>(values);
+  for (size_t k = 0; k < h.sample_idx.size(); ++k) h.sample_val[k] = hv[h.sample_idx[k]];
+  h.delta_host = values;
+  e.last_delta_total = h.n_runs;
+}
+// runs stored since the previous query (rpm_get_option "delta_sent_runs"); blocking, for tests and reports only
+int host_delta_sent_runs(Engine& e, int* sent) {
+  *sent = 0;
+  if (!e.dev || !e.dev->host_path) return RPM_OK;
+  HostPath& h = host_path(e);
+  if (!h.d_sent) return RPM_OK;
+  unsigned now = 0;
+  HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+  HIP_TRY(e, hipMemcpy(&now, h.d_sent, sizeof(unsigned), hipMemcpyDeviceToHost));
+  *sent = int(now - h.sent_read);
+  h.sent_read = now;
+  return RPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One launch for the constraint side of an iterate: x from the caller's array, g into the caller's array, the
+// Jacobian (when `with_jac`) into the staging buffer.  Returns with everything queued; *g_pending tells the caller
+// that g still has to be copied out of the staging buffer (no page-locked alias), *scan tells it that the NaN/Inf
+// verdicts need the separate scan kernel (the launch was not the one-role kernel).
+static int enqueue_cons(Engine& e, const double* x, double* g, bool with_g, bool with_jac) {
+  Device& d = *e.dev;
+  const size_t B = size_t(e.n_instances);
+  HIP_TRY(e, hipSetDevice(d.device_id));
+  const bool zc = e.opt_zero_copy != 0;
+  const double* xa = zc ? static_cast<const double*>(dev_pin_host(e, x, B * e.n * sizeof(double))) : nullptr;
+  if (!xa) {
+    if (!zc) (void)dev_pin_host(e, x, B * e.n * sizeof(double));
+    HIP_TRY(e, hipMemcpyAsync(d.d_x, x, B * e.n * sizeof(double), hipMemcpyHostToDevice, d.stream));
+    xa = d.d_x;
+  }
+  const bool fused_chk = e.opt_check_finite && dev_cons_is_one_role(e);
+  double* ga = nullptr;
+  if (with_g) {
+    void* alias = dev_pin_host(e, g, B * e.m * sizeof(double));
+    if (zc && alias && (fused_chk || !e.opt_check_finite)) ga = static_cast<double*>(alias);
+  }
+  if (e.opt_check_finite) {
+    int rc = ensure_flags(e);
+    if (rc) return rc;
+    d.h_flags2[0] = d.h_flags2[1] = 0;   // the previous verdicts were read after their synchronisation
+  }
+  const int flags = (with_g ? 1 : 0) | (with_jac ? 2 : 0) | (fused_chk ? 8 : 0);
+  int rc = dev_eval_cons(e, xa, ga ? ga : d.d_g, d.d_values, flags, d.stream);
+  if (rc) return rc;
+  if (with_g && !ga) HIP_TRY(e, hipMemcpyAsync(g, d.d_g, B * e.m * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  if (e.opt_check_finite && !fused_chk) {
+    rc = dev_nonfinite_enqueue(e, d.d_g, with_g ? B * e.m : 0, d.d_values, with_jac ? B * size_t(e.nnz_jac) : 0);
+    if (rc) return rc;
+  }
+  return RPM_OK;
+}
+
+static int ensure_device(Engine& e) {
+  if (e.dev) return RPM_OK;
+  return device_init(e, 0);
+}
+
+int host_eval_g(Engine& e, const double* x, int new_x, double* g) {
+  int rc = ensure_device(e);
+  if (rc) return rc;
+  Device& d = *e.dev;
+  if (new_x) host_new_x(e);
+  d.cache_valid = false;
+  const bool pair = e.opt_fuse_pair != 0;   // the Jacobian of the same x comes out of the same launch
+  rc = enqueue_cons(e, x, g, true, pair);
+  if (rc) return rc;
+  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  d.cache_valid = pair;
+  e.jac_nonfinite = -1;
+  if (e.opt_check_finite) {
+    if (pair) e.jac_nonfinite = d.h_flags2[1];
+    if (d.h_flags2[0] != 0) {
+      e.err = "eval_g: non-finite constraint value";
+      return RPM_E_NONFINITE;
+    }
+  }
+  return RPM_OK;
+}
+
+// queue the delivery of the staged Jacobian values into `values`; *delta = the delivery needs delta_commit afterwards
+static int enqueue_values(Engine& e, double* values, bool* delta) {
+  Device& d = *e.dev;
+  const size_t B = size_t(e.n_instances);
+  void* va = dev_pin_host(e, values, B * e.nnz_jac * sizeof(double));
+  *delta = false;
+  if (e.opt_delta_values && va) {
+    *delta = true;
+    return delta_enqueue(e, values, static_cast<double*>(va));
+  }
+  if (e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1) {
+    e.err = "host-pointer Jacobian delivery of an interval-sharded engine needs option delta_values = 1 (each rank stores only its own runs)";
+    return RPM_E_UNSUPPORTED;
+  }
+  // values = [NL | LIN | CONST]: with "const_once" the constant tail (54 % of the entries at the metric problem) crosses
+  // PCIe only when the caller hands a buffer this engine did not fill last time
+  size_t count = B * e.nnz_jac;
+  if (e.opt_const_once && e.n_instances == 1 && values == e.const_filled) count = size_t(e.nnz_nl);
+  HIP_TRY(e, hipMemcpyAsync(values, d.d_values, count * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  return RPM_OK;
+}
+
+int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values) {
+  int rc = ensure_device(e);
+  if (rc) return rc;
+  Device& d = *e.dev;
+  if (new_x) host_new_x(e);
+  const bool cached = !new_x && d.cache_valid;
+  if (!cached) {
+    d.cache_valid = false;
+    rc = enqueue_cons(e, x, nullptr, false, true);
+    if (rc) return rc;
+    e.jac_nonfinite = -1;
+  }
+  bool delta = false;
+  rc = enqueue_values(e, values, &delta);
+  if (rc) return rc;
+  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  if (delta) delta_commit(e, values);
+  e.const_filled = values;
+  if (e.opt_check_finite) {
+    const int bad = cached ? e.jac_nonfinite : d.h_flags2[1];
+    if (bad != 0) {
+      e.err = "eval_jac_g: non-finite Jacobian value";
+      return RPM_E_NONFINITE;
+    }
+  }
+  return RPM_OK;
+}
+
+// ---- objective and gradient (LpopcIpopt::eval_f / eval_grad_f, Core/LpopcIpopt.cpp:106-133).  The first of the two calls
+// at a new x launches ONE objective kernel that produces both (the gradient kernel computes the quadrature anyway); the
+// value comes home through page-locked memory with that launch's synchronisation, the gradient stays in HBM until
+// eval_grad_f asks for it (one copy).  NaN/Inf in the gradient is noted by the kernel that stores it.
+void host_new_x(Engine& e) {   // any callback that receives new_x = true invalidates what the others cached
+  if (!e.dev) return;
+  e.dev->cache_valid = false;
+  if (e.dev->host_path) host_path(e).obj_valid = false;
+}
+
+static int enqueue_obj(Engine& e, const double* x) {
+  Device& d = *e.dev;
+  HostPath& h = host_path(e);
+  const size_t B = size_t(e.n_instances);
+  HIP_TRY(e, hipSetDevice(d.device_id));
+  if (!h.h_obj) {
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&h.h_obj), B * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&h.d_obj_alias), h.h_obj, 0));
+  }
+  const double* xa = e.opt_zero_copy ? static_cast<const double*>(dev_pin_host(e, x, B * e.n * sizeof(double))) : nullptr;
+  if (!xa) {
+    if (!e.opt_zero_copy) (void)dev_pin_host(e, x, B * e.n * sizeof(double));
+    HIP_TRY(e, hipMemcpyAsync(d.d_x, x, B * e.n * sizeof(double), hipMemcpyHostToDevice, d.stream));
+    xa = d.d_x;
+  }
+  int rc = ensure_flags(e);
+  if (rc) return rc;
+  d.h_flags2[3] = 0;
+  return dev_eval_obj(e, xa, h.d_obj_alias, d.d_grad, d.stream, e.opt_check_finite != 0);
+}
+
+int host_eval_f(Engine& e, const double* x, int new_x, double* obj) {
+  int rc = ensure_device(e);
+  if (rc) return rc;
+  if (new_x) host_new_x(e);
+  HostPath& h = host_path(e);
+  if (!h.obj_valid) {
+    rc = enqueue_obj(e, x);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+    h.obj_valid = true;
+  }
+  for (int b = 0; b < e.n_instances; ++b) obj[b] = h.h_obj[b];
+  if (e.opt_check_finite)
+    for (int b = 0; b < e.n_instances; ++b)
+      if (!std::isfinite(obj[b])) { e.err = "eval_f: non-finite objective"; return RPM_E_NONFINITE; }
+  return RPM_OK;
+}
+
+int host_eval_grad_f(Engine& e, const double* x, int new_x, double* grad) {
+  int rc = ensure_device(e);
+  if (rc) return rc;
+  if (new_x) host_new_x(e);
+  HostPath& h = host_path(e);
+  Device& d = *e.dev;
+  if (!h.obj_valid) {
+    rc = enqueue_obj(e, x);
+    if (rc) return rc;
+  }
+  const size_t count = size_t(e.n_instances) * e.n;
+  (void)dev_pin_host(e, grad, count * sizeof(double));
+  HIP_TRY(e, hipMemcpyAsync(grad, d.d_grad, count * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  h.obj_valid = true;
+  if (e.opt_check_finite && d.h_flags2[3] != 0) { e.err = "eval_grad_f: non-finite gradient"; return RPM_E_NONFINITE; }
+  return RPM_OK;
+}
+
+int host_eval_pair(Engine& e, const double* x, double* g, double* values) {
+  int rc = ensure_device(e);
+  if (rc) return rc;
+  Device& d = *e.dev;
+  host_new_x(e);
+  rc = enqueue_cons(e, x, g, true, true);
+  if (rc) return rc;
+  bool delta = false;
+  rc = enqueue_values(e, values, &delta);
+  if (rc) return rc;
+  HIP_TRY(e, hipStreamSynchronize(d.stream));   // the one synchronisation of the pair
+  if (delta) delta_commit(e, values);
+  e.const_filled = values;
+  d.cache_valid = true;
+  e.jac_nonfinite = -1;
+  if (e.opt_check_finite) {
+    e.jac_nonfinite = d.h_flags2[1];
+    if (d.h_flags2[0] != 0) { e.err = "eval_pair: non-finite constraint value"; return RPM_E_NONFINITE; }
+    if (d.h_flags2[1] != 0) { e.err = "eval_pair: non-finite Jacobian value"; return RPM_E_NONFINITE; }
+  }
+  return RPM_OK;
+}
+
+}  // namespace rpm

@@ -31,6 +31,7 @@ template <class Prob, bool WG, bool WJ, bool AN, bool WAVE = false>
 __device__ void endpoint_block(const KParams& K, const TaskDev task, const double* __restrict__ x,
                                double* __restrict__ g, double* __restrict__ vals, double* lds, int inst) {
   constexpr int NX = Prob::NX;
+  bool bad_g = false, bad_j = false;
   constexpr int NE = Prob::NE_MAX > 0 ? Prob::NE_MAX : 1;
   constexpr int NL = Prob::NLINK_MAX > 0 ? Prob::NLINK_MAX : 1;
   static_assert(!WAVE || 2 * NX + 3 <= 64, "endpoint perturbations must fit one wave");
@@ -46,6 +47,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
         acc += K.alin_v[2 * r] * x[K.alin_j[2 * r]];
         acc += K.alin_v[2 * r + 1] * x[K.alin_j[2 * r + 1]];
         g[K.m_nl + r] = acc;
+        chk_note(bad_g, acc);
       }
       if (WJ) {
         vals[K.nnz_nl + 2 * r] = K.alin_v[2 * r];
@@ -89,7 +91,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       for (int i = 0; i < NE; ++i)
         if (i < ph.ne) {
           if (!WAVE) lds[i] = ev[i];
-          if (WG) g[ph.g0 + (NX + Prob::NC) * ph.N + i] = ev[i];
+          if (WG) { g[ph.g0 + (NX + Prob::NC) * ph.N + i] = ev[i]; chk_note(bad_g, ev[i]); }
         }
     }
     if constexpr (!WAVE) {
@@ -114,7 +116,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       else pos = 2 * NX + 1;
 #pragma unroll
       for (int i = 0; i < NE; ++i)
-        if (i < ph.ne) vals[ph.v_evt0 + i * (2 * NX + 2) + pos] = de[i];
+        if (i < ph.ne) { vals[ph.v_evt0 + i * (2 * NX + 2) + pos] = de[i]; chk_note(bad_j, de[i]); }
     }
   } else {
     // ---- one linkage pair: lane 0 = base, 1..NX = xf_left perturbations, NX+1..2NX = x0_right
@@ -152,7 +154,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       for (int i = 0; i < NL; ++i)
         if (i < lk.nlink) {
           if (!WAVE) lds[i] = lo[i];
-          if (WG) g[lk.g0 + i] = lo[i];
+          if (WG) { g[lk.g0 + i] = lo[i]; chk_note(bad_g, lo[i]); }
         }
     }
     if constexpr (!WAVE) {
@@ -171,9 +173,10 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       }
 #pragma unroll
       for (int i = 0; i < NL; ++i)
-        if (i < lk.nlink) vals[lk.v0 + v * lk.nlink + i] = dl[i];  // column-major, :461-501
+        if (i < lk.nlink) { vals[lk.v0 + v * lk.nlink + i] = dl[i]; chk_note(bad_j, dl[i]); }  // column-major, :461-501
     }
   }
+  chk_report(K.chk, bad_g, bad_j);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -219,6 +222,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   // ---- issue the loads nothing depends on first: this thread's node record and its share of the
   //      constant-block sources (stored at the very end) ----
   const int kk = tid % T, role = tid / T;
+  bool bad_g = false, bad_j = false;              // NaN/Inf among the values this thread stores (host-pointer path)
   const int kc = kk < tl.cnt ? kk : tl.cnt - 1;   // clamp so idle lanes read valid memory
   const int k = tl.k0 + kc;
   const int nidx = ph.node0 + k;
@@ -343,15 +347,18 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       Fb[(NX + j) * T + kk] = cp[j];
-      if (WG) g[ph.g0 + (NX + j) * ph.N + k] = cp[j];           // path rows, :138-164
+      if (WG) { g[ph.g0 + (NX + j) * ph.N + k] = cp[j]; chk_note(bad_g, cp[j]); }          // path rows, :138-164
     }
   }
   __syncthreads();
 
   if (act) {
     const int N = ph.N;
-    if (WG && sv >= 0 && sv < NX)
-      g[ph.g0 + sv * N + k] = (DXM ? DXs[sv * T + kk] : dx) - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
+    if (WG && sv >= 0 && sv < NX) {
+      const double dfc = (DXM ? DXs[sv * T + kk] : dx) - Fb[sv * T + kk] * (tspan / 2.0);   // defects, :113,122
+      g[ph.g0 + sv * N + k] = dfc;
+      chk_note(bad_g, dfc);
+    }
 #ifdef RPM_DIAG
     if (!(K.diag_mask & 8))
 #endif
@@ -375,6 +382,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
             val = J[o];
           }
           vb[size_t(o * NB + v) * N] = val;
+          chk_note(bad_j, val);
         }
       } else {
         // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign of the reference kept
@@ -393,10 +401,13 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
           }
           vb[size_t(o * NB + NX + NU) * N] = v0;
           vb[size_t(o * NB + NX + NU + 1) * N] = vf;
+          chk_note(bad_j, v0);
+          chk_note(bad_j, vf);
         }
       }
     }
   }
+  chk_report(K.chk, bad_g, bad_j);
 
   // ---- this workgroup's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718): the block is
   //      nx back-to-back copies of the phase's off-diagonal value list; read each source value once,
@@ -1062,6 +1073,7 @@ static hipError_t launch_tile_inst(const Engine& e, const KParams& kp, const dou
     if (s != hipSuccess) return s;
   }
   dim3 grid(unsigned(d.kp.n_my_tiles + d.kp.n_tasks), unsigned(e.n_instances));
+  if (grid.x == 0) return hipSuccess;   // an interval-sharded rank that owns no tile of this (small) mesh
   hipLaunchKernelGGL(kern, grid, dim3(threads), d.lds_bytes, st, kp, dx, dg, dv);
   return hipGetLastError();
 }
@@ -1076,6 +1088,7 @@ static hipError_t launch_tile_rl(const Engine& e, const KParams& kp, const doubl
     if (s != hipSuccess) return s;
   }
   dim3 grid(unsigned(d.kp.n_my_tiles + d.kp.n_tasks), unsigned(e.n_instances));
+  if (grid.x == 0) return hipSuccess;   // an interval-sharded rank that owns no tile of this (small) mesh
   hipLaunchKernelGGL(kern, grid, dim3(T * RG), d.lds_bytes, st, kp, dx, dg, dv);
   return hipGetLastError();
 }
@@ -1108,6 +1121,9 @@ static bool use_pipeline(const Engine& e) {
   const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
   return W >= 2LL * d.pl_slots || (W <= d.pl_slots && 4 * W >= 3LL * d.pl_slots);
 }
+
+// true when the next constraint launch is rpm_tile_kernel (one role per thread), the layout that carries the fused NaN/Inf check
+bool dev_cons_is_one_role(const Engine& e) { return !(e.role_looped && e.tile_nodes == 64 && e.opt_dx_mode == 0); }
 
 int dev_pipeline_active(const Engine& e) { return e.dev && e.role_looped && e.opt_dx_mode == 0 && use_pipeline(e) ? 1 : 0; }
 
@@ -1167,6 +1183,8 @@ int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, i
   KParams kp = e.dev->kp;
   kp.sg = (flags & 4) ? e.stride_g() : e.m;
   kp.sv = (flags & 4) ? e.stride_values() : e.nnz_jac;
+  // flags bit 3 (host-pointer path, one-role kernel only): OR "a stored value is NaN/Inf" into the engine's two host-visible words
+  kp.chk = ((flags & 8) && dev_cons_is_one_role(e)) ? e.dev->d_flags2 : nullptr;
   hipError_t s = hipErrorInvalidValue;
   with_problem(e.problem_id, [&](auto prob) {
     using P = decltype(prob);

@@ -24,10 +24,10 @@ RPM_OK, RPM_E_INVALID, RPM_E_UNSUPPORTED, RPM_E_DEVICE, RPM_E_NONFINITE = 0, 1, 
 ABI_SYMBOLS = [
     "rpm_create", "rpm_destroy", "rpm_last_error", "rpm_device_init", "rpm_get_nlp_info",
     "rpm_get_bounds_info", "rpm_get_starting_point", "rpm_eval_f", "rpm_eval_grad_f", "rpm_eval_g",
-    "rpm_eval_jac_g", "rpm_eval_h", "rpm_finalize_solution", "rpm_get_solution", "rpm_eval_g_dev",
+    "rpm_eval_jac_g", "rpm_eval_pair", "rpm_eval_h", "rpm_finalize_solution", "rpm_get_solution", "rpm_eval_g_dev",
     "rpm_eval_jac_g_dev", "rpm_eval_pair_dev", "rpm_eval_f_dev", "rpm_eval_grad_f_dev", "rpm_eval_h_dev",
     "rpm_synchronize", "rpm_set_option", "rpm_get_option", "rpm_set_instance_constants", "rpm_get_phase_sizes", "rpm_get_phase_tables",
-    "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_nlp2op_control", "rpm_final_result_save",
+    "rpm_shard_segments", "rpm_shard_pack_dev", "rpm_shard_unpack_dev", "rpm_shard_slot_len", "rpm_shard_pack_all_dev", "rpm_shard_unpack_all_dev", "rpm_nlp2op_control", "rpm_final_result_save",
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
     "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_set_all_bounds", "rpm_ipm_get_info",
@@ -72,6 +72,7 @@ def lib():
     L.rpm_eval_grad_f.argtypes = [vp, C.c_int, dp, C.c_int, dp]
     L.rpm_eval_g.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, dp]
     L.rpm_eval_jac_g.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_int, ip, ip, dp]
+    L.rpm_eval_pair.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
     L.rpm_eval_h.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp, C.c_int, C.c_int, ip, ip, dp]
     L.rpm_finalize_solution.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, C.c_double]
     L.rpm_get_solution.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
@@ -118,6 +119,9 @@ def lib():
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
     L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+    L.rpm_shard_slot_len.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.rpm_shard_pack_all_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.rpm_shard_unpack_all_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     _LIB = L
     return L
 
@@ -219,9 +223,9 @@ class NLPEngine:
         self._check(self._L.rpm_eval_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
         return out[0] if self.n_instances == 1 else out
 
-    def eval_grad_f(self, x, new_x=True):
+    def eval_grad_f(self, x, new_x=True, out=None):
         x = self._x(x)
-        out = np.zeros(self.n * self.n_instances)
+        out = np.zeros(self.n * self.n_instances) if out is None else out
         self._check(self._L.rpm_eval_grad_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
         return out
 
@@ -241,6 +245,14 @@ class NLPEngine:
         out = np.zeros(self.nnz_jac * self.n_instances) if out is None else out
         self._check(self._L.rpm_eval_jac_g(self._h, self.n, _dp(x), int(new_x), self.m, self.nnz_jac, None, None, _dp(out)))
         return out
+
+    def eval_pair(self, x, g_out=None, values_out=None):
+        """rpm_eval_pair: eval_g + eval_jac_g of one x in one call (host arrays) -> (g, values)."""
+        x = self._x(x)
+        g = np.zeros(self.m * self.n_instances) if g_out is None else g_out
+        v = np.zeros(self.nnz_jac * self.n_instances) if values_out is None else values_out
+        self._check(self._L.rpm_eval_pair(self._h, self.n, _dp(x), self.m, _dp(g), self.nnz_jac, _dp(v)))
+        return g, v
 
     def eval_h_structure(self):
         i, j = np.zeros(self.nnz_h, dtype=np.int32), np.zeros(self.nnz_h, dtype=np.int32)
@@ -381,6 +393,20 @@ class NLPEngine:
     def shard_unpack_dev(self, which, d_gathered, stride, d_full, stream=None):
         self._check(self._L.rpm_shard_unpack_dev(self._h, which, self._ptr(d_gathered), int(stride),
                                                  self._ptr(d_full), self._stream(stream)))
+
+
+    def shard_slot_len(self):
+        v = C.c_longlong()
+        self._check(self._L.rpm_shard_slot_len(self._h, C.byref(v)))
+        return v.value
+
+    def shard_pack_all_dev(self, d_g, d_values, d_slot, stream=None):
+        self._check(self._L.rpm_shard_pack_all_dev(self._h, self._ptr(d_g), self._ptr(d_values), self._ptr(d_slot),
+                                                   self._stream(stream)))
+
+    def shard_unpack_all_dev(self, d_gathered, d_g, d_values, skip_own=True, stream=None):
+        self._check(self._L.rpm_shard_unpack_all_dev(self._h, self._ptr(d_gathered), self._ptr(d_g), self._ptr(d_values),
+                                                     1 if skip_own else 0, self._stream(stream)))
 
 
 class HpLiuRefiner:

@@ -41,6 +41,44 @@ def main():
         gathered = torch.cat(recv).numpy()
         out = unpack_host(gathered, stride, all_segs, np.full_like(full[which], np.nan))
         assert np.array_equal(out, full[which]), "gathered vector differs from the single-rank result"
+    # ONE collective for g + values of several instances on a RAGGED hp mesh (rpm_peer.hip's slot layout, host mirror):
+    # pack this rank's runs of both vectors into its slot, all-gather the [world][slot] buffer in place, scatter the other
+    # rank's slot — the assembled vectors equal the single-rank result for every instance
+    from lpopc_amd.dist import pack_all_host, slot_layout, unpack_all_host
+    rp = problems.launch()
+    meshes = [([-1, -0.6, 0.1, 1], [5, 23, 2]), ([-1, 0.5, 1], [16, 17]), ([-1, 1], [33]), ([-1, -0.9, -0.5, 0.0, 0.25, 1], [3, 4, 7, 12, 16])]
+    for i, (mesh, nodes) in enumerate(meshes):
+        problems.set_mesh(rp.GetPhase(i), mesh, nodes)
+    B = 3
+    re_ = NLPEngine(rp, n_instances=B, shard_mode=1, shard_rank=rank, shard_world=world)
+    ro = Oracle(rp)
+    rxl, rxu, _, _ = re_.get_bounds_info()
+    rx0 = re_.get_starting_point()[:re_.n]
+    rxs = [problems.seeded_iterate(rx0, rxl, rxu, 40 + b) for b in range(B)]
+    g_full = np.concatenate([ro.eval_g(x_) for x_ in rxs])
+    v_full = np.concatenate([ro.eval_jac_g(x_) for x_ in rxs])
+    layout, slot = slot_layout(re_, world, B)
+    assert slot == re_.shard_slot_len()
+    g_mine, v_mine = np.full_like(g_full, np.nan), np.full_like(v_full, np.nan)
+    for b in range(B):
+        for off, ln, _ in layout[rank][0]:
+            g_mine[b * re_.m + off:b * re_.m + off + ln] = g_full[b * re_.m + off:b * re_.m + off + ln]
+        for off, ln, _ in layout[rank][1]:
+            v_mine[b * re_.nnz_jac + off:b * re_.nnz_jac + off + ln] = v_full[b * re_.nnz_jac + off:b * re_.nnz_jac + off + ln]
+    buf = torch.zeros(world * slot, dtype=torch.float64)
+    mine = buf[rank * slot:(rank + 1) * slot]
+    mine.copy_(torch.from_numpy(pack_all_host(g_mine, v_mine, layout[rank], B, re_.m, re_.nnz_jac, slot)))
+    dist.all_gather_into_tensor(buf, mine.clone())
+    unpack_all_host(buf.numpy(), layout, B, re_.m, re_.nnz_jac, slot, g_mine, v_mine, skip_rank=rank)
+    assert np.array_equal(g_mine, g_full) and np.array_equal(v_mine, v_full), "packed exchange differs from the single-rank result"
+    # every entry of g / values is owned by exactly one rank
+    cover_g, cover_v = np.zeros(re_.m, dtype=int), np.zeros(re_.nnz_jac, dtype=int)
+    for r in range(world):
+        for off, ln, _ in layout[r][0]:
+            cover_g[off:off + ln] += 1
+        for off, ln, _ in layout[r][1]:
+            cover_v[off:off + ln] += 1
+    assert (cover_g == 1).all() and (cover_v == 1).all()
     # bench.py's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank, 10.0 - rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
