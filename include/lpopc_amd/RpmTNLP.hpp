@@ -23,7 +23,16 @@ class RpmTNLPT : public Base {
   using IndexStyleEnum = typename Base::IndexStyleEnum;
   using SolverReturn = typename Base::SolverReturn;
 
-  explicit RpmTNLPT(rpm_engine* engine) : e_(engine) {}
+  // ipopt_owned_arrays = true (what Ipopt's TNLPAdapter guarantees: it allocates full_x_, full_g_ and jac_g_ once per
+  // solve, hands the same arrays to every callback and never writes into jac_g_ itself): the engine page-locks them on
+  // first sight ("pin_host"), reads x / stores g in place ("zero_copy") and delivers `values` by difference
+  // ("delta_values": the constant Doffdiag block, the linear entries and every x-independent block cross PCIe once; the
+  // engine still checks 64 sampled entries of the array before each delivery and re-sends everything if one differs).
+  // Pass false for a caller that allocates fresh arrays per call or edits `values` in place: plain staged copies.
+  explicit RpmTNLPT(rpm_engine* engine, bool ipopt_owned_arrays = true) : e_(engine) {
+    rpm_set_option(e_, "pin_host", ipopt_owned_arrays ? 1 : 0);
+    rpm_set_option(e_, "delta_values", ipopt_owned_arrays ? 1 : 0);
+  }
 
   bool get_nlp_info(Index& n, Index& m, Index& nnz_jac_g, Index& nnz_h_lag, IndexStyleEnum& index_style) override {
     int n_, m_, nj, nh, st;

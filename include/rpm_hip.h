@@ -51,7 +51,10 @@ enum {
   RPM_PROBLEM_BRYSON_DENHAM = 3,   /* example/bryson-denham/BrysonDenham.cpp:100-167 */
   RPM_PROBLEM_BRACHISTOCHRONE = 4, /* authored here (BASELINE config 1) */
   RPM_PROBLEM_MIN_TIME_CLIMB = 5,  /* authored here (BASELINE config 2) */
-  RPM_PROBLEM_QUADROTOR = 6        /* authored here (BASELINE config 5) */
+  RPM_PROBLEM_QUADROTOR = 6,       /* authored here (BASELINE config 5) */
+  RPM_PROBLEM_USER = 100           /* the functor `rpm::UserProblem` of a user's header, in a library built from that header
+                                      (lpopc_amd/userproblem.py, INTEGRATION.md "your own problem"): the stand-in for
+                                      subclassing FunctionWrapper (Core/LpFunctionWrapper.h:50-69) */
 };
 
 /* first-derive option, Core/LpOptDerive.hpp:29-32 */

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "problems/problems.hpp"
+#ifdef RPM_USER_PROBLEM_HEADER
+#include RPM_USER_PROBLEM_HEADER   // defines struct rpm::UserProblem (same interface as the structs of problems.hpp)
+#endif
 #include "rpm_engine.hpp"
 
 namespace rpm {
@@ -121,12 +124,17 @@ __device__ __forceinline__ void chk_report(int* chk, bool bad_g, bool bad_j) {
 template <class F>
 inline bool with_problem(int id, F&& fn) {
   switch (id) {
+#ifndef RPM_ONLY_USER_PROBLEM   // a user library may leave the built-in functors out (6x shorter build)
     case RPM_PROBLEM_LAUNCH: fn(LaunchProblem{}); return true;
     case RPM_PROBLEM_HYPERSENSITIVE: fn(HypersensitiveProblem{}); return true;
     case RPM_PROBLEM_BRYSON_DENHAM: fn(BrysonDenhamProblem{}); return true;
     case RPM_PROBLEM_BRACHISTOCHRONE: fn(BrachistochroneProblem{}); return true;
     case RPM_PROBLEM_MIN_TIME_CLIMB: fn(MinTimeClimbProblem{}); return true;
     case RPM_PROBLEM_QUADROTOR: fn(QuadrotorProblem{}); return true;
+#endif
+#ifdef RPM_USER_PROBLEM_HEADER
+    case RPM_PROBLEM_USER: fn(UserProblem{}); return true;
+#endif
   }
   return false;
 }

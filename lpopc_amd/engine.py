@@ -43,13 +43,19 @@ def build(force=False):
     return _SO
 
 
-def lib():
+_LIBS = {}
+
+
+def lib(path=None):
+    """The native library (ctypes handle with its prototypes set): the package's librpm_hip.so, or — `path` — a library
+    built from a user's functor header (lpopc_amd.userproblem).  One handle per path, loaded once."""
     global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(_SO):
+    so = os.path.abspath(path) if path else _SO
+    if so in _LIBS:
+        return _LIBS[so]
+    if not os.path.exists(so):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(the engine has no CPU fallback)" % _SO)
+                          "(the engine has no CPU fallback)" % so)
     # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7.  Importing torch first makes the
     # loader resolve this library's libamdhip64.so.7 dependency to the copy torch already mapped; loading in
     # the other order leaves two runtimes in the process and torch then reports "No HIP GPUs are available".
@@ -57,7 +63,7 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(_SO)
+    L = C.CDLL(so)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
     L.rpm_create.argtypes = [C.POINTER(_abi.rpm_problem_desc), C.POINTER(vp)]
     L.rpm_destroy.argtypes = [vp]
@@ -122,7 +128,9 @@ def lib():
     L.rpm_shard_slot_len.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.rpm_shard_pack_all_dev.argtypes = [vp, vp, vp, vp, vp]
     L.rpm_shard_unpack_all_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp]
-    _LIB = L
+    _LIBS[so] = L
+    if so == _SO:
+        _LIB = L
     return L
 
 
@@ -147,7 +155,7 @@ class NLPEngine:
 
     def __init__(self, problem, options=None, n_instances=1, shard_mode=0, shard_rank=0, shard_world=1,
                  tile_nodes=0, device=None, role_loop=None):
-        self._L = lib()
+        self._L = lib(getattr(problem.GetOpimalProblemFuns(), "library", None))
         self._desc, self._keep = _abi.lower(problem, options, n_instances, shard_mode, shard_rank, shard_world)
         h = C.c_void_p()
         rc = self._L.rpm_create(C.byref(self._desc), C.byref(h))
@@ -414,12 +422,22 @@ class HpLiuRefiner:
     reference's mesh / solution histories across meshes."""
 
     def __init__(self, n_phases, tol, nmax, ratio_r):
-        self._L = lib()
-        self._h = C.c_void_p()
-        rc = self._L.rpm_hpliu_create(int(n_phases), float(tol), int(nmax), float(ratio_r), C.byref(self._h))
-        if rc != RPM_OK:
-            raise RpmError(rc, "rpm_hpliu_create: invalid arguments")
+        self._args = (int(n_phases), float(tol), int(nmax), float(ratio_r))
+        self._L = None          # the native object is created by the library of the first engine it refines
+        self._h = None
         self.P = int(n_phases)
+
+    def _ensure(self, engine):
+        if self._h is not None:
+            if engine._L is not self._L:
+                raise RpmError(RPM_E_INVALID, "HpLiuRefiner: engines of one refinement history must come from one native library")
+            return
+        self._L = engine._L
+        self._h = C.c_void_p()
+        rc = self._L.rpm_hpliu_create(*self._args, C.byref(self._h))
+        if rc != RPM_OK:
+            self._h = None
+            raise RpmError(rc, "rpm_hpliu_create: invalid arguments")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -431,6 +449,7 @@ class HpLiuRefiner:
     def refine(self, engine, x=None, rel_err=None, capacity=8192):
         """-> (no_more_refine, [(mesh_points, nodes_per_interval) per phase]).  rel_err: list of per-phase relative-error
         matrices to decide from (host only); default: estimate on the device."""
+        self._ensure(engine)
         xp = _dp(engine._x(x)) if x is not None else None
         rp = None
         if rel_err is not None:
@@ -457,7 +476,7 @@ class BatchedIPM:
               4: "inertia correction failed", 5: "NaN/Inf"}
 
     def __init__(self, engine, **options):
-        self._L = lib()
+        self._L = engine._L
         self._e = engine
         self._h = C.c_void_p()
         rc = self._L.rpm_ipm_create(engine._h, C.byref(self._h))

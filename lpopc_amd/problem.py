@@ -25,9 +25,12 @@ class Limit:
 class ProblemFunctor:
     """Stands where shared_ptr<FunctionWrapper> stands in the reference."""
 
-    def __init__(self, problem_id, consts=()):
+    def __init__(self, problem_id, consts=(), library=None):
         self.problem_id = int(problem_id)
         self.consts = [float(c) for c in consts]
+        # path of the native library that holds the functor: None = the package's librpm_hip.so (built-in problems);
+        # for RPM_PROBLEM_USER the library lpopc_amd.userproblem.build() compiled from the user's functor header
+        self.library = library
 
 
 class Phase:
