@@ -704,7 +704,10 @@ constexpr PlShape pl_shape(int R) {
   return R <= 12 ? PlShape{2, 4, 2} : PlShape{1, pl_role_groups(R), 2};
 }
 
-template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN>
+// (Tried for the one-half shape, R > 12 roles: __launch_bounds__(..., 6) so that two 11-wave workgroups share a CU and one's
+// store phases overlap the other's dynamics.  The quadrotor kernel needs ~156 VGPRs; at 80 it spills 76 of them and the
+// 1024-instance sweep takes 89.9 us instead of 51 — DESIGN.md §4.)
+template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN, bool DXM = false>
 __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
     const KParams K, int n_inst, const double* __restrict__ xall, double* __restrict__ gall,
     double* __restrict__ vall) {
@@ -733,9 +736,11 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
   const int S_TT = PL_REC, S_X = S_TT + 2, S_U = S_X + NX * K.max_span, S_D = S_U + NU * T;
   const int S_TAU = S_D + K.max_drow, S_DG = S_TAU + T, S_ND = S_DG + T, S_CV = S_ND + 2 * T;
   const int S_SIZE = S_CV + (WJ ? K.max_cshare : 0);
-  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T + 2);
+  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T + 2 + (DXM ? NX * T : 0));
   double* Fb = lds + 2 * S_SIZE;
   int* fb_ready = reinterpret_cast<int*>(Fb + (NX + NC) * T);   // tile count for which Fb holds the unperturbed dynamics
+  int* dx_ready = fb_ready + 1;                                 // dx_mode 1: DMA waves that have published their rows of D.X, summed over tiles
+  double* DXs = Fb + (NX + NC) * T + 2;                         // dx_mode 1: [NX][T] D.X of the current tile (matrix cores)
 #ifdef RPM_DIAG
 #define RPM_PTRC(j, slot)                                                           \
   if (K.trace && (threadIdx.x & 63) == 0 && (j) < 2) K.trace[size_t(w) * 64 + (j)*32 + (slot)] = wall_clock64()
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
       if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
       if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
     };
-    if (dw == 0 && lane == 0) *fb_ready = 0;
+    if (dw == 0 && lane == 0) { *fb_ready = 0; *dx_ready = 0; }
     if (n_iter > 0)   // the tile table never changes: constant address space, i.e. scalar loads for the first record
       stage(w, lds, runs_of((const __attribute__((address_space(4))) int*)(K.tiles + (w - (w / nt) * nt))));
     for (int j = 0; j < n_iter_wg; ++j) {
@@ -802,6 +807,53 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
       __builtin_amdgcn_s_waitcnt(0);   // the staged loads (and the constant stores before them) have landed
       __syncthreads();                 // A: buffer `cur` is complete
       RPM_PTRC(j, 16);
+      if constexpr (DXM && WG) {
+        // dx_mode 1: the tile's D.X on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), by the DMA waves — the matrix pipe is
+        // idle in this kernel and these waves have slack — first thing after the buffer is complete, so that the state
+        // roles find it published when their dynamics are done.  A = the tile's block-banded D rows (zero outside a row's
+        // interval), B = the staged X rows (span x NX, zero-padded to 16 columns); 16-row blocks are dealt to the NDMA
+        // waves; a block only walks the columns its rows' intervals touch (5 k-steps for a 16-node interval).  Operand
+        // maps: A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15], C/D: col = l&15, row = (l>>4) + 4 reg.  The k-order
+        // (and the fused multiply-add) differ from the reference's ascending-column loop: agreement to rounding only.
+        if (j < n_iter) {
+          typedef double d4 __attribute__((ext_vector_type(4)));
+          const int* rec = reinterpret_cast<const int*>(cur);
+          const int cnt = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, cnt) / 4]);
+          const int span0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, span0) / 4]);
+          const int drow0 = __builtin_amdgcn_readfirstlane(rec[offsetof(TileDev, drow0) / 4]);
+          const NodeDev* ND = reinterpret_cast<const NodeDev*>(cur + S_ND);
+          const double* Ds = cur + S_D;
+          const double* Xs = cur + S_X;
+          const int lr = lane & 15, kq = lane >> 4;
+          for (int rb = 16 * dw; rb < cnt; rb += 16 * NDMA) {
+            const int row = rb + lr;
+            const bool row_ok = row < cnt;
+            const NodeDev ndr = ND[row_ok ? row : cnt - 1];
+            const int rel0 = ndr.dcol0 - span0;
+            const double* drow = Ds + (ndr.drow_off - drow0);
+            const NodeDev nfirst = ND[rb], nlast = ND[min(rb + 15, cnt - 1)];      // wave-uniform: LDS broadcast reads
+            const int kmin = __builtin_amdgcn_readfirstlane(nfirst.dcol0 - span0);
+            const int kmax = __builtin_amdgcn_readfirstlane(nlast.dcol0 + nlast.dlen - span0);
+            for (int cb = 0; cb < NX; cb += 16) {
+              const int st = cb + lr;
+              d4 acc = {0.0, 0.0, 0.0, 0.0};
+              for (int k0 = kmin; k0 < kmax; k0 += 4) {
+                const int kcol = k0 + kq;
+                const int rel = kcol - rel0;
+                const double a = (row_ok && rel >= 0 && rel < ndr.dlen) ? drow[rel] : 0.0;
+                const double b = (st < NX && kcol < kmax) ? Xs[st * K.max_span + kcol] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int orow = rb + kq + 4 * i;
+                if (st < NX && orow < cnt) DXs[st * T + orow] = acc[i];
+              }
+            }
+          }
+          if (lane == 0) __hip_atomic_fetch_add(dx_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718), written while the compute waves are
       // in their first pass and store nothing; then the next tile's loads.  (The order matters twice: an LDS read of
       // this wave after the direct-to-LDS loads would wait for them, and the Jacobian stores of the later passes
@@ -911,7 +963,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
       }
       const int sv = WJ ? role - 1 : role;
       double dx = 0.0;
-      if (WG && sv >= 0 && sv < NX) {   // D.X in the reference's ascending-column order (LpSparseMatrix.cpp:142-153)
+      if (WG && !DXM && sv >= 0 && sv < NX) {   // D.X in the reference's ascending-column order (LpSparseMatrix.cpp:142-153)
         const NodeDev nd = reinterpret_cast<const NodeDev*>(cur + S_ND)[kc];
         const double* drow = Ds + (nd.drow_off - drow0);
         const double* xcol = Xs + sv * K.max_span + (nd.dcol0 - span0);
@@ -981,7 +1033,13 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
       if (act) {
         const double tau = cur[S_TAU + kc], t0 = cur[S_TT], tf = cur[S_TT + 1];
         const double ddiag = cur[S_DG + kc];
-        if (WG && sv >= 0 && sv < NX) g[g0 + sv * N + k] = dx - Fb[sv * T + kk] * ((tf - t0) / 2.0);   // defects, :113,122
+        if (WG && sv >= 0 && sv < NX) {
+          if constexpr (DXM) {   // published by the DMA waves (matrix cores); NDMA of them per tile
+            while (__hip_atomic_load(dx_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NDMA * (jt + 1)) __builtin_amdgcn_s_sleep(1);
+            dx = DXs[sv * T + kk];
+          }
+          g[g0 + sv * N + k] = dx - Fb[sv * T + kk] * ((tf - t0) / 2.0);   // defects, :113,122
+        }
         if (WJ && role >= 1) {
           double J[NO];
 #pragma unroll
@@ -1093,19 +1151,30 @@ static hipError_t launch_tile_rl(const Engine& e, const KParams& kp, const doubl
   return hipGetLastError();
 }
 
-template <class Prob, bool WG, bool WJ, bool AN>
+// extra LDS of the dx_mode 1 variant: one [NX][64] D.X buffer per half
+static size_t pl_dxm_extra(const Engine& e) {
+  ProblemDims pd;
+  problem_dims(e.problem_id, &pd);
+  return size_t(pd.nx + pd.nu + 2 <= 12 ? 2 : 1) * size_t(pd.nx) * 64 * sizeof(double);
+}
+// dx_mode 1 on the pipelined kernel: finite-difference mode only (as in the one-role kernel), and the extra buffer must fit
+static bool pl_dxm_ok(const Engine& e) {
+  return e.first_derive != RPM_DERIVE_ANALYTIC && e.dev->pl_lds + pl_dxm_extra(e) <= 160 * 1024;
+}
+
+template <class Prob, bool WG, bool WJ, bool AN, bool DXM = false>
 static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
   const Device& d = *e.dev;
   constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2);
-  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN>;
-  if (d.pl_lds > 64 * 1024) {
-    hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       int(d.pl_lds));
+  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN, DXM>;
+  const size_t lds = d.pl_lds + (DXM ? size_t(S.NH) * Prob::NX * 64 * sizeof(double) : 0);
+  if (lds > 64 * 1024) {
+    hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (s != hipSuccess) return s;
   }
   const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
   const long long halves = W < d.pl_slots ? W : d.pl_slots;   // pl_slots: resident halves (occupancy query)
-  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA)), d.pl_lds, st, kp,
+  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA)), lds, st, kp,
                      e.n_instances, dx, dg, dv);
   return hipGetLastError();
 }
@@ -1123,14 +1192,26 @@ static bool use_pipeline(const Engine& e) {
 }
 
 // true when the next constraint launch is rpm_tile_kernel (one role per thread), the layout that carries the fused NaN/Inf check
-bool dev_cons_is_one_role(const Engine& e) { return !(e.role_looped && e.tile_nodes == 64 && e.opt_dx_mode == 0); }
+// which of the three layouts the next constraint launch uses: 2 pipelined, 1 role-looped, 0 one role per thread
+static int cons_layout(const Engine& e) {
+  if (!(e.role_looped && e.tile_nodes == 64)) return 0;
+  if (e.opt_dx_mode == 0) return use_pipeline(e) ? 2 : 1;
+  return (use_pipeline(e) && pl_dxm_ok(e)) ? 2 : 0;   // dx_mode 1: matrix-core D.X exists in the pipelined and the one-role kernel
+}
+bool dev_cons_is_one_role(const Engine& e) { return !e.dev || cons_layout(e) == 0; }
 
-int dev_pipeline_active(const Engine& e) { return e.dev && e.role_looped && e.opt_dx_mode == 0 && use_pipeline(e) ? 1 : 0; }
+int dev_pipeline_active(const Engine& e) { return e.dev && cons_layout(e) == 2 ? 1 : 0; }
 
 template <class Prob, int T>
 static hipError_t launch_tile_T(const Engine& e, const KParams& kp, bool wg, bool wj, const double* dx, double* dg,
                                 double* dv, hipStream_t st) {
-  if (e.role_looped && T == 64 && e.opt_dx_mode == 0 && use_pipeline(e)) {
+  const int layout = T == 64 ? cons_layout(e) : 0;
+  if (layout == 2 && e.opt_dx_mode == 1) {   // D.X on the matrix cores, by the DMA waves (finite-difference mode)
+    if (wg && wj) return launch_tile_pl<Prob, true, true, false, true>(e, kp, dx, dg, dv, st);
+    if (wg) return launch_tile_pl<Prob, true, false, false, true>(e, kp, dx, dg, dv, st);
+    return launch_tile_pl<Prob, false, true, false>(e, kp, dx, dg, dv, st);   // Jacobian only: no D.X in it
+  }
+  if (layout == 2) {
     const bool an_pl = e.first_derive == RPM_DERIVE_ANALYTIC;
     if constexpr (Prob::HAS_ANALYTIC) {
       if (an_pl) {
@@ -1142,7 +1223,7 @@ static hipError_t launch_tile_T(const Engine& e, const KParams& kp, bool wg, boo
     if (wj) return launch_tile_pl<Prob, false, true, false>(e, kp, dx, dg, dv, st);
     return launch_tile_pl<Prob, true, false, false>(e, kp, dx, dg, dv, st);
   }
-  if (e.role_looped && T == 64 && e.opt_dx_mode == 0) {   // throughput layout (see rpm_tile_rl_kernel)
+  if (layout == 1) {   // throughput layout (see rpm_tile_rl_kernel)
     const bool an_rl = e.first_derive == RPM_DERIVE_ANALYTIC;
     if constexpr (Prob::HAS_ANALYTIC) {
       if (an_rl) {

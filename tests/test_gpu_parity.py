@@ -237,6 +237,48 @@ def test_mfma_dx_mode(built, name, make, mode, tile):
     eng.close()
 
 
+@pytest.mark.parametrize("name,make,mode,B", [(CASES[5][0], CASES[5][1], CASES[5][2], 20), (CASES[6][0], CASES[6][1], CASES[6][2], 7),
+                                              ("launch_metric", lambda: problems.config("launch"), "perturb", 18),
+                                              ("launch_ragged", _launch_ragged, "perturb", 150), ("bryson_denham", CASES[1][1], "perturb", 9)],
+                         ids=[CASES[5][0], CASES[6][0], "launch_metric", "launch_ragged", "bryson_denham"])
+def test_mfma_dx_mode_in_the_pipelined_kernel(built, name, make, mode, B):
+    """dx_mode=1 in rpm_tile_pl_kernel (what bench.py runs): the DMA waves compute the tile's D.X with
+    v_mfma_f64_16x16x4_f64 and publish it in LDS.  Defects agree with the scalar reference-order sum and with the oracle
+    up to the summation order; every other output (path rows, events, linkages, the whole Jacobian) is bit-identical."""
+    import torch
+    prob = make()
+    orc = oracle_for(prob)
+    xl, xu, _, _ = orc.bounds()
+    xs = np.stack([problems.seeded_iterate(orc.starting_point(), xl, xu, 70 + i, mode) for i in range(B)])
+    dx = torch.from_numpy(xs).cuda()
+    out = []
+    for dxm in (0, 1):
+        eng = NLPEngine(prob, n_instances=B, device=0, role_loop=1)
+        eng.set_option("pipeline", 1)
+        eng.set_option("dx_mode", dxm)
+        dg = torch.full((B, eng.m), np.nan, dtype=torch.float64, device="cuda")
+        dv = torch.full((B, eng.nnz_jac), np.nan, dtype=torch.float64, device="cuda")
+        eng.eval_pair_dev(dx, dg, dv)
+        dg2 = torch.full((B, eng.m), np.nan, dtype=torch.float64, device="cuda")
+        eng.eval_g_dev(dx, dg2)
+        torch.cuda.synchronize()
+        assert eng.get_option("pipeline_active") == 1
+        assert torch.equal(dg, dg2)
+        out.append((dg.cpu().numpy(), dv.cpu().numpy()))
+        eng.close()
+    (g0, v0), (g1, v1) = out
+    assert not np.isnan(g1).any()
+    assert np.array_equal(v1, v0)
+    # summation order only: |d_j x_j| reaches 1e3 on 1/64-wide intervals and 1e10 on the hp mesh's 1e-5-wide ones, where
+    # defects of order 1 stand beside defects of order 1e8 — the bound is relative to the element or to the largest defect
+    def close(a, b):
+        return bool(np.all(np.abs(a - b) <= np.maximum(5e-12 * np.maximum(1.0, np.abs(b)), 1e-13 * np.abs(b).max())))
+    assert close(g1, g0)
+    for b in (0, B // 2, B - 1):
+        assert close(g1[b], orc.eval_g(xs[b]))
+    assert not np.array_equal(g1, g0) or name == "bryson_denham"   # the matrix cores really were used (different rounding)
+
+
 # ---- exact Hessian (hessian-approximation=exact): forward second differences, LpHessian.cpp ------------------
 def _exact():
     o = Options()
