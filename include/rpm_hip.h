@@ -251,6 +251,9 @@ int rpm_ipm_set_all_bounds(rpm_ipm* s, const double* x_l, const double* x_u);   
 int rpm_ipm_get_info(rpm_ipm* s, int* kkt_order, int* band_order, int* half_bandwidth, int* border,
                      long long* storage_doubles, int* n_slacks);
 int rpm_ipm_get_stats(rpm_ipm* s, int* iterations, int* factorizations, int* trial_points);
+/* the factorisation's sub-problems: 5 ints each (order, banded part, border, half bandwidth, doubles per stored column); one
+ * entry for the band + border layout, the interval blocks followed by the separator system with nested dissection */
+int rpm_ipm_get_subproblems(rpm_ipm* s, int capacity, int* geom, int* n_sub);
 /* records of the last solve when option "trace" > 0: 8 doubles per accepted step — f, theta = |c|_1, mu, alpha, alpha_z,
  * delta_w, E_0 at the step's start, backtracking steps */
 int rpm_ipm_get_trace(rpm_ipm* s, int instance, int capacity, double* records, int* n_records);
@@ -274,6 +277,13 @@ int rpm_ipm_solve_dev(rpm_ipm* s, double* d_x, double* d_lambda, double* obj, in
  * caller's matrices given in the band + border storage (host pointers, n_instances of each) */
 int rpm_ipm_get_permutation(rpm_ipm* s, int* pos, int capacity);
 int rpm_ipm_debug_solve(rpm_ipm* s, const double* k_storage, const double* rhs, double* sol, int* n_pos, int* n_neg);
+/* layout-independent forms (band + border, or nested dissection: engine option "ipm_nested" = 1 before rpm_ipm_create — every
+ * mesh interval is eliminated by a workgroup of its own up to the states at its first node, the Schur complements add up into
+ * a block-tridiagonal separator system + border; same LDL^T without pivoting, same inertia from the signs of D): dense
+ * symmetric matrices B x Nt x Nt and vectors in unknown order ([0,n) variables, slacks, multipliers); rpm_ipm_debug_slot
+ * tells whether the layout can hold entry (ua, uc) */
+int rpm_ipm_debug_solve_dense(rpm_ipm* s, const double* k_dense, const double* rhs, double* sol, int* n_pos, int* n_neg);
+int rpm_ipm_debug_slot(rpm_ipm* s, int ua, int uc, long long* offset);
 
 /* ---- device-resident variants (inputs/outputs already in HBM; used by benches, by the
  *      MPC sweep and by any device-side solver).  Pointers are device pointers on the
@@ -324,6 +334,9 @@ int rpm_synchronize(rpm_engine* e);
  *                    bit-identical to a full delivery.  get-only "delta_total_runs": runs this engine owns; "delta_sent_runs": runs
  *                    stored since the previous query of this option (blocking; for tests and reports).
  *                    Interval-sharded engines deliver only the runs they own (host-consumer multi-GPU mode).
+ * "ipm_nested"       -1 (default: when the structure allows) | 0 | 1 (must), read by rpm_ipm_create: factor the KKT matrices by
+ *                    nested dissection over the mesh intervals (one workgroup per interval and instance instead of one per
+ *                    instance: the metric problem's single instance uses 256 CUs instead of one; 0 = one band + border matrix)
  * "zero_copy"        1 (default): with page-locked caller arrays the tile kernel reads x straight from the caller's array and
  *                    stores g straight into it (no copy operations: one launch + one synchronisation per rpm_eval_g);
  *                    0: staged through the engine's HBM buffers with copy-engine transfers

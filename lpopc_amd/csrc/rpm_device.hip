@@ -7,6 +7,8 @@
 
 namespace rpm {
 
+static void pin_release(const void* ptr);   // hipHostUnregister with failure accounting (defined with dev_pin_host)
+
 // ------------------------------------------------------------------------------------------
 // Objective and gradient.  One workgroup per phase; thread = node (strided).  Sums use a fixed
 // binary tree over the workgroup so the result is deterministic (independent of timing).
@@ -185,7 +187,7 @@ void device_destroy(Engine& e) {
   if (d->h_flags2) (void)hipHostFree(d->h_flags2);   // d_flags2 is its device alias
   host_path_destroy(d);
   exchange_destroy(d);
-  for (auto& p : d->pinned) (void)hipHostUnregister(const_cast<void*>(p.ptr));
+  for (auto& p : d->pinned) pin_release(p.ptr);
   (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
   for (auto& row : d->segtab)
     for (auto& t : row)
@@ -416,6 +418,11 @@ int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t coun
 // buffers cannot accumulate page-locked memory; a range that overlaps a new one is dropped first (the caller freed
 // and re-allocated there).  The caller must keep a registered buffer mapped until rpm_destroy or until it has been
 // evicted (rpm_hip.h, option "pin_host").  Returns the device-visible alias of `ptr`, or nullptr when it is not pinned.
+static int g_pin_unreg_fail = 0, g_pin_reg_fail = 0, g_pin_reg_ok = 0;   // process-wide diagnostics (rpm_get_option "pin_*")
+int dev_pin_counter(int which) { return which == 0 ? g_pin_reg_ok : (which == 1 ? g_pin_reg_fail : g_pin_unreg_fail); }
+static void pin_release(const void* ptr) {
+  if (hipHostUnregister(const_cast<void*>(ptr)) != hipSuccess) { ++g_pin_unreg_fail; (void)hipGetLastError(); }
+}
 void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
   constexpr size_t PIN_MAX = 8;
   if (!e.opt_pin_host || !ptr || bytes == 0) return nullptr;   // small arrays too: a pageable copy costs ~20 us each way
@@ -431,22 +438,22 @@ void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
   for (size_t i = 0; i < d.pinned.size();) {   // overlapping older registration: the range was re-allocated
     const char* plo = static_cast<const char*>(d.pinned[i].ptr);
     if (lo < plo + d.pinned[i].bytes && plo < lo + bytes) {
-      (void)hipHostUnregister(const_cast<void*>(d.pinned[i].ptr));
-      (void)hipGetLastError();
+      pin_release(d.pinned[i].ptr);
       d.pinned.erase(d.pinned.begin() + i);
     } else {
       ++i;
     }
   }
   while (d.pinned.size() >= PIN_MAX) {
-    (void)hipHostUnregister(const_cast<void*>(d.pinned.front().ptr));
-    (void)hipGetLastError();
+    pin_release(d.pinned.front().ptr);
     d.pinned.erase(d.pinned.begin());
   }
   if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
     (void)hipGetLastError();
+    ++g_pin_reg_fail;
     return nullptr;
   }
+  ++g_pin_reg_ok;
   void* dptr = nullptr;
   if (hipHostGetDevicePointer(&dptr, const_cast<void*>(ptr), 0) != hipSuccess) {
     (void)hipGetLastError();

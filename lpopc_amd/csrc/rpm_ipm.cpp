@@ -7,7 +7,30 @@
 
 namespace rpm {
 
-int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why) {
+constexpr int IPM_PLAN_W = 16;   // = IPM_W, the factorisation's block width (rpm_ipm_device.hpp)
+
+static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why);
+
+void ipm_plan_group_hessian(IpmPlan& p) {
+  std::vector<std::pair<int, int>> all;   // (slot, COO entry), COO order kept inside a slot
+  for (int k = 0; k < int(p.hes_dst.size()); ++k)
+    if (p.hes_dst[k] >= 0) all.emplace_back(p.hes_dst[k], k);
+  std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+  p.hg_ptr.assign(1, 0);
+  p.hg_src.clear();
+  p.hg_dst.clear();
+  for (size_t i = 0; i < all.size(); ++i) {
+    if (i == 0 || all[i].first != all[i - 1].first) {
+      if (i) p.hg_ptr.push_back(int(p.hg_src.size()));
+      p.hg_dst.push_back(all[i].first);
+    }
+    p.hg_src.push_back(all[i].second);
+  }
+  if (!all.empty()) p.hg_ptr.push_back(int(p.hg_src.size()));
+}
+
+int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why, int nested) {
+  if (nested) return build_ipm_plan_nd(e, p, why);
   p = IpmPlan();
   p.n = e.n;
   p.m = e.m;
@@ -107,7 +130,356 @@ int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why) {
     p.jt_ent[q] = k;
     p.jt_row[q] = e.jac_i[k];
   }
+  p.Nt_alloc = p.Nt;
+  p.max_rows = IPM_PLAN_W + p.b + p.nb;
+  ipm_plan_group_hessian(p);
   return RPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// nested dissection by mesh interval (rpm_ipm.hpp)
+namespace {
+struct NdClass {
+  std::vector<int> ivl;     // Nt: interval of an interior unknown, -1 otherwise
+  std::vector<int> loc;     // Nt: local index inside its interval (interior) or level-2 position (separator / border)
+};
+size_t factor_lds_of(int b, int nb) {   // = kkt_factor_lds_bytes (rpm_ipm_kernels.hip)
+  const size_t W = IPM_PLAN_W;
+  return (size_t(b + 8) * W + W * (W + 1) + W * W + W + 2 * size_t(nb) * W + size_t(nb) * nb) * sizeof(double);
+}
+long long sub_at(const KktSubHost& g, int i, int j) { return g.koff + (long long)j * g.CS + (i < g.Nb ? i - j : g.b + 1 + i - g.Nb); }
+}  // namespace
+
+static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
+  p = IpmPlan();
+  p.nd = 1;
+  p.n = e.n;
+  p.m = e.m;
+  auto fail = [&](const std::string& msg, int code = RPM_E_UNSUPPORTED) {
+    if (why) *why = msg;
+    return code;
+  };
+  if (int(e.hes_i.size()) != e.nnz_h || int(e.jac_i.size()) != e.nnz_jac) return fail("the Jacobian / Hessian structure is not built yet", RPM_E_INVALID);
+  p.row_slack.assign(p.m, -1);
+  for (int r = 0; r < p.m; ++r)
+    if (e.gl[r] != e.gu[r]) {
+      p.row_slack[r] = p.ns++;
+      p.slack_row.push_back(r);
+    }
+  p.nv = p.n + p.ns;
+  p.Nt = p.nv + p.m;
+  p.fixed.assign(p.n, 0);
+  for (int i = 0; i < p.n; ++i) p.fixed[i] = e.xl[i] == e.xu[i] ? 1 : 0;
+
+  // ---- intervals, and where every unknown lives: interior of an interval (with its node as sort key), separator, border
+  struct Ivl { int phase, k0, nk, nx; std::vector<int> interior; int sep0 = 0; bool last = false; };
+  std::vector<Ivl> iv;
+  std::vector<int> ivl_of(p.Nt, -1), sep_of(p.Nt, -1), sep_state(p.Nt, 0);   // sep_state: a state at an interval's first node
+  std::vector<long long> key(p.Nt, -1);
+  for (int ip = 0; ip < e.P; ++ip) {
+    const PhaseDev& q = e.phd[ip];
+    const PhaseHost& ph = e.ph[ip];
+    std::vector<int> node_ivl(q.N);
+    int r0 = 0;
+    const int base = int(iv.size());
+    for (int k = 0; k < ph.K; ++k) {
+      Ivl I;
+      I.phase = ip; I.k0 = r0; I.nk = ph.nk[k]; I.nx = q.nx; I.last = k == ph.K - 1;
+      for (int kk = 0; kk < I.nk; ++kk) node_ivl[r0 + kk] = base + k;
+      r0 += ph.nk[k];
+      iv.push_back(I);
+    }
+    // Separator of an interval = the states at its first node.  What else lives at that node — controls, slacks and the
+    // multipliers of its rows — belongs to the interior but is eliminated LAST there: those rows lean on the separator
+    // states (D(0,0) x_0), which are not eliminated before level 2, so eliminated in node order they would meet pivots of
+    // -delta_c alone (on the badly scaled climb problem the first Newton step came out 3e-4 off); at the end of the
+    // interior they have the interval's other states, D(0,1..N-1), behind them.
+    for (int i = 0; i < q.nx; ++i)
+      for (int k = 0; k < q.N; ++k) {   // X(N, .) stays in the global border
+        const int u = q.x_state0 + i * (q.N + 1) + k, I = node_ivl[k];
+        if (k == iv[I].k0) { sep_of[u] = I; sep_state[u] = 1; }
+        else { ivl_of[u] = I; key[u] = k; }
+      }
+    auto place = [&](int u, int k) {
+      const int I = node_ivl[k];
+      ivl_of[u] = I;
+      key[u] = k == iv[I].k0 ? (long long)q.N + 1 : k;   // first node: after every other node of the interval
+    };
+    for (int j = 0; j < q.nu; ++j)
+      for (int k = 0; k < q.N; ++k) place(q.x_control0 + j * q.N + k, k);
+    for (int r = 0; r < (q.nx + q.nc) * q.N; ++r) {
+      const int row = q.g0 + r, k = r % q.N;
+      place(p.nv + row, k);
+      if (p.row_slack[row] >= 0) place(p.n + p.row_slack[row], k);
+    }
+  }
+  const int KI = int(iv.size());
+  auto type_of = [&](int u) { return u < p.n ? 0 : (u < p.nv ? 1 : 2); };
+  std::vector<int> border;
+  std::vector<std::vector<int>> sep(KI);
+  for (int u = 0; u < p.Nt; ++u) {
+    if (ivl_of[u] >= 0) iv[ivl_of[u]].interior.push_back(u);
+    else if (sep_of[u] >= 0) sep[sep_of[u]].push_back(u);     // ascending unknown index: states, controls, slacks, multipliers
+    else border.push_back(u);
+  }
+  for (Ivl& I : iv)
+    std::stable_sort(I.interior.begin(), I.interior.end(), [&](int a, int c) {
+      if (key[a] != key[c]) return key[a] < key[c];
+      return type_of(a) < type_of(c);
+    });
+  p.nb = int(border.size());
+
+  // ---- positions: [interior_I | border work space of I] for every interval, then level 2 = separators in time order, border
+  NdClass C;
+  C.ivl = ivl_of;
+  C.loc.assign(p.Nt, -1);
+  p.pos.assign(p.Nt, 0);
+  std::vector<int> l2pos(p.Nt, -1);
+  {
+    int q2 = 0;
+    for (int I = 0; I < KI; ++I) { iv[I].sep0 = q2; for (int u : sep[I]) l2pos[u] = q2++; }
+    for (int u : border) l2pos[u] = q2++;
+  }
+  const int Nb2 = [&] { int s2 = 0; for (auto& v : sep) s2 += int(v.size()); return s2; }();
+  // the states among a separator's unknowns come first (ascending unknown index, states have the smallest indices of a phase)
+  std::vector<int> nstate0(KI, 0);
+  for (int I = 0; I < KI; ++I)
+    for (int u : sep[I]) nstate0[I] += sep_state[u];
+  std::vector<int> base(KI), nI(KI), nbL(KI);
+  int cur = 0;
+  for (int I = 0; I < KI; ++I) {
+    base[I] = cur;
+    nI[I] = int(iv[I].interior.size());
+    nbL[I] = int(sep[I].size()) + (iv[I].last ? 0 : nstate0[I + 1]) + p.nb;   // own separator, the NEXT interval's first-node states, border
+    for (int q = 0; q < nI[I]; ++q) { const int u = iv[I].interior[q]; C.loc[u] = q; p.pos[u] = cur + q; }
+    cur += nI[I] + nbL[I];
+  }
+  const int l2base = cur;
+  for (int u = 0; u < p.Nt; ++u)
+    if (ivl_of[u] < 0) { C.loc[u] = l2pos[u]; p.pos[u] = l2base + l2pos[u]; }
+  p.Nt_alloc = l2base + Nb2 + p.nb;
+  p.Nb = Nb2;   // reported by rpm_ipm_get_info as the banded part of level 2
+
+  // local border index of a separator / border unknown seen from interval I, or -1
+  auto lborder = [&](int I, int u) -> int {
+    if (sep_of[u] == I) return l2pos[u] - iv[I].sep0;
+    if (!iv[I].last && sep_of[u] == I + 1) return sep_state[u] ? int(sep[I].size()) + (l2pos[u] - iv[I + 1].sep0) : -1;
+    if (sep_of[u] < 0 && ivl_of[u] < 0) return int(sep[I].size()) + (iv[I].last ? 0 : nstate0[I + 1]) + (l2pos[u] - Nb2);
+    return -1;
+  };
+
+  // ---- half bandwidths from the entries
+  std::vector<int> bI(KI, 0);
+  int b2 = 0;
+  bool bad_pair = false;
+  auto reach = [&](int ua, int uc) {
+    const int Ia = ivl_of[ua], Ic = ivl_of[uc];
+    if (Ia >= 0 && Ic >= 0) {
+      if (Ia != Ic) { bad_pair = true; return; }
+      bI[Ia] = std::max(bI[Ia], std::abs(C.loc[ua] - C.loc[uc]));
+    } else if (Ia >= 0 || Ic >= 0) {
+      const int I = Ia >= 0 ? Ia : Ic, u = Ia >= 0 ? uc : ua;
+      if (lborder(I, u) < 0) bad_pair = true;
+    } else if (l2pos[ua] < Nb2 && l2pos[uc] < Nb2) {
+      b2 = std::max(b2, std::abs(l2pos[ua] - l2pos[uc]));
+    }
+  };
+  for (int k = 0; k < e.nnz_jac; ++k)
+    if (!p.fixed[e.jac_j[k]]) reach(p.nv + e.jac_i[k], e.jac_j[k]);
+  for (int k = 0; k < e.nnz_h; ++k)
+    if (!p.fixed[e.hes_i[k]] && !p.fixed[e.hes_j[k]]) reach(e.hes_i[k], e.hes_j[k]);
+  for (int s = 0; s < p.ns; ++s) reach(p.nv + p.slack_row[s], p.n + s);
+  if (bad_pair) return fail("nested dissection: an entry couples the interiors of two mesh intervals, or an interior to a separator that is not its own");
+  for (int I = 0; I < KI; ++I)   // the Schur complements couple an interval's separator with the next one's states
+    if (!iv[I].last) b2 = std::max(b2, int(sep[I].size()) + nstate0[I + 1] - 1);
+
+  // ---- sub-problem geometry and storage
+  long long koff = 0;
+  p.subs.clear();
+  for (int I = 0; I < KI; ++I) {
+    KktSubHost g;
+    g.Nb = nI[I];
+    g.nb = nbL[I];
+    g.Nt = g.Nb + g.nb;
+    g.b = std::max(bI[I], IPM_PLAN_W);
+    if (g.b > g.Nb - 1) g.b = std::max(g.Nb - 1, 0);
+    g.CS = g.b + 1 + g.nb;
+    g.CS += g.CS & 1;
+    g.koff = koff;
+    g.roff = base[I];
+    koff += (long long)g.Nt * g.CS;
+    p.subs.push_back(g);
+  }
+  {
+    KktSubHost g;
+    g.Nb = Nb2;
+    g.nb = p.nb;
+    g.Nt = Nb2 + p.nb;
+    g.b = std::max(b2, IPM_PLAN_W);
+    if (g.b > g.Nb - 1) g.b = std::max(g.Nb - 1, 0);
+    g.CS = g.b + 1 + g.nb;
+    g.CS += g.CS & 1;
+    g.koff = koff;
+    g.roff = l2base;
+    koff += (long long)g.Nt * g.CS;
+    p.subs.push_back(g);
+    p.b = g.b;
+    p.CS = g.CS;
+  }
+  p.storage_nd = koff;
+  if (p.storage_nd > INT32_MAX) return fail("KKT storage of one instance exceeds 2^31 doubles");
+  p.max_rows = 0;
+  p.max_factor_lds = 0;
+  for (const KktSubHost& g : p.subs) {
+    p.max_rows = std::max(p.max_rows, IPM_PLAN_W + g.b + g.nb);
+    p.max_factor_lds = std::max(p.max_factor_lds, factor_lds_of(g.b, g.nb));
+  }
+
+  // ---- storage slot of every entry
+  const KktSubHost& G2 = p.subs.back();
+  auto dst = [&](int ua, int uc) -> long long {
+    const int Ia = ivl_of[ua], Ic = ivl_of[uc];
+    if (Ia >= 0 && Ic >= 0) {
+      if (Ia != Ic) return -1;
+      int a = C.loc[ua], c = C.loc[uc];
+      if (a < c) std::swap(a, c);
+      if (a - c > p.subs[Ia].b) return -1;
+      return sub_at(p.subs[Ia], a, c);
+    }
+    if (Ia >= 0 || Ic >= 0) {
+      const int I = Ia >= 0 ? Ia : Ic, ui = Ia >= 0 ? ua : uc, uo = Ia >= 0 ? uc : ua;
+      const int lb = lborder(I, uo);
+      if (lb < 0) return -1;
+      return sub_at(p.subs[I], p.subs[I].Nb + lb, C.loc[ui]);
+    }
+    int a = l2pos[ua], c = l2pos[uc];
+    if (a < c) std::swap(a, c);
+    if (a < Nb2 && a - c > G2.b) return -1;
+    return sub_at(G2, a, c);
+  };
+  bool missing = false;
+  auto dst_i = [&](int ua, int uc) -> int {
+    const long long o = dst(ua, uc);
+    if (o < 0) missing = true;
+    return int(o);
+  };
+  p.jac_dst.assign(e.nnz_jac, -1);
+  p.hes_dst.assign(e.nnz_h, -1);
+  for (int k = 0; k < e.nnz_jac; ++k)
+    if (!p.fixed[e.jac_j[k]]) p.jac_dst[k] = dst_i(p.nv + e.jac_i[k], e.jac_j[k]);
+  for (int k = 0; k < e.nnz_h; ++k)
+    if (!p.fixed[e.hes_i[k]] && !p.fixed[e.hes_j[k]]) p.hes_dst[k] = dst_i(e.hes_i[k], e.hes_j[k]);
+  p.diag_dst.resize(p.Nt);
+  for (int u = 0; u < p.Nt; ++u) p.diag_dst[u] = dst_i(u, u);
+  p.slk_dst.resize(p.ns);
+  for (int s = 0; s < p.ns; ++s) p.slk_dst[s] = dst_i(p.nv + p.slack_row[s], p.n + s);
+  if (missing) return fail("nested dissection: an entry of the KKT matrix has no slot in the interval / separator layout");
+
+  // ---- corner gather (level-1 Schur complements -> level 2), right-hand-side gather and solution scatter, in interval order
+  {
+    std::vector<std::vector<int>> src_of;          // per distinct level-2 slot
+    std::vector<long long> slot_key;
+    std::vector<std::pair<long long, int>> all;    // (level-2 offset, level-1 offset), generated in interval order
+    std::vector<std::pair<int, int>> rall;         // (level-2 rhs position, work-space position)
+    for (int I = 0; I < KI; ++I) {
+      const KktSubHost& g = p.subs[I];
+      std::vector<int> l2_of(g.nb);                // level-2 position of local border index
+      int q = 0;
+      for (int u : sep[I]) l2_of[q++] = l2pos[u];
+      if (!iv[I].last)
+        for (int u : sep[I + 1])
+          if (sep_state[u]) l2_of[q++] = l2pos[u];
+      for (int j = 0; j < p.nb; ++j) l2_of[q++] = Nb2 + j;
+      for (int r = 0; r < g.nb; ++r) {
+        for (int c = 0; c <= r; ++c) all.emplace_back(sub_at(G2, l2_of[r], l2_of[c]), int(sub_at(g, g.Nb + r, g.Nb + c)));
+        rall.emplace_back(l2base + l2_of[r], g.roff + g.Nb + r);
+        p.gap_pos.push_back(g.roff + g.Nb + r);
+        p.rs_dst.push_back(g.roff + g.Nb + r);
+        p.rs_src.push_back(l2base + l2_of[r]);
+      }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+    p.cg_ptr.push_back(0);
+    for (size_t i = 0; i < all.size(); ++i) {
+      if (i == 0 || all[i].first != all[i - 1].first) {
+        if (i) p.cg_ptr.push_back(int(p.cg_src.size()));
+        p.cg_dst.push_back(int(all[i].first));
+      }
+      p.cg_src.push_back(all[i].second);
+    }
+    p.cg_ptr.push_back(int(p.cg_src.size()));
+    if (all.empty()) p.cg_ptr.assign(1, 0);
+    std::stable_sort(rall.begin(), rall.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+    p.rg_ptr.push_back(0);
+    for (size_t i = 0; i < rall.size(); ++i) {
+      if (i == 0 || rall[i].first != rall[i - 1].first) {
+        if (i) p.rg_ptr.push_back(int(p.rg_src.size()));
+        p.rg_dst.push_back(rall[i].first);
+      }
+      p.rg_src.push_back(rall[i].second);
+    }
+    p.rg_ptr.push_back(int(p.rg_src.size()));
+    if (rall.empty()) p.rg_ptr.assign(1, 0);
+  }
+  // Jacobian by column, entries of a column in COO order
+  p.jt_ptr.assign(p.n + 1, 0);
+  for (int k = 0; k < e.nnz_jac; ++k) ++p.jt_ptr[e.jac_j[k] + 1];
+  for (int i = 0; i < p.n; ++i) p.jt_ptr[i + 1] += p.jt_ptr[i];
+  p.jt_ent.resize(e.nnz_jac);
+  p.jt_row.resize(e.nnz_jac);
+  std::vector<int> fill(p.jt_ptr.begin(), p.jt_ptr.end() - 1);
+  for (int k = 0; k < e.nnz_jac; ++k) {
+    const int q = fill[e.jac_j[k]]++;
+    p.jt_ent[q] = k;
+    p.jt_row[q] = e.jac_i[k];
+  }
+  ipm_plan_group_hessian(p);
+  // keep what ipm_plan_offset needs
+  p.nd_ivl = ivl_of;
+  p.nd_loc = C.loc;
+  p.nd_sep = sep_of;
+  p.nd_sep0.resize(KI);
+  p.nd_nsep.resize(KI);
+  p.nd_last.resize(KI);
+  p.nd_nstate0 = nstate0;
+  p.nd_sep_state = sep_state;
+  for (int I = 0; I < KI; ++I) { p.nd_sep0[I] = iv[I].sep0; p.nd_nsep[I] = int(sep[I].size()); p.nd_last[I] = iv[I].last ? 1 : 0; }
+  return RPM_OK;
+}
+
+long long ipm_plan_offset(const IpmPlan& p, int ua, int uc) {
+  if (!p.nd) {
+    int a = p.pos[ua], c = p.pos[uc];
+    if (a < c) std::swap(a, c);
+    if (a < p.Nb && a - c > p.b) return -1;
+    return p.at(a, c);
+  }
+  const KktSubHost& G2 = p.subs.back();
+  const int Nb2 = G2.Nb;
+  auto lborder = [&](int I, int u) -> int {
+    if (p.nd_sep[u] == I) return p.nd_loc[u] - p.nd_sep0[I];
+    if (!p.nd_last[I] && p.nd_sep[u] == I + 1) return p.nd_sep_state[u] ? p.nd_nsep[I] + (p.nd_loc[u] - p.nd_sep0[I + 1]) : -1;
+    if (p.nd_sep[u] < 0 && p.nd_ivl[u] < 0) return p.nd_nsep[I] + (p.nd_last[I] ? 0 : p.nd_nstate0[I + 1]) + (p.nd_loc[u] - Nb2);
+    return -1;
+  };
+  const int Ia = p.nd_ivl[ua], Ic = p.nd_ivl[uc];
+  if (Ia >= 0 && Ic >= 0) {
+    if (Ia != Ic) return -1;
+    int a = p.nd_loc[ua], c = p.nd_loc[uc];
+    if (a < c) std::swap(a, c);
+    if (a - c > p.subs[Ia].b) return -1;
+    return sub_at(p.subs[Ia], a, c);
+  }
+  if (Ia >= 0 || Ic >= 0) {
+    const int I = Ia >= 0 ? Ia : Ic, ui = Ia >= 0 ? ua : uc, uo = Ia >= 0 ? uc : ua;
+    const int lb = lborder(I, uo);
+    if (lb < 0) return -1;
+    return sub_at(p.subs[I], p.subs[I].Nb + lb, p.nd_loc[ui]);
+  }
+  int a = p.nd_loc[ua], c = p.nd_loc[uc];
+  if (a < c) std::swap(a, c);
+  if (a < Nb2 && a - c > G2.b) return -1;
+  return sub_at(G2, a, c);
 }
 
 }  // namespace rpm

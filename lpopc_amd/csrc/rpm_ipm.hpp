@@ -19,6 +19,15 @@
 
 namespace rpm {
 
+// One dense-ish sub-problem of the factorisation in band + border storage: element (i, j), i >= j, of its lower triangle
+// sits at koff + j * CS + (i < Nb ? i - j : b + 1 + i - Nb) of the instance's KKT storage; its right-hand side is the
+// slice [roff, roff + Nt) of the instance's vector.
+struct KktSubHost {
+  int Nt, Nb, nb, b, CS;
+  long long koff;
+  int roff;
+};
+
 struct IpmPlan {
   int n = 0, m = 0, ns = 0, nv = 0;   // variables, rows, slacks (one per inequality row), nv = n + ns
   int Nt = 0, Nb = 0, nb = 0;         // KKT order, banded part, border
@@ -31,13 +40,41 @@ struct IpmPlan {
   std::vector<int> diag_dst;          // Nt: offset of every unknown's diagonal entry
   std::vector<int> slk_dst;           // ns: offset of the (row, slack) entry (value -1)
   std::vector<int> jt_ptr, jt_ent, jt_row;   // Jacobian by column (deterministic J^T lambda)
-  long long storage() const { return (long long)Nt * CS; }
+  std::vector<int> hg_ptr, hg_src, hg_dst;   // Hessian by storage slot: K[hg_dst[i]] += (sum of hess[hg_src[...]] in COO order) — duplicates
+                                             // (I-part / E-part, LpHessian.cpp:598) are summed in a fixed order, not by racing atomics
+  // ---- nested dissection by mesh interval (nd = 1) ------------------------------------------------------------------
+  // The unknowns of a mesh interval — states of its nodes but the first, controls, slacks, defect / path multipliers —
+  // couple only to each other, to the states at the interval's first node ("separator"), to the separator of the NEXT
+  // interval (last column of the interval's D block, Core/RPMGenerator.cpp:150-165) and to the border.  Level 1: every
+  // interval is a band + border sub-problem of its own (border = its two separators + the global border; the first node's
+  // controls, slacks and multipliers are ordered last inside it, see rpm_ipm.cpp), factored up to
+  // its corner by a workgroup of its own; the corners are Schur complements that add up (in a fixed order) into level 2:
+  // the separators in time order (block tridiagonal, blocks of nx) + the global border, one more band + border problem.
+  // A quasi-definite matrix has an LDL^T under every symmetric permutation (Vanderbei 1995), so this ordering needs no
+  // pivoting either, and the signs of all the D's still give the inertia.
+  int nd = 0;
+  int Nt_alloc = 0;                   // length of the right-hand-side vector: Nt plus the level-1 border work spaces
+  long long storage_nd = 0;           // doubles of KKT storage per instance (level-1 blocks, then level 2)
+  std::vector<KktSubHost> subs;       // level-1 sub-problems, then ONE level-2 entry (the last)
+  std::vector<int> cg_ptr, cg_src;    // corner gather: level-2 storage offset cg_dst[i] += sum of K[cg_src[cg_ptr[i] .. cg_ptr[i+1])]
+  std::vector<int> cg_dst;
+  std::vector<int> rg_ptr, rg_src;    // right-hand-side gather: rhs[rg_dst[i]] += sum of rhs[rg_src[...]]  (level-1 border work spaces)
+  std::vector<int> rg_dst;
+  std::vector<int> rs_dst, rs_src;    // solution scatter: rhs[rs_dst[i]] = rhs[rs_src[i]]
+  std::vector<int> gap_pos;           // every position of a level-1 border work space (zeroed before the forward sweep)
+  std::vector<int> nd_ivl, nd_loc, nd_sep, nd_sep0, nd_nsep, nd_last, nd_nstate0, nd_sep_state;   // classification kept for ipm_plan_offset
+  int max_rows = 0;                   // largest 16 + b + nb over all sub-problems (rows of a block column)
+  size_t max_factor_lds = 0;
+  long long storage() const { return nd ? storage_nd : (long long)Nt * CS; }
   long long at(int pa, int pb) const {        // pa >= pb
     return (long long)pb * CS + (pa < Nb ? pa - pb : b + 1 + pa - Nb);
   }
 };
 
 // rpm_ipm.cpp (host only): ordering, band width and the scatter maps from the engine's layout
-int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why);
+int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why, int nested = 0);
+void ipm_plan_group_hessian(IpmPlan& p);   // hg_* from hes_dst
+// storage offset of the entry between unknowns ua, uc ([0,n) x, [n,nv) slacks, [nv,nv+m) multipliers); -1 if the layout has no slot for it
+long long ipm_plan_offset(const IpmPlan& p, int ua, int uc);
 
 }  // namespace rpm

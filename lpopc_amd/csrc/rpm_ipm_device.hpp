@@ -36,11 +36,25 @@ struct IpmInst {
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 
+// band + border storage of one instance (rpm_ipm.hpp): element (i, j), i >= j
+struct KktGeom {
+  int Nt, Nb, nb, b, CS;
+  __device__ size_t at(int i, int j) const { return size_t(j) * CS + (i < Nb ? i - j : b + 1 + i - Nb); }
+};
+// one sub-problem of the factorisation (rpm_ipm.hpp KktSubHost): its geometry, where its block starts inside an instance's
+// KKT storage, where its right-hand side starts inside an instance's vector
+struct KktSub {
+  KktGeom g;
+  int roff;
+  long long koff;
+};
 struct IpmDev {
   int B, n, m, ns, nv, Nt, Nb, nb, b, CS, nnz_jac, nnz_h;
   long long sg, sv, kstride;
   // plan tables
   const int *pos, *row_slack, *slack_row, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
+  const int *hg_ptr, *hg_src, *hg_dst;   // Hessian entries grouped by storage slot
+  int n_hg;
   const double *gl, *gu;
   // per-instance state
   double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
@@ -51,13 +65,19 @@ struct IpmDev {
   IpmInst* inst;
   int* cnt;     // [0] running, [1] to refactor, [2] line searches pending
   IpmOpts o;
+  // factorisation sub-problems: one (the whole band + border matrix) or, with nested dissection, n_l1 interval blocks
+  // followed by the separator system; pivot signs of every sub-problem land in piv[(instance * n_sub + sub) * 3 + {+,-,bad}]
+  const KktSub* subs;
+  int n_sub, n_l1;          // n_sub = n_l1 + 1; n_l1 = 0: no dissection
+  int* piv;
+  const int *cg_ptr, *cg_src, *cg_dst;   // corner gather (level-1 Schur complements into level 2)
+  const int *rg_ptr, *rg_src, *rg_dst;   // right-hand-side gather
+  const int *rs_dst, *rs_src;            // solution scatter into the level-1 border work spaces
+  const int* gap_pos;                    // positions of those work spaces (zeroed before the forward sweep)
+  int n_cg, n_rg, n_rs, n_gap;
+  int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
 };
 
-// band + border storage of one instance (rpm_ipm.hpp): element (i, j), i >= j
-struct KktGeom {
-  int Nt, Nb, nb, b, CS;
-  __device__ size_t at(int i, int j) const { return size_t(j) * CS + (i < Nb ? i - j : b + 1 + i - Nb); }
-};
 constexpr int IPM_MT = 8;   // most 16-row tiles per wave of the factorisation: block columns of up to 4 x 8 x 16 = 512 rows
 
 // launchers (rpm_ipm_kernels.hip); all asynchronous on `st`
@@ -74,7 +94,9 @@ void ipm_launch_update(const IpmDev& D, hipStream_t st);
 // factorisation / substitution of every running instance; tiles_per_wave 4 or IPM_MT
 size_t kkt_factor_lds_bytes(const IpmPlan& p);
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes);
-void kkt_launch_factor(const IpmDev& D, const KktGeom& G, int tiles_per_wave, size_t lds_bytes, hipStream_t st);
-void kkt_launch_solve(const IpmDev& D, const KktGeom& G, int check_status, hipStream_t st);
+// factor every running instance that asks for it / solve in place in D.rhs: the band + border matrix, or level 1 ->
+// corner gather -> level 2 and forward -> gather -> level 2 -> scatter -> backward with nested dissection
+void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hipStream_t st);
+void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st);
 
 }  // namespace rpm

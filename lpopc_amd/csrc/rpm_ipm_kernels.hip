@@ -238,7 +238,7 @@ __global__ void ipm_zero_kernel(IpmDev D) {
   const IpmInst& S = D.inst[bi];
   if (S.status != 0 || !S.refactor) return;
   double2* K = reinterpret_cast<double2*>(D.K + size_t(bi) * D.kstride);
-  const long long n2 = (long long)D.Nt * D.CS / 2;
+  const long long n2 = D.kstride / 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x)
     K[i] = make_double2(0.0, 0.0);
 }
@@ -251,9 +251,12 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool resto = S.mode == 1;      // restoration: W = zeta D_R^2 + mu / s^2, -I in the constraint block, no Hessian
-  if (!resto)
-    for (int k = t0; k < D.nnz_h; k += stride)
-      if (D.hes_dst[k] >= 0) unsafeAtomicAdd(&K[D.hes_dst[k]], D.hess[size_t(bi) * D.nnz_h + k]);
+  if (!resto)   // duplicates of a slot (I-part / E-part of the reference's COO) are summed in COO order: bit-reproducible.  The
+    for (int i = t0; i < D.n_hg; i += stride) {   // slot may also take the diagonal term below: two atomic adds onto zero commute
+      double acc = 0.0;
+      for (int j = D.hg_ptr[i]; j < D.hg_ptr[i + 1]; ++j) acc += D.hess[size_t(bi) * D.nnz_h + D.hg_src[j]];
+      unsafeAtomicAdd(&K[D.hg_dst[i]], acc);
+    }
   for (int k = t0; k < D.nnz_jac; k += stride)
     if (D.jac_dst[k] >= 0) K[D.jac_dst[k]] = D.jac[size_t(bi) * D.sv + k];
   for (int s = t0; s < D.ns; s += stride) K[D.slk_dst[s]] = -1.0;
@@ -315,14 +318,19 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
 #ifndef IPM_LB
 #define IPM_LB 3   // waves per SIMD the 4-tile factorisation is compiled for
 #endif
-template <int MT>           // 16-row tiles per wave: 4 (block columns of up to 256 rows, 4 workgroups per CU) or 8
-__global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(double* Kall, long long kstride, KktGeom G, IpmInst* inst) {
+template <int MT>           // 16-row tiles per wave: 4 (block columns of up to 256 rows, 3 workgroups per CU), 6 (384 rows, 2 per CU: at 3 it spills 91 VGPRs) or 8 (512 rows)
+__global__ __launch_bounds__(256, MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1)) void kkt_factor_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0,
+                                                                               int n_here, int n_sub, IpmInst* inst, int* piv, int partial) {
+  // workgroup = (instance, sub-problem sub0 + s).  partial: nested dissection level 1 — eliminate the band part only and
+  // leave the Schur complement of the border x border corner, unfactored, in the corner's storage.
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W;
-  const int bi = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
-  IpmInst& S = inst[bi];
+  const int bi = blockIdx.x / n_here, sidx = sub0 + int(blockIdx.x) % n_here, t = threadIdx.x, nt = blockDim.x;
+  const IpmInst& S = inst[bi];
   if (S.status != 0 || !S.refactor) return;
-  double* K = Kall + size_t(bi) * kstride;
+  const KktSub sub = subs[sidx];
+  const KktGeom G = sub.g;
+  double* K = Kall + size_t(bi) * kstride + sub.koff;
   extern __shared__ double lds[];
   double* T = lds;                              // (b + 8) x W
   double* Dg = T + size_t(G.b + 8) * W;         // W x (W + 1)
@@ -487,6 +495,18 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(d
     IPM_TICK(4);
     J0 = J1;
   }
+  if (partial) {                                            // level 1 of the nested dissection: hand the corner over as it is
+    for (int idx = t; idx < nb * nb; idx += nt) {
+      const int r = idx / nb, c = idx % nb;
+      if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[idx];
+    }
+    if (npos) atomicAdd(&cnt[0], npos);
+    if (nneg) atomicAdd(&cnt[1], nneg);
+    if (nbad) atomicAdd(&cnt[2], nbad);
+    __syncthreads();
+    if (t < 3) piv[(size_t(bi) * n_sub + sidx) * 3 + t] = cnt[t];
+    return;
+  }
   for (int k = 0; k < nb; ++k) {                            // the corner, unblocked, in LDS
     __syncthreads();
     const double dk = C[k * nb + k];
@@ -531,25 +551,30 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : 1) void kkt_factor_kernel(d
   if (nbad) atomicAdd(&cnt[2], nbad);
   __syncthreads();
   IPM_TICK(5);
-  if (t == 0) {
-    S.npos = cnt[0]; S.nneg = cnt[1]; S.nbad = cnt[2];
+  if (t < 3) piv[(size_t(bi) * n_sub + sidx) * 3 + t] = cnt[t];
 #ifdef IPM_TIMING
-    for (int i = 0; i < 6; ++i) S.dbg[i] = tc[i];
+  if (t == 0)
+    for (int i = 0; i < 6; ++i) inst[bi].dbg[i] = tc[i];
 #endif
-  }
 }
 
 // L y = r, then x = L^-T D^-1 y, in place in rhs: one workgroup per instance, IPM_W columns per step.  The diagonal
 // blocks hold L11^-1, so a step's own 16 unknowns are 16 parallel dot products.  The right-hand side lives in LDS when it
 // fits (RL); the diagonal block and each thread's panel row of the NEXT step are fetched while the current one is worked.
 template <bool RL>
-__global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long long kstride, KktGeom G, const IpmInst* inst,
-                                                        double* rhs_all, int check_status) {
+__global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
+                                                        const IpmInst* inst, double* rhs_all, long long rhs_stride, int check_status,
+                                                        int phase) {
+  // phase 0: forward and backward over all blocks; nested dissection level 1: phase 1 = forward over the band blocks only
+  // (the border work space receives -L_border y, this interval's contribution to the separator system's right-hand side),
+  // phase 2 = backward over the band blocks only (the work space then holds the separator / border solution)
   constexpr int W = IPM_W;
-  const int bi = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const int bi = blockIdx.x / n_here, t = threadIdx.x, nt = blockDim.x;
   if (check_status && inst[bi].status != 0) return;
-  const double* K = Kall + size_t(bi) * kstride;
-  double* rg = rhs_all + size_t(bi) * G.Nt;
+  const KktSub sub = subs[sub0 + int(blockIdx.x) % n_here];
+  const KktGeom G = sub.g;
+  const double* K = Kall + size_t(bi) * kstride + sub.koff;
+  double* rg = rhs_all + size_t(bi) * rhs_stride + sub.roff;
   extern __shared__ double rsh[];
   double* r = RL ? rsh : rg;
   __shared__ double Dg[W * (W + 1)], ys[W], zs[W], red[4][W];     // Dg: d on the diagonal, L11^-1 below it
@@ -578,8 +603,9 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       l[c] = (row >= 0 && c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0;
   };
   double dg, l[W];
-  fetch(0, dg, l);
-  for (int blk = 0; blk < nblk; ++blk) {
+  const int fwd_end = phase == 1 ? nbb : (phase == 2 ? 0 : nblk), bwd_begin = phase == 2 ? nbb : (phase == 1 ? 0 : nblk);
+  if (fwd_end > 0) fetch(0, dg, l);
+  for (int blk = 0; blk < fwd_end; ++blk) {
     const Blk B = blk_of(blk);
     if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     if (t < W) zs[t] = t < B.w ? r[B.J0 + t] : 0.0;
@@ -606,8 +632,8 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     fetch(blk + 1, dg, l);      // in flight across the barrier and the next step's diagonal solve
     __syncthreads();
   }
-  fetch(nblk - 1, dg, l);
-  for (int blk = nblk - 1; blk >= 0; --blk) {
+  if (bwd_begin > 0) fetch(bwd_begin - 1, dg, l);
+  for (int blk = bwd_begin - 1; blk >= 0; --blk) {
     const Blk B = blk_of(blk);
     if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     double p[W];
@@ -653,6 +679,14 @@ __global__ void ipm_inertia_kernel(IpmDev D) {
   IpmInst& S = D.inst[bi];
   if (S.status != 0 || !S.refactor) return;
   const IpmOpts& o = D.o;
+  {   // pivot signs of all the sub-problems of this instance (one without dissection)
+    int np = 0, nn = 0, nz = 0;
+    for (int s2 = 0; s2 < D.n_sub; ++s2) {
+      const int* q = D.piv + (size_t(bi) * D.n_sub + s2) * 3;
+      np += q[0]; nn += q[1]; nz += q[2];
+    }
+    S.npos = np; S.nneg = nn; S.nbad = nz;
+  }
   if (S.npos == D.nv && S.nbad == 0) {
     S.refactor = 0;
     if (S.delta_w > 0) S.delta_w_last = S.delta_w;
@@ -934,27 +968,92 @@ void ipm_launch_update(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_update_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
 }
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
+  if (p.nd) return p.max_factor_lds;
   return (size_t(p.b + 8) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
           size_t(p.nb) * p.nb) * sizeof(double);
 }
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;
   return hipFuncSetAttribute(tiles_per_wave == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>)
-                                                 : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
+                             : tiles_per_wave == 6 ? reinterpret_cast<const void*>(kkt_factor_kernel<6>)
+                                                   : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
 }
-void kkt_launch_factor(const IpmDev& D, const KktGeom& G, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
-  if (tiles_per_wave == 4)
-    hipLaunchKernelGGL(kkt_factor_kernel<4>, dim3(unsigned(D.B)), dim3(256), lds_bytes, st, D.K, D.kstride, G, D.inst);
-  else
-    hipLaunchKernelGGL(kkt_factor_kernel<IPM_MT>, dim3(unsigned(D.B)), dim3(256), lds_bytes, st, D.K, D.kstride, G, D.inst);
+// ---- nested dissection glue: sums in a fixed (interval) order, so the factorisation stays deterministic ----------------------
+// K[dst[i]] += sum_j K[src[j]], j in [ptr[i], ptr[i+1]): the level-1 Schur complements into the separator system
+__global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int* __restrict__ ptr, const int* __restrict__ src,
+                                      const int* __restrict__ dst, int n, const IpmInst* inst, int need_refactor) {
+  const int bi = blockIdx.y;
+  if (inst[bi].status != 0 || (need_refactor && !inst[bi].refactor)) return;
+  double* K = Kall + size_t(bi) * kstride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double acc = K[dst[i]];
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) acc += K[src[j]];
+    K[dst[i]] = acc;
+  }
 }
-void kkt_launch_solve(const IpmDev& D, const KktGeom& G, int check_status, hipStream_t st) {
-  if (size_t(D.Nt) * sizeof(double) <= 48 * 1024)
-    hipLaunchKernelGGL(kkt_solve_kernel<true>, dim3(unsigned(D.B)), dim3(256), size_t(D.Nt) * sizeof(double), st, D.K, D.kstride, G,
-                       D.inst, D.rhs, check_status);
+// mode 0: v[pos[i]] = 0;  mode 1: v[dst[i]] = v[src[i]]
+__global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __restrict__ dst, const int* __restrict__ src, int n, int mode,
+                               const IpmInst* inst, int check_status) {
+  const int bi = blockIdx.y;
+  if (check_status && inst[bi].status != 0) return;
+  double* v = vall + size_t(bi) * vstride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[dst[i]] = mode ? v[src[i]] : 0.0;
+}
+
+static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partial, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
+  const dim3 grid(unsigned(D.B) * unsigned(n_here));
+  if (tiles_per_wave == 4)
+    hipLaunchKernelGGL(kkt_factor_kernel<4>, grid, dim3(256), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
+  else if (tiles_per_wave == 6)
+    hipLaunchKernelGGL(kkt_factor_kernel<6>, grid, dim3(256), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
   else
-    hipLaunchKernelGGL(kkt_solve_kernel<false>, dim3(unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, G, D.inst, D.rhs, check_status);
+    hipLaunchKernelGGL(kkt_factor_kernel<IPM_MT>, grid, dim3(256), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv,
+                       partial);
+}
+static void launch_solve_subs(const IpmDev& D, int sub0, int n_here, int phase, int check_status, hipStream_t st) {
+  const dim3 grid(unsigned(D.B) * unsigned(n_here));
+  if (size_t(D.max_sub_nt) * sizeof(double) <= 48 * 1024)
+    hipLaunchKernelGGL(kkt_solve_kernel<true>, grid, dim3(256), size_t(D.max_sub_nt) * sizeof(double), st, D.K, D.kstride, D.subs, sub0, n_here,
+                       D.inst, D.rhs, (long long)D.Nt, check_status, phase);
+  else
+    hipLaunchKernelGGL(kkt_solve_kernel<false>, grid, dim3(256), 0, st, D.K, D.kstride, D.subs, sub0, n_here, D.inst, D.rhs, (long long)D.Nt,
+                       check_status, phase);
+}
+void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
+  if (D.n_l1 == 0) {
+    launch_factor_subs(D, 0, 1, 0, tiles_per_wave, lds_bytes, st);
+    return;
+  }
+  launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);                 // every interval up to its corner
+  if (D.n_cg) {
+    const unsigned blocks = unsigned(std::max(1, std::min(1024, (D.n_cg + 255) / 256)));
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, D.cg_ptr, D.cg_src, D.cg_dst,
+                       D.n_cg, D.inst, 1);
+  }
+  launch_factor_subs(D, D.n_l1, 1, 0, tiles_per_wave, lds_bytes, st);                 // separators + border
+}
+void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
+  if (D.n_l1 == 0) {
+    launch_solve_subs(D, 0, 1, 0, check_status, st);
+    return;
+  }
+  auto vec = [&](const int* dst, const int* src, int n, int mode) {
+    if (!n) return;
+    const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
+    hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, dst, src, n, mode, D.inst,
+                       check_status);
+  };
+  vec(D.gap_pos, nullptr, D.n_gap, 0);                                                 // border work spaces start at zero
+  launch_solve_subs(D, 0, D.n_l1, 1, check_status, st);                                // forward, every interval
+  if (D.n_rg) {
+    const unsigned blocks = unsigned(std::max(1, std::min(256, (D.n_rg + 255) / 256)));
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, D.rg_ptr, D.rg_src, D.rg_dst,
+                       D.n_rg, D.inst, 0);
+  }
+  launch_solve_subs(D, D.n_l1, 1, 0, check_status, st);                                // separators + border
+  vec(D.rs_dst, D.rs_src, D.n_rs, 1);                                                  // their solution into the work spaces
+  launch_solve_subs(D, 0, D.n_l1, 2, check_status, st);                                // backward, every interval
 }
 
 }  // namespace rpm

@@ -63,7 +63,6 @@ int ipm_alloc_c(rpm_ipm* h, const T** dst, const std::vector<T>& src) {
   *dst = p;
   return rc;
 }
-KktGeom geom_of(const IpmPlan& p) { return KktGeom{p.Nt, p.Nb, p.nb, p.b, p.CS}; }
 
 int fetch_counts(rpm_ipm* h, hipStream_t st) {
   IPM_TRY(h, hipMemcpyAsync(h->h_cnt, h->D.cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -79,8 +78,8 @@ int launch_check(rpm_ipm* h, const char* what) {
   return RPM_OK;
 }
 int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve, int check_status) {
-  if (factor) kkt_launch_factor(h->D, geom_of(h->plan), h->factor_mt, h->factor_lds, st);
-  if (solve) kkt_launch_solve(h->D, geom_of(h->plan), check_status, st);
+  if (factor) kkt_launch_factor(h->D, h->factor_mt, h->factor_lds, st);
+  if (solve) kkt_launch_solve(h->D, check_status, st);
   return launch_check(h, "kkt kernels");
 }
 }  // namespace
@@ -111,7 +110,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   e.ipm_attached += 1;   // freezes the engine's instance strides (rpm_set_option "instance_align"); released by ~rpm_ipm
   h->attached = true;
   std::string why;
-  rc = build_ipm_plan(e, h->plan, &why);
+  rc = build_ipm_plan(e, h->plan, &why, e.opt_ipm_nested != 0);
+  if (rc && e.opt_ipm_nested == -1) rc = build_ipm_plan(e, h->plan, &why, 0);   // automatic: no interval structure to dissect -> one band
   if (rc) {
     e.err = "rpm_ipm_create: " + why;
     delete h;
@@ -120,7 +120,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   const IpmPlan& p = h->plan;
   IpmDev& D = h->D;
   const size_t B = size_t(e.n_instances);
-  D.B = int(B); D.n = p.n; D.m = p.m; D.ns = p.ns; D.nv = p.nv; D.Nt = p.Nt; D.Nb = p.Nb; D.nb = p.nb; D.b = p.b; D.CS = p.CS;
+  D.B = int(B); D.n = p.n; D.m = p.m; D.ns = p.ns; D.nv = p.nv; D.Nt = p.Nt_alloc; D.Nb = p.Nb; D.nb = p.nb; D.b = p.b; D.CS = p.CS;
   D.nnz_jac = e.nnz_jac; D.nnz_h = e.nnz_h;
   D.sg = e.stride_g(); D.sv = e.stride_values(); D.kstride = p.storage();
   auto fail = [&](int code) { e.err = "rpm_ipm_create: " + h->err; delete h; return code; };
@@ -129,17 +129,37 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc_c(h, &D.jac_dst, p.jac_dst)); A_(ipm_alloc_c(h, &D.hes_dst, p.hes_dst));
   A_(ipm_alloc_c(h, &D.diag_dst, p.diag_dst)); A_(ipm_alloc_c(h, &D.slk_dst, p.slk_dst)); A_(ipm_alloc_c(h, &D.jt_ptr, p.jt_ptr));
   A_(ipm_alloc_c(h, &D.jt_ent, p.jt_ent)); A_(ipm_alloc_c(h, &D.jt_row, p.jt_row));
+  A_(ipm_alloc_c(h, &D.hg_ptr, p.hg_ptr)); A_(ipm_alloc_c(h, &D.hg_src, p.hg_src)); A_(ipm_alloc_c(h, &D.hg_dst, p.hg_dst));
+  D.n_hg = int(p.hg_dst.size());
   A_(ipm_alloc_c(h, &D.gl, e.gl)); A_(ipm_alloc_c(h, &D.gu, e.gu));
   A_(ipm_alloc(h, &D.v, B * p.nv)); A_(ipm_alloc(h, &D.vl, B * p.nv)); A_(ipm_alloc(h, &D.vu, B * p.nv));
   A_(ipm_alloc(h, &D.zL, B * p.nv)); A_(ipm_alloc(h, &D.zU, B * p.nv)); A_(ipm_alloc(h, &D.lam, B * p.m));
   A_(ipm_alloc(h, &D.dv, B * p.nv)); A_(ipm_alloc(h, &D.dlam, B * p.m)); A_(ipm_alloc(h, &D.dzL, B * p.nv));
   A_(ipm_alloc(h, &D.dzU, B * p.nv)); A_(ipm_alloc(h, &D.glag, B * p.nv)); A_(ipm_alloc(h, &D.c, B * p.m));
-  A_(ipm_alloc(h, &D.rhs, B * p.Nt)); A_(ipm_alloc(h, &D.K, B * size_t(p.storage()))); A_(ipm_alloc(h, &D.filt, B * 2 * IPM_FMAX));
+  A_(ipm_alloc(h, &D.rhs, B * size_t(p.Nt_alloc))); A_(ipm_alloc(h, &D.K, B * size_t(p.storage()))); A_(ipm_alloc(h, &D.filt, B * 2 * IPM_FMAX));
   A_(ipm_alloc(h, &D.xe, B * p.n)); A_(ipm_alloc(h, &D.xt, B * p.n)); A_(ipm_alloc(h, &D.grad, B * p.n));
   A_(ipm_alloc(h, &D.g, B * size_t(D.sg))); A_(ipm_alloc(h, &D.jac, B * size_t(D.sv))); A_(ipm_alloc(h, &D.hess, B * size_t(e.nnz_h)));
   A_(ipm_alloc(h, &D.obj, B)); A_(ipm_alloc(h, &D.gt, B * size_t(D.sg))); A_(ipm_alloc(h, &D.objt, B));
   A_(ipm_alloc(h, &D.inst, B)); A_(ipm_alloc(h, &D.cnt, size_t(4)));
   A_(ipm_alloc(h, &D.vR, B * p.nv)); A_(ipm_alloc(h, &D.dr2, B * p.nv));
+  {   // factorisation sub-problems: the whole band + border matrix, or the interval blocks followed by the separator system
+    std::vector<KktSub> subs;
+    if (p.nd) {
+      for (const KktSubHost& g : p.subs) subs.push_back(KktSub{KktGeom{g.Nt, g.Nb, g.nb, g.b, g.CS}, g.roff, g.koff});
+    } else {
+      subs.push_back(KktSub{KktGeom{p.Nt, p.Nb, p.nb, p.b, p.CS}, 0, 0});
+    }
+    D.n_sub = int(subs.size());
+    D.n_l1 = p.nd ? D.n_sub - 1 : 0;
+    D.max_sub_nt = 0;
+    for (const KktSub& q : subs) D.max_sub_nt = std::max(D.max_sub_nt, q.g.Nt);
+    A_(ipm_alloc_c(h, &D.subs, subs));
+    A_(ipm_alloc(h, &D.piv, B * subs.size() * 3));
+    A_(ipm_alloc_c(h, &D.cg_ptr, p.cg_ptr)); A_(ipm_alloc_c(h, &D.cg_src, p.cg_src)); A_(ipm_alloc_c(h, &D.cg_dst, p.cg_dst));
+    A_(ipm_alloc_c(h, &D.rg_ptr, p.rg_ptr)); A_(ipm_alloc_c(h, &D.rg_src, p.rg_src)); A_(ipm_alloc_c(h, &D.rg_dst, p.rg_dst));
+    A_(ipm_alloc_c(h, &D.rs_dst, p.rs_dst)); A_(ipm_alloc_c(h, &D.rs_src, p.rs_src)); A_(ipm_alloc_c(h, &D.gap_pos, p.gap_pos));
+    D.n_cg = int(p.cg_dst.size()); D.n_rg = int(p.rg_dst.size()); D.n_rs = int(p.rs_dst.size()); D.n_gap = int(p.gap_pos.size());
+  }
 #undef A_
   if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt), 4 * sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc"; return fail(RPM_E_DEVICE); }
   // variable bounds of every instance default to the engine's
@@ -150,9 +170,9 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     if (hipMemcpy(D.vl, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(D.vu, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy"; return fail(RPM_E_DEVICE); }
   }
-  h->factor_mt = IPM_W + p.b + p.nb <= 256 ? 4 : IPM_MT;
-  if (IPM_W + p.b + p.nb > 4 * IPM_MT * 16) {
-    h->err = "band + border of " + std::to_string(p.b + p.nb) + " rows exceeds the factorisation's 512 rows per block column";
+  h->factor_mt = p.max_rows <= 256 ? 4 : (p.max_rows <= 384 ? 6 : IPM_MT);
+  if (p.max_rows > 4 * IPM_MT * 16) {
+    h->err = "band + border of " + std::to_string(p.max_rows - IPM_W) + " rows exceeds the factorisation's 512 rows per block column";
     return fail(RPM_E_UNSUPPORTED);
   }
   h->factor_lds = kkt_factor_lds_bytes(p);
@@ -210,6 +230,23 @@ int rpm_ipm_get_info(rpm_ipm* h, int* kkt_order, int* band_order, int* half_band
   if (border) *border = h->plan.nb;
   if (storage_doubles) *storage_doubles = h->plan.storage();
   if (n_slacks) *n_slacks = h->plan.ns;
+  return RPM_OK;
+}
+
+/* the factorisation's sub-problems (one without nested dissection; the interval blocks followed by the separator system
+ * with it): 5 ints each — order, banded part, border, half bandwidth, doubles per stored column */
+int rpm_ipm_get_subproblems(rpm_ipm* h, int capacity, int* geom, int* n_sub) {
+  if (!h || !n_sub) return RPM_E_INVALID;
+  const IpmPlan& p = h->plan;
+  const int n = p.nd ? int(p.subs.size()) : 1;
+  *n_sub = n;
+  if (!geom) return RPM_OK;
+  if (capacity < n) return RPM_E_INVALID;
+  for (int i = 0; i < n; ++i) {
+    int* g = geom + 5 * i;
+    if (p.nd) { g[0] = p.subs[i].Nt; g[1] = p.subs[i].Nb; g[2] = p.subs[i].nb; g[3] = p.subs[i].b; g[4] = p.subs[i].CS; }
+    else { g[0] = p.Nt; g[1] = p.Nb; g[2] = p.nb; g[3] = p.b; g[4] = p.CS; }
+  }
   return RPM_OK;
 }
 
@@ -287,10 +324,12 @@ int rpm_ipm_debug_solve(rpm_ipm* h, const double* k_storage, const double* rhs, 
   std::vector<IpmInst> inst(D.B);
   for (auto& s : inst) { s = IpmInst{}; s.refactor = 1; }
   IPM_TRY(h, hipMemcpy(D.inst, inst.data(), inst.size() * sizeof(IpmInst), hipMemcpyHostToDevice));
+  if (p.nd) { h->err = "rpm_ipm_debug_solve takes the band + border storage; with nested dissection use rpm_ipm_debug_solve_dense"; return RPM_E_UNSUPPORTED; }
   IPM_TRY(h, hipMemcpy(D.K, k_storage, size_t(D.B) * p.storage() * sizeof(double), hipMemcpyHostToDevice));
   IPM_TRY(h, hipMemcpy(D.rhs, rhs, size_t(D.B) * p.Nt * sizeof(double), hipMemcpyHostToDevice));
   int rc = factor_and_solve_launch(h, st, true, true, 0);
   if (rc) return rc;
+  ipm_launch_inertia(D, st);      // sums the pivot signs into the instance records
   IPM_TRY(h, hipStreamSynchronize(st));
   IPM_TRY(h, hipMemcpy(sol, D.rhs, size_t(D.B) * p.Nt * sizeof(double), hipMemcpyDeviceToHost));
   IPM_TRY(h, hipMemcpy(inst.data(), D.inst, inst.size() * sizeof(IpmInst), hipMemcpyDeviceToHost));
@@ -302,6 +341,53 @@ int rpm_ipm_debug_solve(rpm_ipm* h, const double* k_storage, const double* rhs, 
     if (n_pos) n_pos[bi] = inst[bi].npos;
     if (n_neg) n_neg[bi] = inst[bi].nneg;
   }
+  return RPM_OK;
+}
+
+/* test hook, layout-independent: factor + solve the caller's DENSE symmetric matrices (B x Nt x Nt, row-major, rows and columns
+ * in unknown order: [0,n) variables, slacks, multipliers) against B right-hand sides (unknown order); entries the layout has
+ * no slot for must be zero (RPM_E_INVALID otherwise).  Works for the band + border layout and for nested dissection. */
+int rpm_ipm_debug_solve_dense(rpm_ipm* h, const double* k_dense, const double* rhs, double* sol, int* n_pos, int* n_neg) {
+  if (!h || !k_dense || !rhs || !sol) return RPM_E_INVALID;
+  const IpmPlan& p = h->plan;
+  IpmDev& D = h->D;
+  hipStream_t st = static_cast<hipStream_t>(dev_stream(h->eng->e));
+  const size_t B = size_t(D.B), Nt = size_t(p.Nt);
+  std::vector<double> store(B * size_t(p.storage()), 0.0), r(B * size_t(p.Nt_alloc), 0.0);
+  for (size_t bi = 0; bi < B; ++bi)
+    for (size_t a = 0; a < Nt; ++a) {
+      r[bi * p.Nt_alloc + p.pos[a]] = rhs[bi * Nt + a];
+      for (size_t c = 0; c <= a; ++c) {
+        const double v = k_dense[(bi * Nt + a) * Nt + c];
+        if (v == 0.0) continue;
+        const long long o = ipm_plan_offset(p, int(a), int(c));
+        if (o < 0) { h->err = "rpm_ipm_debug_solve_dense: entry (" + std::to_string(a) + ", " + std::to_string(c) + ") has no slot in the layout"; return RPM_E_INVALID; }
+        store[bi * size_t(p.storage()) + size_t(o)] = v;
+      }
+    }
+  std::vector<IpmInst> inst(D.B);
+  for (auto& s2 : inst) { s2 = IpmInst{}; s2.refactor = 1; }
+  IPM_TRY(h, hipMemcpy(D.inst, inst.data(), inst.size() * sizeof(IpmInst), hipMemcpyHostToDevice));
+  IPM_TRY(h, hipMemcpy(D.K, store.data(), store.size() * sizeof(double), hipMemcpyHostToDevice));
+  IPM_TRY(h, hipMemcpy(D.rhs, r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice));
+  int rc = factor_and_solve_launch(h, st, true, true, 0);
+  if (rc) return rc;
+  ipm_launch_inertia(D, st);
+  IPM_TRY(h, hipStreamSynchronize(st));
+  IPM_TRY(h, hipMemcpy(r.data(), D.rhs, r.size() * sizeof(double), hipMemcpyDeviceToHost));
+  IPM_TRY(h, hipMemcpy(inst.data(), D.inst, inst.size() * sizeof(IpmInst), hipMemcpyDeviceToHost));
+  for (size_t bi = 0; bi < B; ++bi) {
+    for (size_t a = 0; a < Nt; ++a) sol[bi * Nt + a] = r[bi * p.Nt_alloc + p.pos[a]];
+    if (n_pos) n_pos[bi] = inst[bi].npos;
+    if (n_neg) n_neg[bi] = inst[bi].nneg;
+  }
+  return RPM_OK;
+}
+
+/* storage offset of the entry between unknowns ua and uc (unknown order as above), -1 if the layout has no slot for it */
+int rpm_ipm_debug_slot(rpm_ipm* h, int ua, int uc, long long* offset) {
+  if (!h || !offset || ua < 0 || uc < 0 || ua >= h->plan.Nt || uc >= h->plan.Nt) return RPM_E_INVALID;
+  *offset = ipm_plan_offset(h->plan, ua, uc);
   return RPM_OK;
 }
 

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
     "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_set_all_bounds", "rpm_ipm_get_info",
-    "rpm_ipm_get_stats", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_get_kernel_times", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve",
+    "rpm_ipm_get_stats", "rpm_ipm_get_subproblems", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_get_kernel_times", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve", "rpm_ipm_debug_solve_dense", "rpm_ipm_debug_slot",
 ]
 
 
@@ -115,6 +115,7 @@ def lib(path=None):
     L.rpm_ipm_set_all_bounds.argtypes = [vp, dp, dp]
     L.rpm_ipm_get_info.argtypes = [vp, ip, ip, ip, ip, C.POINTER(C.c_longlong), ip]
     L.rpm_ipm_get_stats.argtypes = [vp, ip, ip, ip]
+    L.rpm_ipm_get_subproblems.argtypes = [vp, C.c_int, ip, ip]
     L.rpm_ipm_get_trace.argtypes = [vp, C.c_int, C.c_int, dp, ip]
     L.rpm_ipm_get_restorations.argtypes = [vp, ip]
     L.rpm_ipm_get_kernel_times.argtypes = [vp, dp, dp]
@@ -122,6 +123,8 @@ def lib(path=None):
     L.rpm_ipm_solve_dev.argtypes = [vp, vp, vp, dp, ip, ip, dp, vp]
     L.rpm_ipm_get_permutation.argtypes = [vp, ip, C.c_int]
     L.rpm_ipm_debug_solve.argtypes = [vp, dp, dp, dp, ip, ip]
+    L.rpm_ipm_debug_solve_dense.argtypes = [vp, dp, dp, dp, ip, ip]
+    L.rpm_ipm_debug_slot.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
     L.rpm_shard_segments.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.rpm_segment), ip, ip]
     L.rpm_shard_pack_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_shard_unpack_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -517,6 +520,23 @@ class BatchedIPM:
         return {"kkt_order": a[0].value, "band_order": a[1].value, "half_bandwidth": a[2].value, "border": a[3].value,
                 "storage_doubles": st.value, "n_slacks": ns.value}
 
+    def subproblems(self):
+        """Geometry of the factorisation's sub-problems: rows of (order, banded part, border, half bandwidth, column stride)."""
+        n = C.c_int()
+        self._chk(self._L.rpm_ipm_get_subproblems(self._h, 0, None, C.byref(n)))
+        g = np.zeros((n.value, 5), dtype=np.int32)
+        self._chk(self._L.rpm_ipm_get_subproblems(self._h, n.value, _ip(g), C.byref(n)))
+        return g
+
+    def factor_flops(self):
+        """Floating-point operations of one LDL^T of one instance (multiply-adds counted as 2), from the sub-problems."""
+        total = 0.0
+        for nt, nb_, nbd, b, _ in self.subproblems():
+            j = np.arange(nb_)
+            r = np.minimum(b, nb_ - 1 - j) + nbd          # rows below the pivot of band column j
+            total += float(np.sum(r * (r + 1.0))) + nbd ** 3 / 3.0
+        return total
+
     def stats(self):
         a = [C.c_int() for _ in range(3)]
         self._chk(self._L.rpm_ipm_get_stats(self._h, C.byref(a[0]), C.byref(a[1]), C.byref(a[2])))
@@ -555,6 +575,22 @@ class BatchedIPM:
         npos, nneg = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
         self._chk(self._L.rpm_ipm_debug_solve(self._h, _dp(k), _dp(r), _dp(sol), _ip(npos), _ip(nneg)))
         return sol, npos, nneg
+
+    def debug_solve_dense(self, k_dense, rhs):
+        """Factor + solve dense symmetric matrices (B, Nt, Nt) in unknown order; -> (solutions, n_pos, n_neg)."""
+        B, nt = self._e.n_instances, self.info()["kkt_order"]
+        k = np.ascontiguousarray(k_dense, dtype=np.float64)
+        r = np.ascontiguousarray(rhs, dtype=np.float64)
+        assert k.shape == (B, nt, nt) and r.shape == (B, nt)
+        sol = np.zeros((B, nt))
+        npos, nneg = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(self._L.rpm_ipm_debug_solve_dense(self._h, _dp(k), _dp(r), _dp(sol), _ip(npos), _ip(nneg)))
+        return sol, npos, nneg
+
+    def slot(self, ua, uc):
+        off = C.c_longlong()
+        self._chk(self._L.rpm_ipm_debug_slot(self._h, int(ua), int(uc), C.byref(off)))
+        return off.value
 
     def solve(self, x0):
         """x0: (n_instances, n) starting points -> dict(x, lambda, obj, status, iterations, kkt_error)."""

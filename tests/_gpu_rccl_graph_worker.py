@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_exchange.py::test_rccl_all_gather_captured_in_the_step_graph (one process, world size 1)."""
+"""Worker of tests/test_z_gpu_exchange.py::test_rccl_all_gather_captured_in_the_step_graph (one process, world size 1)."""
 import os
 import sys
 

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_exchange.py::test_two_processes_on_one_gpu_host_consumer_and_sweep: two ranks share GPU 0
+"""Worker of tests/test_z_gpu_exchange.py::test_two_processes_on_one_gpu_host_consumer_and_sweep: two ranks share GPU 0
 (gloo carries the control messages; RCCL refuses two ranks on one device), and rehearse
   * the host-consumer mode: both ranks' interval-sharded engines store their runs of g / values into ONE shared
     page-locked host segment (lpopc_amd.dist.HostConsumerGroup) == a single engine's result, bit for bit, over several

@@ -56,20 +56,21 @@ def test_bench_kernels_against_the_oracle(built, name, make, B, mode, kernel):
     torch.cuda.synchronize()
     assert eng.get_option("pipeline_active") == (1 if kernel == "pipelined" else 0)
     assert eng.get_option("role_loop") == 1
-    g, v = d_g.cpu().numpy(), d_v.cpu().numpy()
-    assert not np.isnan(g[:, :eng.m]).any() and not np.isnan(v[:, :eng.nnz_jac]).any()     # every slot of every instance written
+    # every slot of every instance written (checked on the device: the batch is up to 436 MB)
+    assert not bool(torch.isnan(d_g[:, :eng.m]).any()) and not bool(torch.isnan(d_v[:, :eng.nnz_jac]).any())
     n_const = sum(orc.phase_tables(p)["doff_vals"].size * prob.GetPhase(p).get_optimal_info()[0] for p in range(eng.n_phases))
-    f, grad = d_f.cpu().numpy(), d_grad.cpu().numpy()
+    f = d_f.cpu().numpy()
     picks = sorted(set([0, 1, B // 7, B // 3, B // 2, B - B // 5, B - 2, B - 1]))
     assert len(picks) >= 8
     for b in picks:
+        g_b, v_b, grad_b = d_g[b, :eng.m].cpu().numpy(), d_v[b, :eng.nnz_jac].cpu().numpy(), d_grad[b].cpu().numpy()
         g_ref, v_ref = orc.eval_g(xs[b]), orc.eval_jac_g(xs[b])
-        assert rel_err(g[b, :eng.m], g_ref) <= G_TOL, (b, rel_err(g[b, :eng.m], g_ref))
-        assert rel_err(v[b, :eng.nnz_jac], v_ref) <= JFD_TOL, (b, rel_err(v[b, :eng.nnz_jac], v_ref))
-        assert np.array_equal(v[b, eng.nnz_jac - n_const:eng.nnz_jac], v_ref[-n_const:])      # constant block: copies
+        assert rel_err(g_b, g_ref) <= G_TOL, (b, rel_err(g_b, g_ref))
+        assert rel_err(v_b, v_ref) <= JFD_TOL, (b, rel_err(v_b, v_ref))
+        assert np.array_equal(v_b[eng.nnz_jac - n_const:], v_ref[-n_const:])      # constant block: copies
         f_ref = orc.eval_f(xs[b])
         assert abs(f[b] - f_ref) <= 1e-12 * max(1.0, abs(f_ref))
-        assert rel_err(grad[b], orc.eval_grad_f(xs[b])) <= JFD_TOL
+        assert rel_err(grad_b, orc.eval_grad_f(xs[b])) <= JFD_TOL
     eng.close()
 
 

@@ -24,6 +24,17 @@ def _iterates(eng, count, mode="perturb"):
     return [problems.seeded_iterate(x0, xl, xu, 100 + i, mode) for i in range(count)]
 
 
+@pytest.fixture(autouse=True)
+def _registrations_are_released(built):
+    """Every page-lock registration an engine makes is released by rpm_destroy / eviction: a refused hipHostUnregister
+    would leave a stale pinned range behind for whatever the process allocates at that address next."""
+    yield
+    probe = NLPEngine(problems.brachistochrone(1, 10))
+    failures, made = probe.get_option("pin_unregister_failures"), probe.get_option("pin_registered")
+    probe.close()
+    assert failures == 0, (failures, made)
+
+
 CASES = [
     ("launch_3x6", lambda: problems.launch(3, 6), "perturb"),                 # arrays below the 64 KB pinning threshold
     ("launch_metric", lambda: problems.launch(64, 16), "perturb"),

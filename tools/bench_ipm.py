@@ -17,11 +17,13 @@ from lpopc_amd.problem import Options
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_cpu = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+nested = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 o = Options()
 o.SetStringValue("hessian-approximation", "exact")
 prob = problems.quadrotor(8, 8)
 eng = NLPEngine(prob, o, n_instances=B, device=0)
 eng.set_option("instance_align", 16)
+eng.set_option("ipm_nested", nested)
 ipm = BatchedIPM(eng)
 one = NLPEngine(prob, o, device=0)
 xl, xu, _, _ = one.get_bounds_info()
@@ -50,8 +52,9 @@ for rep in range(3):
 st, info, kt = ipm.stats(), ipm.info(), ipm.kernel_times()
 dt = min(times)
 nb, b, nbd = info["band_order"], info["half_bandwidth"], info["border"]
-flops_factor = float(nb) * (b + nbd) ** 2 + nbd ** 3 / 3.0        # multiply-adds x2 / 2 (lower triangle): ~ N (b + border)^2
+flops_factor = ipm.factor_flops()        # from the sub-problems' geometry: sum over band columns of r (r + 1), r = rows below the pivot
 out = {"workload": "quadrotor MPC sweep, %d instances x (8x8), per-instance initial states" % B, "instances": B,
+       "factorisation": "nested dissection over the mesh intervals" if nested else "band + border", "sub_problems_per_instance": int(ipm.subproblems().shape[0]),
        "solve_s": dt, "solves_per_s": B / dt, "iterations_min_max": [int(r["iterations"].min()), int(r["iterations"].max())],
        "batched_iterations": st["iterations"], "factorizations": st["factorizations"], "trial_points": st["trial_points"],
        "converged": int((r["status"] == 0).sum()), "max_kkt_error": float(r["kkt_error"].max()), "kkt": info,

@@ -61,6 +61,7 @@ def check_linear_algebra():
     for name, prob, B in (("brachistochrone 2x6", problems.brachistochrone(2, 6), 3), ("quadrotor 3x4", problems.quadrotor(3, 4), 2),
                           ("launch 2x5", problems.launch(2, 5), 2)):
         eng = NLPEngine(prob, exact(), n_instances=B, device=0)
+        eng.set_option("ipm_nested", 0)      # this check fills the band + border storage itself
         ipm = BatchedIPM(eng)
         info = ipm.info()
         store, dense, sign = random_kkt(ipm, B, 7)
