@@ -19,6 +19,7 @@ Extra first-class sections on rank 0 at N = 1 (what a TNLP caller can consume):
   sequential       B = 1 device-resident pairs/s (a sequential solver loop on the device)
   host_pointer     PCIe-inclusive pairs/s through rpm_eval_g / rpm_eval_jac_g / rpm_eval_pair on caller-owned arrays
   ms_per_ipopt_iter  eval_f + eval_grad_f + eval_g + eval_jac_g at ONE iterate, device-resident and host-pointer
+  device_ipm       one device interior-point iteration on the metric problem; the 1024-instance MPC sweep solved on the device
   roofline         HBM roofline of the dominant kernel: algorithmic bytes per launch / launch duration from HIP events
   cpu_baseline     the CPU oracle (a C port of lpopc's algorithm, oracle/) on one host core, bounded sample
 """
@@ -294,6 +295,59 @@ def sequential_section(ctx, args, prob, xs):
     return seq, s2["ms_per_step"]
 
 
+def device_ipm_section(ctx, args):
+    """Row f-2 beside the callbacks: wall time of one device interior-point iteration on the METRIC problem (callbacks,
+    exact Hessian, KKT assembly, nested-dissection LDL^T, substitution, line search — the solver does not converge on
+    Delta-III from lpopc's default guess, DESIGN.md f-2, so this is the cost of an iteration, not of a solve), and the
+    1024-instance quadrotor MPC sweep solved to 1e-8."""
+    import numpy as np
+    from lpopc_amd import problems
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    from lpopc_amd.problem import Options
+    o = Options()
+    o.SetStringValue("hessian-approximation", "exact")
+    out = {}
+    eng = NLPEngine(problems.launch(args.intervals, args.nodes), o, device=ctx.local_rank)
+    ipm = BatchedIPM(eng, max_iter=6, restoration=0)
+    x0 = eng.get_starting_point()[None, :]
+    ipm.solve(x0)                       # warm-up (module load)
+    t0 = time.perf_counter()
+    r = ipm.solve(x0)
+    dt = time.perf_counter() - t0
+    st, info, kt = ipm.stats(), ipm.info(), ipm.kernel_times()
+    out["metric_problem"] = {"ms_per_ipm_iteration": 1e3 * dt / max(1, st["iterations"]), "iterations_timed": st["iterations"],
+                             "factorizations": st["factorizations"], "factor_ms_per_launch": kt["factor_ms"] / max(1, st["factorizations"]),
+                             "kkt_order": info["kkt_order"], "sub_problems": int(ipm.subproblems().shape[0]),
+                             "status_after_the_timed_iterations": int(r["status"][0]),
+                             "note": "iteration cost only: status 2 = iteration limit; the solver does not converge on Delta-III (DESIGN.md f-2)"}
+    ipm.close()
+    eng.close()
+    B = 1024
+    prob = problems.quadrotor(8, 8)
+    eng = NLPEngine(prob, o, n_instances=B, device=ctx.local_rank)
+    eng.set_option("instance_align", 16)
+    ipm = BatchedIPM(eng)
+    xl, xu, _, _ = NLPEngine(prob, o).get_bounds_info()
+    x_start = eng.get_starting_point()[:eng.n]
+    rng = np.random.RandomState(5)
+    idx = [i * 65 for i in range(12)]
+    L, U = np.tile(xl, (B, 1)), np.tile(xu, (B, 1))
+    for bi in range(B):
+        L[bi, idx] = U[bi, idx] = np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.1, 0.1, 6)])
+    ipm.set_all_bounds(L, U)
+    x0 = np.tile(x_start, (B, 1))
+    ipm.solve(x0)
+    t0 = time.perf_counter()
+    r = ipm.solve(x0)
+    dt = time.perf_counter() - t0
+    out["config5_sweep_1024"] = {"solve_s": dt, "solves_per_s": B / dt, "converged": int((r["status"] == 0).sum()),
+                                 "batched_iterations": ipm.stats()["iterations"], "max_kkt_error": float(r["kkt_error"].max()),
+                                 "note": "host arrays in and out (rpm_ipm_solve), per-instance initial states"}
+    ipm.close()
+    eng.close()
+    return out
+
+
 def host_section(ctx, args, prob, xs):
     from lpopc_amd.engine import NLPEngine
     from lpopc_amd.hostbench import time_host_path, time_ipopt_iteration
@@ -489,6 +543,10 @@ def main():
                                                 "median; Ipopt itself is absent, so no linear-solver time is in it"}
         except Exception as ex:
             errors["sequential"] = repr(ex)
+        try:
+            out["device_ipm"] = device_ipm_section(ctx, args)
+        except Exception as ex:
+            errors["device_ipm"] = repr(ex)
         try:
             hp, it_plain, it_delta = host_section(ctx, args, prob, xs_main)
             out["host_pointer"] = hp

@@ -21,8 +21,11 @@ struct IpmOpts {
   int max_iter = 3000, max_ls = 40;
   double acceptable_tol = 1e-6;      // Ipopt: "solved to acceptable level" after acceptable_iter consecutive such iterations
   int acceptable_iter = 15;
-  int resto = 1, resto_max = 60;     // Gauss-Newton feasibility restoration after a failed line search
-  double kappa_resto = 0.9;
+  int resto = 1, resto_max = 300;    // restoration phase (paper section 3.3) after a failed line search; its iteration limit
+  double kappa_resto = 0.9, resto_rho = 1000.0, mult_reset = 1e3;
+  double bound_relax = 1e-8;         // Ipopt's bound_relax_factor: finite bounds of free unknowns move out by this * max(1, |bound|)
+  int max_soc = 4;                   // second-order correction steps per iteration (paper A-5.5 .. A-5.9)
+  double kappa_soc = 0.99;
 };
 
 struct IpmInst {
@@ -30,9 +33,12 @@ struct IpmInst {
   double delta_w, delta_w_last, alpha_max, alpha_z, alpha, alpha_min, dphi, phi, theta_max, theta_min;
   int status;   // 0 running, 1 converged, 6 converged to the acceptable level, 2 iteration limit, 3 line search failed (Ipopt would enter restoration), 4 inertia correction failed, 5 NaN/Inf
   int iter, nfilt, accepted, refactor, npos, nneg, nbad, ls, armijo, nzb, pad;
-  int mode, resto_it, enter_resto, n_resto;   // mode 1: feasibility restoration
-  int n_acc, pad2;                            // consecutive iterations with E_0 <= acceptable_tol
-  double th0, zeta, psi, slope;
+  int mode, resto_it, enter_resto, n_resto;   // mode 0 regular iteration, 2 restoration phase, 3 least-squares multipliers on leaving it
+  int n_acc, skip_update;                     // consecutive iterations with E_0 <= acceptable_tol; this pass changed lambda only
+  double th0, zeta;                           // restoration: infeasibility where it was entered, weight of the proximity term
+  double mu_r, th_r, thr_max, thr_min, phi_r; // restoration: its own barrier parameter, infeasibility |c - p + n|_1, filter bounds, barrier objective
+  int nrfilt, soc_on, soc_req, soc_p, use_soc, n_soc;   // restoration filter entries; second-order correction state
+  double alpha_soc, az_soc, th_old_soc;
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 
@@ -60,10 +66,14 @@ struct IpmDev {
   double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
   double *xe, *xt, *grad, *g, *jac, *hess, *obj, *gt, *objt;
   double *vR, *dr2;   // restoration: reference point and D_R^2 = 1 / max(1, |v_R|)^2
+  double *vl0, *vu0;  // the caller's bounds; vl, vu are these moved out by bound_relax (ipm_init_kernel)
+  double *pp, *nn, *zp, *zn, *dpp, *dnn, *dzp, *dzn;   // restoration: c(v) - p + n = 0, p, n >= 0, their multipliers and steps (m each)
+  double* rfilt;      // restoration's own filter
+  double *dv2, *dlam2, *dzL2, *dzU2, *csoc, *ct;       // second-order correction: candidate step, c_soc, c(trial point)
   double* trace;   // per instance trace_cap records of IPM_TRACE doubles (one per accepted step), or NULL
   int trace_cap;
   IpmInst* inst;
-  int* cnt;     // [0] running, [1] to refactor, [2] line searches pending
+  int* cnt;     // [0] running, [1] to refactor, [2] line searches pending, [3] second-order corrections requested
   IpmOpts o;
   // factorisation sub-problems: one (the whole band + border matrix) or, with nested dissection, n_l1 interval blocks
   // followed by the separator system; pivot signs of every sub-problem land in piv[(instance * n_sub + sub) * 3 + {+,-,bad}]
@@ -91,12 +101,15 @@ void ipm_launch_direction(const IpmDev& D, hipStream_t st);
 void ipm_launch_trial(const IpmDev& D, hipStream_t st);
 void ipm_launch_accept(const IpmDev& D, hipStream_t st);
 void ipm_launch_update(const IpmDev& D, hipStream_t st);
+void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st);          // right-hand side of the second-order correction
+void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st);    // its step and step lengths
 // factorisation / substitution of every running instance; tiles_per_wave 4 or IPM_MT
 size_t kkt_factor_lds_bytes(const IpmPlan& p);
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes);
 // factor every running instance that asks for it / solve in place in D.rhs: the band + border matrix, or level 1 ->
 // corner gather -> level 2 and forward -> gather -> level 2 -> scatter -> backward with nested dissection
 void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hipStream_t st);
+// check_status: 0 every instance, 1 the running ones, 2 the running ones that asked for a second-order correction
 void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st);
 
 }  // namespace rpm

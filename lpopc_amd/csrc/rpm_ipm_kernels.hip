@@ -37,29 +37,37 @@ __device__ inline bool has_lo(double l, double u) { return l > -IPM_INF && l != 
 __device__ inline bool has_up(double l, double u) { return u < IPM_INF && l != u; }
 
 // ------------------------------------------------------------------------------------------------ start
-// x pushed into the interior of its bounds (Ipopt 3.12 bound_push / bound_frac, paper section 3.6), z = 1, lambda = 0
+// x pushed into the interior of its bounds (Ipopt 3.12 bound_push / bound_frac, paper section 3.6), z = 1, lambda = 0.  The
+// bounds themselves first move out by bound_relax * max(1, |bound|) (Ipopt's bound_relax_factor): vl0 / vu0 keep the caller's.
+__device__ inline double push_inside(double x, double l, double u, bool lo, bool up, const IpmOpts& o) {
+  if (lo) {
+    const double p = up ? fmin(o.bound_push * fmax(1.0, fabs(l)), o.bound_frac * (u - l)) : o.bound_push * fmax(1.0, fabs(l));
+    x = fmax(x, l + p);
+  }
+  if (up) {
+    const double p = lo ? fmin(o.bound_push * fmax(1.0, fabs(u)), o.bound_frac * (u - l)) : o.bound_push * fmax(1.0, fabs(u));
+    x = fmin(x, u - p);
+  }
+  return x;
+}
 __global__ __launch_bounds__(256) void ipm_init_kernel(IpmDev D, const double* x0) {
   const int bi = blockIdx.x;
-  double* v = D.v + size_t(bi) * D.nv;
-  const double *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
+  const size_t o = size_t(bi) * D.nv;
   for (int i = threadIdx.x; i < D.n; i += blockDim.x) {
     double x = x0[size_t(bi) * D.n + i];
-    const double l = vl[i], u = vu[i];
+    double l = D.vl0[o + i], u = D.vu0[o + i];
+    const bool lo = l > -IPM_INF && l != u, up = u < IPM_INF && l != u;
     if (l == u) x = l;
     else {
-      const bool lo = l > -IPM_INF, up = u < IPM_INF;
-      if (lo) {
-        const double p = up ? fmin(D.o.bound_push * fmax(1.0, fabs(l)), D.o.bound_frac * (u - l)) : D.o.bound_push * fmax(1.0, fabs(l));
-        x = fmax(x, l + p);
-      }
-      if (up) {
-        const double p = lo ? fmin(D.o.bound_push * fmax(1.0, fabs(u)), D.o.bound_frac * (u - l)) : D.o.bound_push * fmax(1.0, fabs(u));
-        x = fmin(x, u - p);
-      }
+      if (lo) l -= D.o.bound_relax * fmax(1.0, fabs(l));
+      if (up) u += D.o.bound_relax * fmax(1.0, fabs(u));
+      x = push_inside(x, l, u, lo, up, D.o);
     }
-    v[i] = x;
-    D.zL[size_t(bi) * D.nv + i] = has_lo(l, u) ? 1.0 : 0.0;
-    D.zU[size_t(bi) * D.nv + i] = has_up(l, u) ? 1.0 : 0.0;
+    D.v[o + i] = x;
+    D.vl[o + i] = l;
+    D.vu[o + i] = u;
+    D.zL[o + i] = lo ? 1.0 : 0.0;
+    D.zU[o + i] = up ? 1.0 : 0.0;
   }
   for (int r = threadIdx.x; r < D.m; r += blockDim.x) D.lam[size_t(bi) * D.m + r] = 0.0;
   if (threadIdx.x == 0) {
@@ -68,24 +76,17 @@ __global__ __launch_bounds__(256) void ipm_init_kernel(IpmDev D, const double* x
     S.mu = D.o.mu_init;
   }
 }
-// slacks start at g(x0), pushed inside [g_l, g_u] the same way
+// slacks start at g(x0), pushed inside the (relaxed) [g_l, g_u] the same way
 __global__ __launch_bounds__(256) void ipm_init_slack_kernel(IpmDev D) {
   const int bi = blockIdx.x;
   for (int s = threadIdx.x; s < D.ns; s += blockDim.x) {
     const int r = D.slack_row[s];
-    const double l = D.gl[r], u = D.gu[r];
-    double x = D.g[size_t(bi) * D.sg + r];
+    double l = D.gl[r], u = D.gu[r];
     const bool lo = l > -IPM_INF, up = u < IPM_INF;
-    if (lo) {
-      const double p = up ? fmin(D.o.bound_push * fmax(1.0, fabs(l)), D.o.bound_frac * (u - l)) : D.o.bound_push * fmax(1.0, fabs(l));
-      x = fmax(x, l + p);
-    }
-    if (up) {
-      const double p = lo ? fmin(D.o.bound_push * fmax(1.0, fabs(u)), D.o.bound_frac * (u - l)) : D.o.bound_push * fmax(1.0, fabs(u));
-      x = fmin(x, u - p);
-    }
+    if (lo) l -= D.o.bound_relax * fmax(1.0, fabs(l));
+    if (up) u += D.o.bound_relax * fmax(1.0, fabs(u));
     const size_t o = size_t(bi) * D.nv + D.n + s;
-    D.v[o] = x;
+    D.v[o] = push_inside(D.g[size_t(bi) * D.sg + r], l, u, lo, up, D.o);
     D.vl[o] = l;
     D.vu[o] = u;
     D.zL[o] = lo ? 1.0 : 0.0;
@@ -99,18 +100,22 @@ __global__ void ipm_pack_x_kernel(IpmDev D) {
 }
 
 // ------------------------------------------------------------------------------------------------ residuals, E_mu, mu
+// multiplier reset (16) of a bound multiplier z for the slack s
+__device__ inline double reset16(double z, double s, double mu, double ks) { return fmax(fmin(z, ks * mu / s), mu / (ks * s)); }
+
 __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmDev D) {
   __shared__ double sh[4];
+  __shared__ int verdict;       // restoration: 0 stay, 1 leave it (least-squares multipliers next), 2 stop
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
+  const int mode_in = S.mode;
   const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
   const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv, *lam = D.lam + size_t(bi) * D.m;
   const double *jac = D.jac + size_t(bi) * D.sv, *g = D.g + size_t(bi) * D.sg, *grad = D.grad + size_t(bi) * D.n;
   double* glag = D.glag + size_t(bi) * D.nv;
   double dinf = 0, cinf = 0, th1 = 0, cmax = 0, cmin = 1e300, sl = 0, sz = 0, ln = 0, bad = 0, nzb = 0;
   // pass 1: constraint values and what does not depend on the multipliers
-  double csq = 0, qd = 0;
   for (int r = t; r < D.m; r += blockDim.x) {
     const int s = D.row_slack[r];
     const double cr = s < 0 ? g[r] - D.gl[r] : g[r] - v[D.n + s];
@@ -118,57 +123,91 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmDev D) {
     if (!(fabs(cr) < 1e300)) bad = 1;
     cinf = fmax(cinf, fabs(cr));
     th1 += fabs(cr);
-    csq += cr * cr;
   }
   cinf = block_red(cinf, 1, sh); th1 = block_red(th1, 0, sh);
-  __shared__ int verdict;       // restoration: 0 stay, 1 back to the regular iteration, 2 stop
-  const int mode_in = S.mode;
-  if (mode_in == 1) {
+  if (mode_in == 2) {
+    // ---- restoration phase (paper section 3.3): min rho sum(p + n) + zeta/2 |D_R (v - v_R)|^2  s.t.  c(v) - p + n = 0, p, n >= 0, bounds
+    const IpmOpts& o = D.o;
+    const double rho = o.resto_rho, zeta = S.zeta;
+    const double *pp = D.pp + size_t(bi) * D.m, *nn = D.nn + size_t(bi) * D.m, *zp = D.zp + size_t(bi) * D.m, *zn = D.zn + size_t(bi) * D.m;
     const double *vR = D.vR + size_t(bi) * D.nv, *dr2 = D.dr2 + size_t(bi) * D.nv;
+    double thr = 0, rinf = 0, spn = 0, lnpn = 0, qd = 0;
+    for (int r = t; r < D.m; r += blockDim.x) {
+      const double rc = D.c[size_t(bi) * D.m + r] - pp[r] + nn[r];
+      thr += fabs(rc); rinf = fmax(rinf, fabs(rc));
+      spn += pp[r] + nn[r];
+      lnpn += log(pp[r]) + log(nn[r]);
+      dinf = fmax(dinf, fmax(fabs(rho - lam[r] - zp[r]), fabs(rho + lam[r] - zn[r])));
+      const double p1 = zp[r] * pp[r], p2 = zn[r] * nn[r];
+      cmax = fmax(cmax, fmax(p1, p2)); cmin = fmin(cmin, fmin(p1, p2));
+    }
     for (int i = t; i < D.nv; i += blockDim.x) {
+      double acc = 0.0;                       // A^T lambda only: the proximity term is added where zeta is known
+      if (i < D.n) { for (int q = D.jt_ptr[i]; q < D.jt_ptr[i + 1]; ++q) acc += jac[D.jt_ent[q]] * lam[D.jt_row[q]]; }
+      else acc = -lam[D.slack_row[i - D.n]];
+      glag[i] = acc;
       const double l = vl[i], u = vu[i];
       if (l == u) continue;
-      if (l > -IPM_INF) ln += log(v[i] - l);
-      if (u < IPM_INF) ln += log(u - v[i]);
       const double dd = v[i] - vR[i];
       qd += dr2[i] * dd * dd;
+      dinf = fmax(dinf, fabs(zeta * dr2[i] * dd + acc - zL[i] + zU[i]));
+      if (!(fabs(acc) < 1e300)) bad = 1;
+      if (l > -IPM_INF) { const double d = v[i] - l, pr = zL[i] * d; cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); ln += log(d); }
+      if (u < IPM_INF) { const double d = u - v[i], pr = zU[i] * d; cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); ln += log(d); }
     }
-    csq = block_red(csq, 0, sh); ln = block_red(ln, 0, sh); qd = block_red(qd, 0, sh); bad = block_red(bad, 1, sh);
+    thr = block_red(thr, 0, sh); rinf = block_red(rinf, 1, sh); spn = block_red(spn, 0, sh); lnpn = block_red(lnpn, 0, sh);
+    qd = block_red(qd, 0, sh); dinf = block_red(dinf, 1, sh); cmax = block_red(cmax, 1, sh); cmin = block_red(cmin, 2, sh);
+    ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh);
     if (t == 0) {
-      const IpmOpts& o = D.o;
-      const double f = D.obj[bi], phi = f - S.mu * ln;
+      const double f = D.obj[bi];
       verdict = 0;
-      if (bad != 0 || !(fabs(f) < 1e300) || !(fabs(ln) < 1e300)) { S.status = 5; verdict = 2; }
+      if (bad != 0 || !(fabs(f) < 1e300) || !(fabs(ln) < 1e300) || !(fabs(lnpn) < 1e300)) { S.status = 5; verdict = 2; }
       else {
+        const double phi_o = f - S.mu * ln;      // the ORIGINAL barrier objective: what the original filter is asked about
         bool back = S.resto_it > 0 && th1 <= o.kappa_resto * S.th0 && th1 <= S.theta_max;
         const double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
         for (int k = 0; back && k < S.nfilt; ++k)
-          if (th1 >= F[2 * k] && phi >= F[2 * k + 1]) back = false;
+          if (th1 >= F[2 * k] && phi_o >= F[2 * k + 1]) back = false;
         if (back) verdict = 1;
-        else if (S.resto_it >= o.resto_max || S.iter >= o.max_iter) { S.status = S.iter >= o.max_iter ? 2 : 3; verdict = 2; }
+        else if (S.resto_it >= o.resto_max) { S.status = 3; verdict = 2; }
+        else if (S.iter >= o.max_iter) { S.status = 2; verdict = 2; }
         else {
-          S.f = f; S.theta = th1; S.lnsum = ln; S.cinf = cinf;
-          S.psi = 0.5 * csq + 0.5 * S.zeta * qd - S.mu * ln;
-          S.refactor = 1;
-          S.delta_w = 0.0;
-          atomicAdd(&D.cnt[0], 1);
+          if (S.resto_it == 0) { S.thr_max = 1e4 * fmax(1.0, thr); S.thr_min = 1e-4 * fmax(1.0, thr); }
+          const double mu_min = o.tol / 10.0;
+          double mu_r = S.mu_r;
+          bool stuck = false;
+          for (int guard = 0; guard < 64; ++guard) {
+            const double emu = fmax(fmax(dinf, rinf), fmax(fabs(cmax - mu_r), fabs(cmin - mu_r)));
+            if (!(emu <= o.kappa_eps * mu_r)) break;
+            if (mu_r <= mu_min) { stuck = true; break; }     // a minimiser of the infeasibility that the filter does not take
+            mu_r = fmax(mu_min, fmin(o.kappa_mu * mu_r, pow(mu_r, o.theta_mu)));
+            S.nrfilt = 0;
+          }
+          if (stuck) { S.status = 3; verdict = 2; }
+          else {
+            S.mu_r = mu_r; S.zeta = sqrt(mu_r); S.tau = fmax(o.tau_min, 1.0 - mu_r);
+            S.f = f; S.theta = th1; S.lnsum = ln; S.cinf = cinf; S.th_r = thr;
+            S.phi_r = rho * spn + 0.5 * S.zeta * qd - mu_r * (ln + lnpn);
+            S.refactor = 1;
+            S.delta_w = 0.0;
+            atomicAdd(&D.cnt[0], 1);
+          }
         }
       }
     }
     __syncthreads();
     if (verdict != 1) return;
-    // back to the regular iteration: lambda = 0, bound multipliers clipped (as after Ipopt's restoration)
-    for (int r = t; r < D.m; r += blockDim.x) D.lam[size_t(bi) * D.m + r] = 0.0;
+    // leaving the restoration: bound multipliers clipped against the ORIGINAL mu, then one pass that only computes
+    // least-squares multipliers (mode 3; paper section 3.6) before the regular iteration resumes at this point
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double l = vl[i], u = vu[i];
       if (l == u) continue;
       const size_t o2 = size_t(bi) * D.nv + i;
-      if (l > -IPM_INF) { const double sl2 = v[i] - l; D.zL[o2] = fmax(fmin(fmin(D.zL[o2], 1e3), D.o.kappa_sigma * S.mu / sl2), S.mu / (D.o.kappa_sigma * sl2)); }
-      if (u < IPM_INF) { const double su2 = u - v[i]; D.zU[o2] = fmax(fmin(fmin(D.zU[o2], 1e3), D.o.kappa_sigma * S.mu / su2), S.mu / (D.o.kappa_sigma * su2)); }
+      if (l > -IPM_INF) D.zL[o2] = reset16(fmin(D.zL[o2], 1e3), v[i] - l, S.mu, D.o.kappa_sigma);
+      if (u < IPM_INF) D.zU[o2] = reset16(fmin(D.zU[o2], 1e3), u - v[i], S.mu, D.o.kappa_sigma);
     }
-    if (t == 0) { S.mode = 0; S.n_resto += 1; }
-    __syncthreads();
-    ln = 0; bad = 0;
+    if (t == 0) { S.mode = 3; S.refactor = 1; S.delta_w = 0.0; atomicAdd(&D.cnt[0], 1); }
+    return;
   }
   // pass 2: gradient of the Lagrangian, complementarity products
   for (int i = t; i < D.nv; i += blockDim.x) {
@@ -250,8 +289,10 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
   const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool resto = S.mode == 1;      // restoration: W = zeta D_R^2 + mu / s^2, -I in the constraint block, no Hessian
-  if (!resto)   // duplicates of a slot (I-part / E-part of the reference's COO) are summed in COO order: bit-reproducible.  The
+  // mode 0: (13).  mode 2 (restoration, p and n eliminated): [[zeta D_R^2 + Sigma_v, A^T], [A, -(Sigma_p^-1 + Sigma_n^-1)]], no
+  // Hessian (Gauss-Newton model).  mode 3 (least-squares multipliers): [[I, A^T], [A, -delta_c]].
+  const int mode = S.mode;
+  if (mode == 0)   // duplicates of a slot (I-part / E-part of the reference's COO) are summed in COO order: bit-reproducible.  The
     for (int i = t0; i < D.n_hg; i += stride) {   // slot may also take the diagonal term below: two atomic adds onto zero commute
       double acc = 0.0;
       for (int j = D.hg_ptr[i]; j < D.hg_ptr[i + 1]; ++j) acc += D.hess[size_t(bi) * D.nnz_h + D.hg_src[j]];
@@ -261,27 +302,41 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
     if (D.jac_dst[k] >= 0) K[D.jac_dst[k]] = D.jac[size_t(bi) * D.sv + k];
   for (int s = t0; s < D.ns; s += stride) K[D.slk_dst[s]] = -1.0;
   double* rhs = D.rhs + size_t(bi) * D.Nt;
+  const double mu = mode == 2 ? S.mu_r : S.mu;
   for (int i = t0; i < D.nv; i += stride) {
     const double l = vl[i], u = vu[i];
     double diag = 1.0, r = 0.0;
-    if (l != u && !resto) {
-      diag = S.delta_w;
-      r = D.glag[size_t(bi) * D.nv + i];
-      if (l > -IPM_INF) { const double d = v[i] - l; diag += zL[i] / d; r -= S.mu / d; }
-      if (u < IPM_INF) { const double d = u - v[i]; diag += zU[i] / d; r += S.mu / d; }
-    } else if (l != u) {
-      const double w2 = S.zeta * D.dr2[size_t(bi) * D.nv + i];
-      diag = S.delta_w + w2;
-      r = w2 * (v[i] - D.vR[size_t(bi) * D.nv + i]);
-      if (l > -IPM_INF) { const double d = v[i] - l; diag += S.mu / (d * d); r -= S.mu / d; }
-      if (u < IPM_INF) { const double d = u - v[i]; diag += S.mu / (d * d); r += S.mu / d; }
+    if (l != u) {
+      if (mode == 3) {
+        diag = 1.0 + S.delta_w;
+        r = (i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0) - zL[i] + zU[i];
+      } else {
+        diag = S.delta_w;
+        r = D.glag[size_t(bi) * D.nv + i];
+        if (mode == 2) {
+          const double w2 = S.zeta * D.dr2[size_t(bi) * D.nv + i];
+          diag += w2;
+          r += w2 * (v[i] - D.vR[size_t(bi) * D.nv + i]);
+        }
+        if (l > -IPM_INF) { const double d = v[i] - l; diag += zL[i] / d; r -= mu / d; }
+        if (u < IPM_INF) { const double d = u - v[i]; diag += zU[i] / d; r += mu / d; }
+      }
     }
     unsafeAtomicAdd(&K[D.diag_dst[i]], diag);
     rhs[D.pos[i]] = -r;
   }
   for (int r = t0; r < D.m; r += stride) {
-    K[D.diag_dst[D.nv + r]] = resto ? -1.0 : -D.o.delta_c;
-    rhs[D.pos[D.nv + r]] = -D.c[size_t(bi) * D.m + r];
+    double k22 = -D.o.delta_c, rr = 0.0;
+    if (mode == 0) rr = -D.c[size_t(bi) * D.m + r];
+    else if (mode == 2) {
+      const size_t q = size_t(bi) * D.m + r;
+      const double pp = D.pp[q], nn = D.nn[q], sp = D.zp[q] / pp, sn = D.zn[q] / nn, lam = D.lam[q];
+      const double rp = D.o.resto_rho - lam - mu / pp, rn = D.o.resto_rho + lam - mu / nn;
+      k22 = -(1.0 / sp + 1.0 / sn);
+      rr = -(D.c[q] - pp + nn) - rp / sp + rn / sn;
+    }
+    K[D.diag_dst[D.nv + r]] = k22;
+    rhs[D.pos[D.nv + r]] = rr;
   }
 }
 
@@ -570,7 +625,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
   // phase 2 = backward over the band blocks only (the work space then holds the separator / border solution)
   constexpr int W = IPM_W;
   const int bi = blockIdx.x / n_here, t = threadIdx.x, nt = blockDim.x;
-  if (check_status && inst[bi].status != 0) return;
+  if (check_status && (inst[bi].status != 0 || (check_status == 2 && !inst[bi].soc_req))) return;
   const KktSub sub = subs[sub0 + int(blockIdx.x) % n_here];
   const KktGeom G = sub.g;
   const double* K = Kall + size_t(bi) * kstride + sub.koff;
@@ -699,45 +754,15 @@ __global__ void ipm_inertia_kernel(IpmDev D) {
 }
 
 // ------------------------------------------------------------------------------------------------ direction
-__global__ __launch_bounds__(256) void ipm_direction_kernel(IpmDev D) {
-  __shared__ double sh[4];
-  const int bi = blockIdx.x, t = threadIdx.x;
-  IpmInst& S = D.inst[bi];
-  if (S.status != 0) return;
+// fraction to the boundary (15): largest a in (0, 1] with w + a dw >= (1 - tau) w
+__device__ inline double ftb(double w, double dw, double tau, double a) { return dw < 0 ? fmin(a, -tau * w / dw) : a; }
+
+// step of the regular iteration from a solution of (13): dz (12), step lengths (15), slope of the barrier objective
+__device__ inline void newton_step(const IpmDev& D, int bi, const double* sol, double* dv, double* dlam, double* dzL, double* dzU,
+                                   double mu, double tau, double* sh, double* amax_o, double* az_o, double* dphi_o, double* bad_o) {
   const size_t o = size_t(bi) * D.nv;
-  const double* sol = D.rhs + size_t(bi) * D.Nt;
+  const int t = threadIdx.x;
   double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
-  const double mu = S.mu, tau = S.tau;
-  if (S.mode == 1) {            // Gauss-Newton step of the restoration: slope = g_b^T d + (A d)^T c, A d = w - c
-    double slope = 0.0;
-    for (int i = t; i < D.nv; i += blockDim.x) {
-      const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
-      double d = 0.0;
-      if (l != u) {
-        d = sol[D.pos[i]];
-        if (!(fabs(d) < 1e300)) bad = 1;
-        double gb = S.zeta * D.dr2[o + i] * (vi - D.vR[o + i]);
-        if (l > -IPM_INF) { const double s = vi - l; if (d < 0) amax = fmin(amax, -tau * s / d); gb -= mu / s; }
-        if (u < IPM_INF) { const double s = u - vi; if (d > 0) amax = fmin(amax, tau * s / d); gb += mu / s; }
-        slope += gb * d;
-      }
-      D.dv[o + i] = d;
-      D.dzL[o + i] = 0.0;
-      D.dzU[o + i] = 0.0;
-    }
-    for (int r = t; r < D.m; r += blockDim.x) {
-      const double cr = D.c[size_t(bi) * D.m + r];
-      slope += (sol[D.pos[D.nv + r]] - cr) * cr;
-      D.dlam[size_t(bi) * D.m + r] = 0.0;
-    }
-    amax = block_red(amax, 2, sh); slope = block_red(slope, 0, sh); bad = block_red(bad, 1, sh);
-    if (t != 0) return;
-    if (bad != 0) { S.status = 5; return; }
-    S.alpha_max = amax; S.alpha_z = 0.0; S.alpha = amax; S.slope = slope; S.dphi = slope;
-    S.ls = 0; S.accepted = 0; S.armijo = 0;
-    atomicAdd(&D.cnt[2], 1);
-    return;
-  }
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
     double d = 0.0, dl = 0.0, du = 0.0;
@@ -748,37 +773,150 @@ __global__ __launch_bounds__(256) void ipm_direction_kernel(IpmDev D) {
       if (l > -IPM_INF) {
         const double s = vi - l, z = D.zL[o + i];
         dl = mu / s - z - z / s * d;                       // (12)
-        if (d < 0) amax = fmin(amax, -tau * s / d);        // (15a)
-        if (dl < 0) az = fmin(az, -tau * z / dl);          // (15b)
+        amax = ftb(s, d, tau, amax);                       // (15a)
+        az = ftb(z, dl, tau, az);                          // (15b)
         gphi -= mu / s;
       }
       if (u < IPM_INF) {
         const double s = u - vi, z = D.zU[o + i];
         du = mu / s - z + z / s * d;
-        if (d > 0) amax = fmin(amax, tau * s / d);
-        if (du < 0) az = fmin(az, -tau * z / du);
+        amax = ftb(s, -d, tau, amax);
+        az = ftb(z, du, tau, az);
         gphi += mu / s;
       }
       dphi += gphi * d;
     }
-    D.dv[o + i] = d;
-    D.dzL[o + i] = dl;
-    D.dzU[o + i] = du;
+    dv[o + i] = d;
+    dzL[o + i] = dl;
+    dzU[o + i] = du;
   }
-  for (int r = t; r < D.m; r += blockDim.x) D.dlam[size_t(bi) * D.m + r] = sol[D.pos[D.nv + r]];
-  amax = block_red(amax, 2, sh); az = block_red(az, 2, sh); dphi = block_red(dphi, 0, sh); bad = block_red(bad, 1, sh);
+  for (int r = t; r < D.m; r += blockDim.x) dlam[size_t(bi) * D.m + r] = sol[D.pos[D.nv + r]];
+  *amax_o = block_red(amax, 2, sh); *az_o = block_red(az, 2, sh); *dphi_o = block_red(dphi, 0, sh); *bad_o = block_red(bad, 1, sh);
+}
+__device__ inline double alpha_min23(const IpmOpts& op, double theta, double theta_min, double dphi) {   // (23)
+  double amin = op.gamma_theta;
+  if (dphi < 0) {
+    amin = fmin(amin, op.gamma_phi * theta / (-dphi));
+    if (theta <= theta_min) amin = fmin(amin, op.delta * pow(theta, op.s_theta) / pow(-dphi, op.s_phi));
+  }
+  return op.gamma_alpha * amin;
+}
+
+__global__ __launch_bounds__(256) void ipm_direction_kernel(IpmDev D) {
+  __shared__ double sh[4];
+  const int bi = blockIdx.x, t = threadIdx.x;
+  IpmInst& S = D.inst[bi];
+  const int status = S.status, mode = S.mode;
+  const double mu = mode == 2 ? S.mu_r : S.mu, tau = S.tau;
+  __syncthreads();              // thread 0 rewrites S.mode below: everybody has read it
+  if (status != 0) return;
+  const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
+  const double* sol = D.rhs + size_t(bi) * D.Nt;
+  if (mode == 3) {              // least-squares multipliers on leaving the restoration; lambda = 0 when they are large (section 3.6)
+    double mx = 0.0;
+    for (int r = t; r < D.m; r += blockDim.x) mx = fmax(mx, fabs(sol[D.pos[D.nv + r]]));
+    mx = block_red(mx, 1, sh);
+    const bool keep = mx <= D.o.mult_reset;       // false for NaN as well
+    for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] = keep ? sol[D.pos[D.nv + r]] : 0.0;
+    if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = 1; S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
+    return;
+  }
+  if (mode == 2) {              // restoration: step in (v, lambda) from the reduced system, p and n recovered from it
+    const double rho = D.o.resto_rho, zeta = S.zeta;
+    double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
+    for (int i = t; i < D.nv; i += blockDim.x) {
+      const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
+      double d = 0.0, dl = 0.0, du = 0.0;
+      if (l != u) {
+        d = sol[D.pos[i]];
+        if (!(fabs(d) < 1e300)) bad = 1;
+        double gb = zeta * D.dr2[o + i] * (vi - D.vR[o + i]);
+        if (l > -IPM_INF) {
+          const double s = vi - l, z = D.zL[o + i];
+          dl = mu / s - z - z / s * d;
+          amax = ftb(s, d, tau, amax); az = ftb(z, dl, tau, az);
+          gb -= mu / s;
+        }
+        if (u < IPM_INF) {
+          const double s = u - vi, z = D.zU[o + i];
+          du = mu / s - z + z / s * d;
+          amax = ftb(s, -d, tau, amax); az = ftb(z, du, tau, az);
+          gb += mu / s;
+        }
+        dphi += gb * d;
+      }
+      D.dv[o + i] = d; D.dzL[o + i] = dl; D.dzU[o + i] = du;
+    }
+    for (int r = t; r < D.m; r += blockDim.x) {
+      const double pp = D.pp[om + r], nn = D.nn[om + r], zp = D.zp[om + r], zn = D.zn[om + r], lam = D.lam[om + r];
+      const double sp = zp / pp, sn = zn / nn, dlam = sol[D.pos[D.nv + r]];
+      if (!(fabs(dlam) < 1e300)) bad = 1;
+      const double rp = rho - lam - mu / pp, rn = rho + lam - mu / nn;
+      const double dp = (dlam - rp) / sp, dn = (-dlam - rn) / sn;
+      const double dzp = mu / pp - zp - sp * dp, dzn = mu / nn - zn - sn * dn;
+      amax = ftb(pp, dp, tau, amax); amax = ftb(nn, dn, tau, amax);
+      az = ftb(zp, dzp, tau, az); az = ftb(zn, dzn, tau, az);
+      dphi += (rho - mu / pp) * dp + (rho - mu / nn) * dn;
+      D.dlam[om + r] = dlam; D.dpp[om + r] = dp; D.dnn[om + r] = dn; D.dzp[om + r] = dzp; D.dzn[om + r] = dzn;
+    }
+    amax = block_red(amax, 2, sh); az = block_red(az, 2, sh); dphi = block_red(dphi, 0, sh); bad = block_red(bad, 1, sh);
+    if (t != 0) return;
+    if (bad != 0) { S.status = 5; return; }
+    S.alpha_max = amax; S.alpha_z = az; S.alpha = amax; S.dphi = dphi;
+    S.alpha_min = alpha_min23(D.o, S.th_r, S.thr_min, dphi);
+    S.ls = 0; S.accepted = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0;
+    atomicAdd(&D.cnt[2], 1);
+    return;
+  }
+  double amax, az, dphi, bad;
+  newton_step(D, bi, sol, D.dv, D.dlam, D.dzL, D.dzU, mu, tau, sh, &amax, &az, &dphi, &bad);
   if (t != 0) return;
   if (bad != 0) { S.status = 5; return; }
-  const IpmOpts& op = D.o;
   S.alpha_max = amax; S.alpha_z = az; S.alpha = amax; S.dphi = dphi;
-  double amin = op.gamma_theta;                            // (23)
-  if (dphi < 0) {
-    amin = fmin(amin, op.gamma_phi * S.theta / (-dphi));
-    if (S.theta <= S.theta_min) amin = fmin(amin, op.delta * pow(S.theta, op.s_theta) / pow(-dphi, op.s_phi));
-  }
-  S.alpha_min = op.gamma_alpha * amin;
-  S.ls = 0; S.accepted = 0; S.armijo = 0;
+  S.alpha_min = alpha_min23(D.o, S.theta, S.theta_min, dphi);
+  S.ls = 0; S.accepted = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; S.soc_p = 0;
   atomicAdd(&D.cnt[2], 1);
+}
+
+// ---- second-order correction (paper section 2.4, A-5.5 .. A-5.9): the same matrix, c replaced by c_soc = alpha c_soc + c(trial)
+__global__ void ipm_soc_rhs_kernel(IpmDev D) {
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || !S.soc_req) return;
+  const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
+  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  double* rhs = D.rhs + size_t(bi) * D.Nt;
+  const bool first = S.soc_p == 0;
+  const double mix = first ? S.alpha : S.alpha_soc, mu = S.mu;
+  for (int r = t0; r < D.m; r += stride) {
+    const double cs = mix * (first ? D.c[om + r] : D.csoc[om + r]) + D.ct[om + r];
+    D.csoc[om + r] = cs;
+    rhs[D.pos[D.nv + r]] = -cs;
+  }
+  for (int i = t0; i < D.nv; i += stride) {
+    const double l = D.vl[o + i], u = D.vu[o + i];
+    double r = 0.0;
+    if (l != u) {
+      r = D.glag[o + i];
+      if (l > -IPM_INF) r -= mu / (D.v[o + i] - l);
+      if (u < IPM_INF) r += mu / (u - D.v[o + i]);
+    }
+    rhs[D.pos[i]] = -r;
+  }
+}
+__global__ __launch_bounds__(256) void ipm_soc_direction_kernel(IpmDev D) {
+  __shared__ double sh[4];
+  const int bi = blockIdx.x;
+  IpmInst& S = D.inst[bi];
+  const int go = S.status == 0 && S.soc_req;
+  __syncthreads();
+  if (!go) return;
+  double amax, az, dphi, bad;
+  newton_step(D, bi, D.rhs + size_t(bi) * D.Nt, D.dv2, D.dlam2, D.dzL2, D.dzU2, S.mu, S.tau, sh, &amax, &az, &dphi, &bad);
+  if (threadIdx.x != 0) return;
+  S.soc_req = 0;
+  if (bad != 0) { S.soc_on = 0; S.alpha = 0.5 * S.alpha; S.ls += 1; return; }   // no usable correction: back to the plain backtracking
+  S.alpha_soc = amax; S.az_soc = az;
 }
 
 // ------------------------------------------------------------------------------------------------ line search
@@ -787,21 +925,26 @@ __global__ void ipm_trial_kernel(IpmDev D) {
   const IpmInst& S = D.inst[bi];
   if (S.status != 0 || S.accepted) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < D.n) D.xt[size_t(bi) * D.n + i] = D.v[size_t(bi) * D.nv + i] + S.alpha * D.dv[size_t(bi) * D.nv + i];
+  if (i >= D.n) return;
+  const size_t o = size_t(bi) * D.nv + i;
+  D.xt[size_t(bi) * D.n + i] = S.soc_on ? D.v[o] + S.alpha_soc * D.dv2[o] : D.v[o] + S.alpha * D.dv[o];
 }
 __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
   __shared__ double sh[4];
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
-  if (S.status != 0 || S.accepted) return;
-  const size_t o = size_t(bi) * D.nv;
-  const double a = S.alpha;
-  double th = 0.0, ln = 0.0, bad = 0.0, csq = 0.0, qd = 0.0;
-  const bool resto = S.mode == 1;
+  const int go = S.status == 0 && !S.accepted, mode = S.mode, soc = S.soc_on;
+  const double a = soc ? S.alpha_soc : S.alpha;
+  __syncthreads();
+  if (!go) return;
+  const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
+  const double* dvp = soc ? D.dv2 : D.dv;
+  double th = 0.0, ln = 0.0, bad = 0.0, qd = 0.0, spn = 0.0, lnpn = 0.0;
+  const bool resto = mode == 2;
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
     if (l == u) continue;
-    const double vt = D.v[o + i] + a * D.dv[o + i];
+    const double vt = D.v[o + i] + a * dvp[o + i];
     if (l > -IPM_INF) ln += log(vt - l);
     if (u < IPM_INF) ln += log(u - vt);
     if (resto) { const double dd = vt - D.vR[o + i]; qd += D.dr2[o + i] * dd * dd; }
@@ -809,21 +952,44 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
   for (int r = t; r < D.m; r += blockDim.x) {
     const int s = D.row_slack[r];
     const double gr = D.gt[size_t(bi) * D.sg + r];
-    const double cr = s < 0 ? gr - D.gl[r] : gr - (D.v[o + D.n + s] + a * D.dv[o + D.n + s]);
+    double cr = s < 0 ? gr - D.gl[r] : gr - (D.v[o + D.n + s] + a * dvp[o + D.n + s]);
+    D.ct[om + r] = cr;
+    if (resto) {
+      const double pt = D.pp[om + r] + a * D.dpp[om + r], nt = D.nn[om + r] + a * D.dnn[om + r];
+      cr += nt - pt;
+      spn += pt + nt;
+      lnpn += log(pt) + log(nt);
+    }
     if (!(fabs(cr) < 1e300)) bad = 1;
     th += fabs(cr);
-    csq += cr * cr;
   }
   th = block_red(th, 0, sh); ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh);
-  if (resto) { csq = block_red(csq, 0, sh); qd = block_red(qd, 0, sh); }
+  if (resto) { qd = block_red(qd, 0, sh); spn = block_red(spn, 0, sh); lnpn = block_red(lnpn, 0, sh); }
   if (t != 0) return;
   const IpmOpts& op = D.o;
-  if (resto) {                  // Armijo on psi = 1/2 |c|^2 + zeta/2 |D_R (v - v_R)|^2 - mu sum ln
-    const double psit = 0.5 * csq + 0.5 * S.zeta * qd - S.mu * ln;
-    if (bad == 0 && fabs(psit) < 1e300 && psit <= S.psi + 1e-4 * a * S.slope) { S.accepted = 1; return; }
+  if (resto) {                  // the restoration problem's own filter line search
+    const double phit = op.resto_rho * spn + 0.5 * S.zeta * qd - S.mu_r * (ln + lnpn);
+    const double slack = 10.0 * 2.220446049250313e-16 * fabs(S.phi_r);
+    bool ok = false;
+    if (bad == 0 && fabs(phit) < 1e300 && th <= S.thr_max) {
+      bool dominated = false;
+      const double* F = D.rfilt + size_t(bi) * 2 * IPM_FMAX;
+      for (int k = 0; k < S.nrfilt; ++k)
+        if (th >= F[2 * k] && phit >= F[2 * k + 1]) dominated = true;
+      if (!dominated) {
+        const bool sw = S.dphi < 0 && a * pow(-S.dphi, op.s_phi) > op.delta * pow(S.th_r, op.s_theta);
+        if (S.th_r <= S.thr_min && sw) {
+          ok = phit - S.phi_r - op.eta_phi * a * S.dphi <= slack;
+          if (ok) S.armijo = 1;
+        } else {
+          ok = th <= (1.0 - op.gamma_theta) * S.th_r || phit - (S.phi_r - op.gamma_phi * S.th_r) <= slack;
+        }
+      }
+    }
+    if (ok) { S.accepted = 1; return; }
     S.alpha = 0.5 * a;
     S.ls += 1;
-    if (S.ls >= op.max_ls) { S.status = 3; return; }
+    if (S.alpha < S.alpha_min || S.ls > op.max_ls) { S.status = 3; return; }     // the restoration failed
     atomicAdd(&D.cnt[2], 1);
     return;
   }
@@ -831,6 +997,7 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
   if (!(fabs(ft) < 1e300) || !(fabs(ln) < 1e300)) bad = 1;
   const double phit = ft - S.mu * ln;
   const double slack = 10.0 * 2.220446049250313e-16 * fabs(S.phi);     // Ipopt's rounding allowance in the phi comparisons
+  const double a_test = S.alpha;       // the switching / Armijo tests of a corrected step use the uncorrected step length (A-5.7)
   bool ok = false;
   if (bad == 0 && th <= S.theta_max) {
     bool dominated = false;
@@ -838,17 +1005,34 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
     for (int k = 0; k < S.nfilt; ++k)
       if (th >= F[2 * k] && phit >= F[2 * k + 1]) dominated = true;
     if (!dominated) {
-      const bool sw = S.dphi < 0 && a * pow(-S.dphi, op.s_phi) > op.delta * pow(S.theta, op.s_theta);   // (19)
+      const bool sw = S.dphi < 0 && a_test * pow(-S.dphi, op.s_phi) > op.delta * pow(S.theta, op.s_theta);   // (19)
       if (S.theta <= S.theta_min && sw) {
-        ok = phit - S.phi - op.eta_phi * a * S.dphi <= slack;                                             // (20)
+        ok = phit - S.phi - op.eta_phi * a_test * S.dphi <= slack;                                            // (20)
         if (ok) S.armijo = 1;
       } else {
-        ok = th <= (1.0 - op.gamma_theta) * S.theta || phit - (S.phi - op.gamma_phi * S.theta) <= slack;  // (18)
+        ok = th <= (1.0 - op.gamma_theta) * S.theta || phit - (S.phi - op.gamma_phi * S.theta) <= slack;      // (18)
       }
     }
   }
-  if (ok) { S.accepted = 1; return; }
-  S.alpha = 0.5 * a;
+  if (ok) {
+    S.accepted = 1;
+    if (soc) { S.use_soc = 1; S.n_soc += 1; }
+    return;
+  }
+  const bool th_ok = fabs(th) < 1e300 && bad == 0;
+  if (soc) {
+    if (th_ok && S.soc_p + 1 < op.max_soc && th <= op.kappa_soc * S.th_old_soc) {      // A-5.9: next correction
+      S.soc_p += 1; S.th_old_soc = th; S.soc_req = 1;
+      atomicAdd(&D.cnt[3], 1);
+      return;
+    }
+    S.soc_on = 0;                                                                       // give up: plain backtracking
+  } else if (S.ls == 0 && op.max_soc > 0 && th_ok && th >= S.theta) {                   // A-5.5
+    S.soc_on = 1; S.soc_p = 0; S.th_old_soc = S.theta; S.soc_req = 1;
+    atomicAdd(&D.cnt[3], 1);
+    return;
+  }
+  S.alpha = 0.5 * S.alpha;
   S.ls += 1;
   if (S.alpha < S.alpha_min || S.ls > op.max_ls) {
     if (S.err0 <= op.acceptable_tol) S.status = 6;             // nothing left to gain: Ipopt reports the acceptable level here too
@@ -865,16 +1049,31 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
   IpmInst& S = D.inst[bi];
   // every thread reads the instance's verdicts BEFORE thread 0 changes any of them (a late wave must not see
   // enter_resto already cleared, or mode already switched, and skip its slice)
-  const int s_status = S.status, s_enter = S.enter_resto, s_accepted = S.accepted, s_mode = S.mode;
-  const double s_alpha = S.alpha, s_alpha_z = S.alpha_z, s_mu = S.mu;
+  const int s_status = S.status, s_enter = S.enter_resto, s_accepted = S.accepted, s_mode = S.mode, s_skip = S.skip_update, s_soc = S.use_soc;
+  const double s_alpha = s_soc ? S.alpha_soc : S.alpha, s_alpha_z = s_soc ? S.az_soc : S.alpha_z, s_mu = S.mu, s_mu_r = S.mu_r, s_cinf = S.cinf;
   __syncthreads();
   if (s_status != 0) return;
-  const size_t o = size_t(bi) * D.nv;
-  if (s_enter) {          // the line search gave up at an infeasible point: start the feasibility restoration from it
+  const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
+  const double ks = D.o.kappa_sigma;
+  if (s_skip) {           // this pass only replaced lambda (least-squares multipliers after the restoration)
+    if (t == 0) { S.skip_update = 0; S.n_resto += 1; }
+    return;
+  }
+  if (s_enter) {          // the line search gave up at an infeasible point: start the restoration phase from it
+    const double rho = D.o.resto_rho, mu_r = fmax(s_mu, s_cinf);
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double vi = D.v[o + i], sc = fmax(1.0, fabs(vi));
       D.vR[o + i] = vi;
       D.dr2[o + i] = 1.0 / (sc * sc);
+      D.zL[o + i] = fmin(rho, D.zL[o + i]);
+      D.zU[o + i] = fmin(rho, D.zU[o + i]);
+    }
+    for (int r = t; r < D.m; r += blockDim.x) {     // (33), (34): the p, n that minimise the restoration's barrier objective at v_R
+      const double c = D.c[om + r], h2 = (mu_r - rho * c) / (2.0 * rho);
+      const double nn = h2 + sqrt(h2 * h2 + mu_r * c / (2.0 * rho)), pp = c + nn;
+      D.nn[om + r] = nn; D.pp[om + r] = pp;
+      D.zp[om + r] = mu_r / pp; D.zn[om + r] = mu_r / nn;
+      D.lam[om + r] = 0.0;
     }
     if (t == 0) {
       if (S.nfilt < IPM_FMAX) {
@@ -883,40 +1082,55 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
         F[2 * S.nfilt + 1] = S.phi - D.o.gamma_phi * S.theta;
         S.nfilt += 1;
       }
-      S.th0 = S.theta; S.zeta = sqrt(S.mu); S.mode = 1; S.resto_it = 0; S.enter_resto = 0;
+      S.th0 = S.theta; S.mu_r = mu_r; S.zeta = sqrt(mu_r); S.mode = 2; S.resto_it = 0; S.enter_resto = 0; S.nrfilt = 0;
     }
     return;
   }
   if (!s_accepted) return;
-  if (s_mode == 1) {
-    for (int i = t; i < D.nv; i += blockDim.x)
-      if (D.vl[o + i] != D.vu[o + i]) D.v[o + i] += s_alpha * D.dv[o + i];
+  if (s_mode == 2) {
+    const double a = s_alpha, az = s_alpha_z, mu = s_mu_r;
+    for (int i = t; i < D.nv; i += blockDim.x) {
+      const double l = D.vl[o + i], u = D.vu[o + i];
+      if (l == u) continue;
+      const double vi = D.v[o + i] + a * D.dv[o + i];
+      D.v[o + i] = vi;
+      if (l > -IPM_INF) D.zL[o + i] = reset16(D.zL[o + i] + az * D.dzL[o + i], vi - l, mu, ks);
+      if (u < IPM_INF) D.zU[o + i] = reset16(D.zU[o + i] + az * D.dzU[o + i], u - vi, mu, ks);
+    }
+    for (int r = t; r < D.m; r += blockDim.x) {
+      const double pp = D.pp[om + r] + a * D.dpp[om + r], nn = D.nn[om + r] + a * D.dnn[om + r];
+      D.pp[om + r] = pp; D.nn[om + r] = nn;
+      D.zp[om + r] = reset16(D.zp[om + r] + az * D.dzp[om + r], pp, mu, ks);
+      D.zn[om + r] = reset16(D.zn[om + r] + az * D.dzn[om + r], nn, mu, ks);
+      D.lam[om + r] += a * D.dlam[om + r];
+    }
     if (t == 0) {
+      if (!S.armijo && S.nrfilt < IPM_FMAX) {
+        double* F = D.rfilt + size_t(bi) * 2 * IPM_FMAX;
+        F[2 * S.nrfilt] = (1.0 - D.o.gamma_theta) * S.th_r;
+        F[2 * S.nrfilt + 1] = S.phi_r - D.o.gamma_phi * S.th_r;
+        S.nrfilt += 1;
+      }
       if (D.trace && S.iter < D.trace_cap) {
         double* R = D.trace + (size_t(bi) * D.trace_cap + S.iter) * IPM_TRACE;
-        R[0] = S.f; R[1] = S.theta; R[2] = S.mu; R[3] = S.alpha; R[4] = 0.0; R[5] = 0.0; R[6] = S.err0; R[7] = -1.0;
+        R[0] = S.f; R[1] = S.theta; R[2] = S.mu_r; R[3] = a; R[4] = az; R[5] = 0.0; R[6] = S.err0; R[7] = -1.0;
       }
       S.resto_it += 1;
       S.iter += 1;
     }
     return;
   }
-  const double a = s_alpha, az = s_alpha_z, mu = s_mu, ks = D.o.kappa_sigma;
+  const double a = s_alpha, az = s_alpha_z, mu = s_mu;
+  const double *dv = s_soc ? D.dv2 : D.dv, *dlam = s_soc ? D.dlam2 : D.dlam, *dzL = s_soc ? D.dzL2 : D.dzL, *dzU = s_soc ? D.dzU2 : D.dzU;
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
     if (l == u) continue;
-    const double vi = D.v[o + i] + a * D.dv[o + i];
+    const double vi = D.v[o + i] + a * dv[o + i];
     D.v[o + i] = vi;
-    if (l > -IPM_INF) {
-      const double s = vi - l;
-      D.zL[o + i] = fmax(fmin(D.zL[o + i] + az * D.dzL[o + i], ks * mu / s), mu / (ks * s));   // (16)
-    }
-    if (u < IPM_INF) {
-      const double s = u - vi;
-      D.zU[o + i] = fmax(fmin(D.zU[o + i] + az * D.dzU[o + i], ks * mu / s), mu / (ks * s));
-    }
+    if (l > -IPM_INF) D.zL[o + i] = reset16(D.zL[o + i] + az * dzL[o + i], vi - l, mu, ks);   // (16)
+    if (u < IPM_INF) D.zU[o + i] = reset16(D.zU[o + i] + az * dzU[o + i], u - vi, mu, ks);
   }
-  for (int r = t; r < D.m; r += blockDim.x) D.lam[size_t(bi) * D.m + r] += a * D.dlam[size_t(bi) * D.m + r];
+  for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] += a * dlam[om + r];
   if (t == 0) {
     if (!S.armijo && S.nfilt < IPM_FMAX) {       // (22)
       double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
@@ -926,7 +1140,7 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
     }
     if (D.trace && S.iter < D.trace_cap) {
       double* R = D.trace + (size_t(bi) * D.trace_cap + S.iter) * IPM_TRACE;
-      R[0] = S.f; R[1] = S.theta; R[2] = S.mu; R[3] = S.alpha; R[4] = S.alpha_z; R[5] = S.delta_w; R[6] = S.err0; R[7] = double(S.ls);
+      R[0] = S.f; R[1] = S.theta; R[2] = S.mu; R[3] = a; R[4] = az; R[5] = S.delta_w; R[6] = S.err0; R[7] = double(S.ls);
     }
     S.iter += 1;
   }
@@ -967,6 +1181,13 @@ void ipm_launch_accept(const IpmDev& D, hipStream_t st) {
 void ipm_launch_update(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_update_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
 }
+void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st) {
+  const int blocks = std::max(1, std::min(64, (std::max(D.nv, D.m) + 255) / 256));
+  hipLaunchKernelGGL(ipm_soc_rhs_kernel, dim3(unsigned(blocks), unsigned(D.B)), dim3(256), 0, st, D);
+}
+void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_soc_direction_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+}
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
   if (p.nd) return p.max_factor_lds;
   return (size_t(p.b + 8) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
@@ -996,7 +1217,7 @@ __global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int
 __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __restrict__ dst, const int* __restrict__ src, int n, int mode,
                                const IpmInst* inst, int check_status) {
   const int bi = blockIdx.y;
-  if (check_status && inst[bi].status != 0) return;
+  if (check_status && (inst[bi].status != 0 || (check_status == 2 && !inst[bi].soc_req))) return;
   double* v = vall + size_t(bi) * vstride;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[dst[i]] = mode ? v[src[i]] : 0.0;
 }

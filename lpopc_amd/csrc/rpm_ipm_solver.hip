@@ -23,7 +23,7 @@ struct rpm_ipm {
   int factor_mt = IPM_MT;
   std::string err;
   std::vector<IpmInst> h_inst;
-  int total_factorizations = 0, total_iterations = 0, total_trials = 0;
+  int total_factorizations = 0, total_iterations = 0, total_trials = 0, total_soc = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // around the factorisation and the substitution of an iteration
   double factor_ms = 0.0, solve_ms = 0.0;
   bool solve_pending = false;
@@ -142,6 +142,15 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc(h, &D.obj, B)); A_(ipm_alloc(h, &D.gt, B * size_t(D.sg))); A_(ipm_alloc(h, &D.objt, B));
   A_(ipm_alloc(h, &D.inst, B)); A_(ipm_alloc(h, &D.cnt, size_t(4)));
   A_(ipm_alloc(h, &D.vR, B * p.nv)); A_(ipm_alloc(h, &D.dr2, B * p.nv));
+  A_(ipm_alloc(h, &D.vl0, B * p.nv)); A_(ipm_alloc(h, &D.vu0, B * p.nv));
+  {   // restoration phase and second-order correction work space (m >= 1 keeps the allocations non-empty)
+    const size_t Bm = B * size_t(std::max(p.m, 1));
+    A_(ipm_alloc(h, &D.pp, Bm)); A_(ipm_alloc(h, &D.nn, Bm)); A_(ipm_alloc(h, &D.zp, Bm)); A_(ipm_alloc(h, &D.zn, Bm));
+    A_(ipm_alloc(h, &D.dpp, Bm)); A_(ipm_alloc(h, &D.dnn, Bm)); A_(ipm_alloc(h, &D.dzp, Bm)); A_(ipm_alloc(h, &D.dzn, Bm));
+    A_(ipm_alloc(h, &D.dlam2, Bm)); A_(ipm_alloc(h, &D.csoc, Bm)); A_(ipm_alloc(h, &D.ct, Bm));
+    A_(ipm_alloc(h, &D.dv2, B * p.nv)); A_(ipm_alloc(h, &D.dzL2, B * p.nv)); A_(ipm_alloc(h, &D.dzU2, B * p.nv));
+    A_(ipm_alloc(h, &D.rfilt, B * 2 * IPM_FMAX));
+  }
   {   // factorisation sub-problems: the whole band + border matrix, or the interval blocks followed by the separator system
     std::vector<KktSub> subs;
     if (p.nd) {
@@ -167,8 +176,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     std::vector<double> l(B * p.nv, 0.0), u(B * p.nv, 0.0);
     for (size_t bi = 0; bi < B; ++bi)
       for (int i = 0; i < p.n; ++i) { l[bi * p.nv + i] = e.xl[i]; u[bi * p.nv + i] = e.xu[i]; }
-    if (hipMemcpy(D.vl, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(D.vu, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy"; return fail(RPM_E_DEVICE); }
+    if (hipMemcpy(D.vl0, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(D.vu0, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy"; return fail(RPM_E_DEVICE); }
   }
   h->factor_mt = p.max_rows <= 256 ? 4 : (p.max_rows <= 384 ? 6 : IPM_MT);
   if (p.max_rows > 4 * IPM_MT * 16) {
@@ -206,6 +215,9 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "acceptable_tol") o.acceptable_tol = value;
   else if (k == "acceptable_iter") o.acceptable_iter = int(value);
   else if (k == "restoration_max_iter") o.resto_max = int(value);
+  else if (k == "bound_relax_factor") { if (!(value >= 0.0)) { h->err = "bound_relax_factor must be >= 0"; return RPM_E_INVALID; } o.bound_relax = value; }
+  else if (k == "max_soc") o.max_soc = std::max(0, int(value));
+  else if (k == "restoration_penalty") o.resto_rho = value;
   else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
     const int cap = int(value);
     if (cap < 0 || cap > 100000) { h->err = "trace: 0 ... 100000 records"; return RPM_E_INVALID; }
@@ -289,8 +301,8 @@ int rpm_ipm_set_bounds(rpm_ipm* h, int instance, const double* x_l, const double
       h->err = "rpm_ipm_set_bounds: variable " + std::to_string(i) + " changes between fixed and free (the KKT layout is shared by all instances)";
       return RPM_E_INVALID;
     }
-  IPM_TRY(h, hipMemcpy(h->D.vl + size_t(instance) * p.nv, x_l, p.n * sizeof(double), hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy(h->D.vu + size_t(instance) * p.nv, x_u, p.n * sizeof(double), hipMemcpyHostToDevice));
+  IPM_TRY(h, hipMemcpy(h->D.vl0 + size_t(instance) * p.nv, x_l, p.n * sizeof(double), hipMemcpyHostToDevice));
+  IPM_TRY(h, hipMemcpy(h->D.vu0 + size_t(instance) * p.nv, x_u, p.n * sizeof(double), hipMemcpyHostToDevice));
   return RPM_OK;
 }
 
@@ -307,9 +319,9 @@ int rpm_ipm_set_all_bounds(rpm_ipm* h, const double* x_l, const double* x_u) {
                  " changes between fixed and free (the KKT layout is shared by all instances)";
         return RPM_E_INVALID;
       }
-  IPM_TRY(h, hipMemcpy2D(h->D.vl, size_t(p.nv) * sizeof(double), x_l, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
+  IPM_TRY(h, hipMemcpy2D(h->D.vl0, size_t(p.nv) * sizeof(double), x_l, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
                          hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy2D(h->D.vu, size_t(p.nv) * sizeof(double), x_u, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
+  IPM_TRY(h, hipMemcpy2D(h->D.vu0, size_t(p.nv) * sizeof(double), x_u, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
                          hipMemcpyHostToDevice));
   return RPM_OK;
 }
@@ -407,7 +419,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   hipStream_t st = static_cast<hipStream_t>(dev_stream(e));
   const unsigned B = unsigned(D.B);
   auto eng_fail = [&](int rc) { h->err = e.err; return rc; };
-  h->total_factorizations = h->total_iterations = h->total_trials = 0;
+  h->total_factorizations = h->total_iterations = h->total_trials = h->total_soc = 0;
   h->factor_ms = h->solve_ms = 0.0;
   h->solve_pending = false;
   if (D.sg != e.stride_g() || D.sv != e.stride_values()) {   // rpm_set_option refuses this while a solver is attached; belt and braces
@@ -455,13 +467,22 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
     if ((rc = factor_and_solve_launch(h, st, false, true, 1))) return rc;
     IPM_TRY(h, hipEventRecord(h->ev[3], st));
     h->solve_pending = true;
-    IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, sizeof(int), st));
+    IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, 2 * sizeof(int), st));
     ipm_launch_direction(D, st);
-    for (int ls = 0; ls <= D.o.max_ls + 1; ++ls) {
+    // line search rounds: every pending instance evaluates one trial point per round — its next backtracking step, or the
+    // next second-order correction (right-hand side, substitution with the factors in place, step lengths) where one was asked for
+    h->h_cnt[3] = 0;
+    for (int ls = 0; ls <= D.o.max_ls + D.o.max_soc + 2; ++ls) {
+      if (h->h_cnt[3] > 0) {
+        ipm_launch_soc_rhs(D, st);
+        if ((rc = factor_and_solve_launch(h, st, false, true, 2))) return rc;
+        ipm_launch_soc_direction(D, st);
+        h->total_soc += 1;
+      }
       ipm_launch_trial(D, st);
       if ((rc = dev_eval_obj(e, D.xt, D.objt, nullptr, st))) return eng_fail(rc);
       if ((rc = dev_eval_cons(e, D.xt, D.gt, nullptr, 1 | 4, st))) return eng_fail(rc);
-      IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, sizeof(int), st));
+      IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, 2 * sizeof(int), st));
       ipm_launch_accept(D, st);
       h->total_trials += 1;
       if ((rc = fetch_counts(h, st))) return rc;
@@ -470,7 +491,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
         if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->solve_ms += ms;
         h->solve_pending = false;
       }
-      if (h->h_cnt[2] == 0) break;
+      if (h->h_cnt[2] == 0 && h->h_cnt[3] == 0) break;
     }
     ipm_launch_update(D, st);
     if ((rc = launch_check(h, "ipm iteration"))) return rc;

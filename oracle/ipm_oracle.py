@@ -8,10 +8,22 @@ algorithm for large-scale nonlinear programming", Math. Program. 106 (2006) — 
   optimality error (5)/(6), barrier update (7), tau (8), primal-dual system (13) with dz from (12), fraction to the
   boundary (15), multiplier reset (16), filter acceptance (18)-(20), filter update (22), alpha_min (23), inertia
   correction Algorithm IC, initial point section 3.6 (bound_push / bound_frac), constants = Ipopt 3.12 defaults.
-Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): Ipopt's restoration phase (its place is
-taken by a much simpler Gauss-Newton feasibility restoration, _restore below, built from the same KKT kernels), second-order
-correction, adaptive barrier update (the reference sets mu_strategy=adaptive; monotone here), NLP scaling, least-squares
-multiplier initialisation (lambda_0 = 0).  One deviation: the constraint regularisation delta_c = 1e-8 is always on
+Restated in round 2 (what the metric problem, Delta-III, turned out to need — tools/exp/ has the experiments):
+  * bound_relax_factor (Ipopt option, default 1e-8): every finite bound of a free variable / inequality row is moved out
+    by 1e-8 max(1,|bound|) before anything else.  Delta-III has no strict interior without it (burn rates and phase
+    durations are fixed, so each phase's final mass EQUALS its lower bound by the dynamics alone);
+  * the second-order correction (paper section 2.4, steps A-5.5 .. A-5.9; max_soc 4, kappa_soc 0.99);
+  * the restoration phase (paper section 3.3): min rho |p + n|_1 + zeta/2 |D_R (v - v_R)|^2 s.t. c(v) - p + n = 0,
+    p, n >= 0 and the bounds, rho = 1000, zeta = sqrt(mu), solved by the same interior-point iteration (monotone mu, own
+    filter) with p, n eliminated from the Newton system — [[zeta D_R^2 + Sigma_v, A^T], [A, -(Sigma_p^-1 + Sigma_n^-1)]],
+    the same matrix structure as (13) — starting values (33)/(34), return when the infeasibility is kappa_resto = 0.9
+    of where it entered and the original filter accepts the point; then least-squares multipliers (section 3.6,
+    lambda = 0 when they exceed 1e3).  One simplification: the restoration problem's Hessian leaves out the constraint
+    curvature sum lambda_j Hess c_j (a Gauss-Newton model of it: no inertia correction is ever needed there).
+Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): adaptive barrier update (the reference sets
+mu_strategy=adaptive; monotone here — a LOQO-rule variant in tools/exp/ converges on Delta-III too, in twice the
+iterations), NLP scaling, least-squares multipliers at the very first iterate (lambda_0 = 0), watchdog.  One deviation:
+the constraint regularisation delta_c = 1e-8 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
 Parity status: UNPINNED by the reference (it holds no solver traces); pinned here by known optima and by scipy.
 
@@ -27,7 +39,9 @@ INF = 1e19
 DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, bound_push=1e-2,
                 bound_frac=1e-2, kappa_sigma=1e10, s_max=100.0, gamma_theta=1e-5, gamma_phi=1e-8, eta_phi=1e-8, delta=1.0,
                 s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-8, delta_w_first=1e-4, delta_w_min=1e-20,
-                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=60, kappa_resto=0.9, acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense")
+                delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=300, kappa_resto=0.9,
+                acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense", bound_relax_factor=1e-8, max_soc=4, kappa_soc=0.99,
+                resto_rho=1000.0, mult_reset=1e3)
 
 
 def _n_positive(K):
@@ -82,10 +96,15 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
     row_slack[ineq] = np.arange(ns)
     vl, vu = np.concatenate([xl, gl[ineq]]), np.concatenate([xu, gu[ineq]])
     free = vl != vu
+    rel = o["bound_relax_factor"]                      # Ipopt's bound_relax_factor: finite bounds of free unknowns move out
+    if rel > 0:
+        vl = np.where(free & (vl > -INF), vl - rel * np.maximum(1.0, np.abs(vl)), vl)
+        vu = np.where(free & (vu < INF), vu + rel * np.maximum(1.0, np.abs(vu)), vu)
     lo, up = free & (vl > -INF), free & (vu < INF)
+    fxi = np.nonzero(~free)[0]
 
-    x = np.where(xl == xu, xl, _push(np.asarray(x0, float), xl, xu, o))
-    s = _push(orc.eval_g(x)[ineq], gl[ineq], gu[ineq], o)
+    x = np.where(xl == xu, xl, _push(np.asarray(x0, float), vl[:n], vu[:n], o))
+    s = _push(orc.eval_g(x)[ineq], vl[n:], vu[n:], o)
     v = np.concatenate([x, s])
     zL, zU = lo.astype(float), up.astype(float)
     lam = np.zeros(m)
@@ -101,76 +120,154 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
     def lnsum(vv):
         return np.log(vv[lo] - vl[lo]).sum() + np.log(vu[up] - vv[up]).sum()
 
+    def jac_dense(jv):
+        A = np.zeros((m, nv))
+        A[ji, jj] = jv
+        A[ineq, n + np.arange(ns)] = -1.0
+        return A
+
+    def kkt(diag11, W, A, diag22):
+        K = np.zeros((nv + m, nv + m))
+        K[:nv, :nv] = np.diag(diag11) if W is None else W + np.diag(diag11)
+        K[nv:, :nv] = A
+        K[:nv, nv:] = A.T
+        K[nv:, nv:] = -np.diag(diag22)
+        K[fxi, :] = 0.0                                   # fixed variables stay as identity rows
+        K[:, fxi] = 0.0
+        K[fxi, fxi] = 1.0
+        return K
+
+    def reset16(z, sl_, mu_, present):
+        ks = o["kappa_sigma"]
+        return np.where(present, np.maximum(np.minimum(z, ks * mu_ / sl_), mu_ / (ks * sl_)), 0.0)
+
+    def ftb(w_, dw_, tau_, sign=-1.0):
+        """fraction to the boundary (15) for w + a dw >= (1 - tau) w"""
+        k = dw_ < 0
+        return float(np.min(-tau_ * w_[k] / dw_[k])) if k.any() else 1.0
+
     n_resto = n_acc = 0
 
     def _restore():
-        """Feasibility restoration (NOT Ipopt's l1 restoration NLP; see the module header): damped Gauss-Newton on
-        psi(v) = 1/2 |c(v)|^2 + zeta/2 |D_R (v - v_R)|^2 - mu sum ln(bound slacks), zeta = sqrt(mu), D_R = diag(1/max(1,|v_R|)),
-        each step from the same KKT matrix with W = zeta D_R^2 + mu/s^2 and -I in the constraint block, until the
-        infeasibility has dropped to kappa_resto = 0.9 of where the line search gave up and the point is acceptable to the
-        filter.  Returns None (back to the regular iteration, lambda = 0, bound multipliers clipped) or status 3."""
+        """Ipopt's restoration phase (paper section 3.3) with p, n eliminated from the Newton system; see the module header.
+        Returns None (back to the regular iteration) or a status (3 restoration failed, 2 iteration limit)."""
         nonlocal v, lam, zL, zU, it, n_resto
         filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))
+        rho = o["resto_rho"]
         vR, th0 = v.copy(), theta
-        Dr2 = 1.0 / np.maximum(1.0, np.abs(vR)) ** 2
-        zeta = np.sqrt(mu)
+        Dr2 = np.where(free, 1.0 / np.maximum(1.0, np.abs(vR)) ** 2, 0.0)
+        mu_r = max(mu, float(np.max(np.abs(c))))
+        zeta = np.sqrt(mu_r)
+        t_ = (mu_r - rho * c) / (2 * rho)                                                           # (33)
+        nn = t_ + np.sqrt(t_ ** 2 + mu_r * c / (2 * rho))
+        pp = c + nn                                                                                 # (34)
+        zp, zn = mu_r / pp, mu_r / nn
+        zL = np.where(lo, np.minimum(rho, zL), 0.0)
+        zU = np.where(up, np.minimum(rho, zU), 0.0)
+        lam = np.zeros(m)
+        rfilt = []
+        thr_max = thr_min = None
+        mu_min = o["tol"] / 10.0
         for itr in range(o["resto_max"] + 1):
             xr = v[:n]
-            gR, jR, fR = orc.eval_g(xr), orc.eval_jac_g(xr), orc.eval_f(xr)
+            gR, jR, fo = orc.eval_g(xr), orc.eval_jac_g(xr), orc.eval_f(xr)
             cR = cons(v, gR)
-            thR, lnR = np.abs(cR).sum(), lnsum(v)
-            if itr > 0 and thR <= o["kappa_resto"] * th0 and thR <= theta_max and \
-                    not any(thR >= a_ and fR - mu * lnR >= b_ for a_, b_ in filt):
-                lam = np.zeros(m)
-                sl_, su_ = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
-                ks = o["kappa_sigma"]
-                zL = np.where(lo, np.maximum(np.minimum(np.minimum(zL, 1e3), ks * mu / sl_), mu / (ks * sl_)), 0.0)
-                zU = np.where(up, np.maximum(np.minimum(np.minimum(zU, 1e3), ks * mu / su_), mu / (ks * su_)), 0.0)
+            th_o, ln_b = np.abs(cR).sum(), lnsum(v)
+            if itr > 0 and th_o <= o["kappa_resto"] * th0 and th_o <= theta_max and \
+                    not any(th_o >= a_ and fo - mu * ln_b >= b_ for a_, b_ in filt):
+                dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
+                zL = reset16(np.minimum(zL, 1e3), dl, mu, lo)
+                zU = reset16(np.minimum(zU, 1e3), du, mu, up)
+                # least-squares multipliers (section 3.6): [[I, A^T], [A, -delta_c]] [w; lambda] = -[grad f - zL + zU; 0]
+                gf = np.zeros(nv)
+                gf[:n] = orc.eval_grad_f(xr)
+                K = kkt(np.ones(nv), None, jac_dense(jR), o["delta_c"] * np.ones(m))
+                sol = np.linalg.solve(K, -np.concatenate([np.where(free, gf - zL + zU, 0.0), np.zeros(m)]))
+                lam = sol[nv:] if np.max(np.abs(sol[nv:])) <= o["mult_reset"] else np.zeros(m)
                 n_resto += 1
                 return None
             if itr == o["resto_max"]:
                 return 3
-            A = np.zeros((m, nv))
-            A[ji, jj] = jR
-            A[ineq, n + np.arange(ns)] = -1.0
-            sl_, su_ = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
-            Md = zeta * Dr2 + np.where(lo, mu / sl_ ** 2, 0.0) + np.where(up, mu / su_ ** 2, 0.0)
-            gb = zeta * Dr2 * (v - vR) - np.where(lo, mu / sl_, 0.0) + np.where(up, mu / su_, 0.0)
-            K = np.zeros((nv + m, nv + m))
-            K[:nv, :nv] = np.diag(Md)
-            K[nv:, :nv] = A
-            K[:nv, nv:] = A.T
-            K[nv:, nv:] = -np.eye(m)
-            fxi = np.nonzero(~free)[0]
-            K[fxi, :] = 0.0
-            K[:, fxi] = 0.0
-            K[fxi, fxi] = 1.0
-            sol = np.linalg.solve(K, -np.concatenate([np.where(free, gb, 0.0), cR]))
-            d, w = np.where(free, sol[:nv], 0.0), sol[nv:]
-            ar = 1.0
-            k = lo & (d < 0)
-            if k.any():
-                ar = min(ar, np.min(-tau * sl_[k] / d[k]))
-            k = up & (d > 0)
-            if k.any():
-                ar = min(ar, np.min(tau * su_[k] / d[k]))
-            psi = 0.5 * cR @ cR + 0.5 * zeta * np.sum(Dr2 * (v - vR) ** 2) - mu * lnR
-            slope = float((w - cR) @ cR + np.where(free, gb, 0.0) @ d)          # (A d)^T c + g_b^T d,  A d = w - c
-            moved = False
-            for _ in range(o["max_ls"]):
-                vt = v + ar * d
+            if it >= o["max_iter"]:
+                return 2
+            A = jac_dense(jR)
+            rc = cR - pp + nn
+            th_r = np.abs(rc).sum()
+            if thr_max is None:
+                thr_max, thr_min = 1e4 * max(1.0, th_r), 1e-4 * max(1.0, th_r)
+            dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
+            dev = Dr2 * (v - vR)
+            qd = float(np.sum(dev * (v - vR)))
+            glag = A.T @ lam                                                     # without the proximity term zeta D_R^2 (v - v_R)
+            dinf = max(np.max(np.abs((zeta * dev + glag - zL + zU)[free])), np.max(np.abs(rho - lam - zp)), np.max(np.abs(rho + lam - zn)))
+            prods = np.concatenate([(zL * dl)[lo], (zU * du)[up], zp * pp, zn * nn])
+            cmax, cmin = prods.max(), prods.min()
+            for _ in range(64):
+                emu = max(dinf, np.max(np.abs(rc)), abs(cmax - mu_r), abs(cmin - mu_r))
+                if not (emu <= o["kappa_eps"] * mu_r):
+                    break
+                if mu_r <= mu_min:
+                    return 3                                                     # a minimiser of the infeasibility the filter does not take
+                mu_r = max(mu_min, min(o["kappa_mu"] * mu_r, mu_r ** o["theta_mu"]))
+                rfilt = []
+            zeta = np.sqrt(mu_r)
+            tau_r = max(o["tau_min"], 1.0 - mu_r)
+            sig = np.where(lo, zL / dl, 0.0) + np.where(up, zU / du, 0.0)
+            sp, sn = zp / pp, zn / nn
+            rp, rn = rho - lam - mu_r / pp, rho + lam - mu_r / nn
+            K = kkt(zeta * Dr2 + sig, None, A, 1.0 / sp + 1.0 / sn)
+            gb = zeta * dev - np.where(lo, mu_r / dl, 0.0) + np.where(up, mu_r / du, 0.0)     # gradient of the barrier objective in v
+            sol = np.linalg.solve(K, np.concatenate([-np.where(free, gb + glag, 0.0), -rc - rp / sp + rn / sn]))
+            d, dlam = np.where(free, sol[:nv], 0.0), sol[nv:]
+            dp, dn = (dlam - rp) / sp, (-dlam - rn) / sn
+            dzp, dzn = mu_r / pp - zp - sp * dp, mu_r / nn - zn - sn * dn
+            dzL = np.where(lo, mu_r / dl - zL - zL / dl * d, 0.0)
+            dzU = np.where(up, mu_r / du - zU + zU / du * d, 0.0)
+            ar = min(1.0, ftb(dl[lo], d[lo], tau_r), ftb(du[up], -d[up], tau_r), ftb(pp, dp, tau_r), ftb(nn, dn, tau_r))
+            az = min(1.0, ftb(zL[lo], dzL[lo], tau_r), ftb(zU[up], dzU[up], tau_r), ftb(zp, dzp, tau_r), ftb(zn, dzn, tau_r))
+            ln_r = ln_b + np.log(pp).sum() + np.log(nn).sum()
+            phi_r = rho * (pp.sum() + nn.sum()) + 0.5 * zeta * qd - mu_r * ln_r
+            dphi = float(np.where(free, gb, 0.0) @ d + (rho - mu_r / pp) @ dp + (rho - mu_r / nn) @ dn)
+            amin = o["gamma_theta"]
+            if dphi < 0:
+                amin = min(amin, o["gamma_phi"] * th_r / (-dphi))
+                if th_r <= thr_min:
+                    amin = min(amin, o["delta"] * th_r ** o["s_theta"] / (-dphi) ** o["s_phi"])
+            amin *= o["gamma_alpha"]
+            slack = 10.0 * np.finfo(float).eps * abs(phi_r)
+            ls, moved, arm = 0, False, False
+            while True:
+                vt, pt, nt = v + ar * d, pp + ar * dp, nn + ar * dn
                 with np.errstate(all="ignore"):
-                    ct = cons(vt, orc.eval_g(vt[:n]))
-                    psit = 0.5 * ct @ ct + 0.5 * zeta * np.sum(Dr2 * (vt - vR) ** 2) - mu * lnsum(vt)
-                if np.isfinite(psit) and psit <= psi + 1e-4 * ar * slope:
-                    v = np.where(free, vt, v)
+                    tht = np.abs(cons(vt, orc.eval_g(vt[:n])) - pt + nt).sum()
+                    phit = rho * (pt.sum() + nt.sum()) + 0.5 * zeta * np.sum(Dr2 * (vt - vR) ** 2) - mu_r * (lnsum(vt) + np.log(pt).sum() + np.log(nt).sum())
+                ok = False
+                if np.isfinite([tht, phit]).all() and tht <= thr_max and not any(tht >= a_ and phit >= b_ for a_, b_ in rfilt):
+                    sw = dphi < 0 and ar * (-dphi) ** o["s_phi"] > o["delta"] * th_r ** o["s_theta"]
+                    if th_r <= thr_min and sw:
+                        ok = phit - phi_r - o["eta_phi"] * ar * dphi <= slack
+                        arm = ok
+                    else:
+                        ok = tht <= (1 - o["gamma_theta"]) * th_r or phit - (phi_r - o["gamma_phi"] * th_r) <= slack
+                if ok:
                     moved = True
                     break
                 ar *= 0.5
-            trace.append(dict(it=it, f=fR, theta=thR, mu=mu, alpha=ar, alpha_z=0.0, delta_w=0.0, err0=err0, ls=-1))
-            it += 1
+                ls += 1
+                if ar < amin or ls > o["max_ls"]:
+                    break
             if not moved:
                 return 3
+            v = np.where(free, vt, v)
+            pp, nn = pt, nt
+            lam = lam + ar * dlam
+            dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
+            zL, zU = reset16(zL + az * dzL, dl, mu_r, lo), reset16(zU + az * dzU, du, mu_r, up)
+            zp, zn = reset16(zp + az * dzp, pp, mu_r, True), reset16(zn + az * dzn, nn, mu_r, True)
+            if not arm:
+                rfilt.append(((1 - o["gamma_theta"]) * th_r, phi_r - o["gamma_phi"] * th_r))
+            trace.append(dict(it=it, f=fo, theta=th_o, mu=mu_r, alpha=ar, alpha_z=az, delta_w=0.0, err0=err0, ls=-1))
+            it += 1
         return 3
 
     status = None
@@ -220,13 +317,10 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         W = np.zeros((nv, nv))
         np.add.at(W, (hi, hj), hv)
         W = W + np.tril(W, -1).T
-        A = np.zeros((m, nv))
-        A[ji, jj] = jv
-        A[ineq, n + np.arange(ns)] = -1.0
+        A = jac_dense(jv)
         dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
         sigma = np.where(lo, zL / dl, 0.0) + np.where(up, zU / du, 0.0)
         rd = glag - np.where(lo, mu / dl, 0.0) + np.where(up, mu / du, 0.0)
-        fxi = np.nonzero(~free)[0]
         dw = 0.0
         Ksp = None
         if o["linear_solver"] == "sparse-lu-no-inertia":
@@ -241,14 +335,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
                                     [As @ keep, -o["delta_c"] * scipy.sparse.identity(m)]], format="csc")
             Ksp = scipy.sparse.linalg.splu(Ks)
         while Ksp is None:                                                                        # Algorithm IC
-            K = np.zeros((nv + m, nv + m))
-            K[:nv, :nv] = W + np.diag(sigma + dw)
-            K[nv:, :nv] = A
-            K[:nv, nv:] = A.T
-            K[nv:, nv:] = -o["delta_c"] * np.eye(m)
-            K[fxi, :] = 0.0                                   # fixed variables stay as identity rows
-            K[:, fxi] = 0.0
-            K[fxi, fxi] = 1.0
+            K = kkt(sigma + dw, W, A, o["delta_c"] * np.ones(m))
             if _n_positive(K) == nv:
                 if dw > 0:
                     dw_last = dw
@@ -262,24 +349,20 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
                 break
         if status is not None:
             break
-        rhs = -np.concatenate([np.where(free, rd, 0.0), c])
-        sol = np.linalg.solve(K, rhs) if Ksp is None else Ksp.solve(rhs)
-        dv, dlam = np.where(free, sol[:nv], 0.0), sol[nv:]
-        dzL = np.where(lo, mu / dl - zL - zL / dl * dv, 0.0)                                      # (12)
-        dzU = np.where(up, mu / du - zU + zU / du * dv, 0.0)
-        amax, az = 1.0, 1.0                                                                       # (15)
-        k = lo & (dv < 0)
-        if k.any():
-            amax = min(amax, np.min(-tau * dl[k] / dv[k]))
-        k = up & (dv > 0)
-        if k.any():
-            amax = min(amax, np.min(tau * du[k] / dv[k]))
-        k = lo & (dzL < 0)
-        if k.any():
-            az = min(az, np.min(-tau * zL[k] / dzL[k]))
-        k = up & (dzU < 0)
-        if k.any():
-            az = min(az, np.min(-tau * zU[k] / dzU[k]))
+        lu = scipy.linalg.lu_factor(K) if Ksp is None else None
+
+        def newton(c_rhs):
+            """the step for constraint right-hand side c_rhs (c itself, or the second-order correction's c_soc)"""
+            rhs = -np.concatenate([np.where(free, rd, 0.0), c_rhs])
+            sol = scipy.linalg.lu_solve(lu, rhs) if Ksp is None else Ksp.solve(rhs)
+            dv_, dlam_ = np.where(free, sol[:nv], 0.0), sol[nv:]
+            dzL_ = np.where(lo, mu / dl - zL - zL / dl * dv_, 0.0)                                # (12)
+            dzU_ = np.where(up, mu / du - zU + zU / du * dv_, 0.0)
+            amax_ = min(1.0, ftb(dl[lo], dv_[lo], tau), ftb(du[up], -dv_[up], tau))               # (15)
+            az_ = min(1.0, ftb(zL[lo], dzL_[lo], tau), ftb(zU[up], dzU_[up], tau))
+            return dv_, dlam_, dzL_, dzU_, amax_, az_
+
+        dv, dlam, dzL, dzU, amax, az = newton(c)
         gphi = np.concatenate([grad, np.zeros(ns)]) - np.where(lo, mu / dl, 0.0) + np.where(up, mu / du, 0.0)
         dphi = float(np.dot(np.where(free, gphi, 0.0), dv))
         amin = o["gamma_theta"]                                                                   # (23)
@@ -288,26 +371,47 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             if theta <= theta_min:
                 amin = min(amin, o["delta"] * theta ** o["s_theta"] / (-dphi) ** o["s_phi"])
         amin *= o["gamma_alpha"]
-        a, ls, armijo, accepted = amax, 0, False, False
+        a, ls, armijo, accepted, n_soc = amax, 0, False, False, 0
         slack = 10.0 * np.finfo(float).eps * abs(phi)
-        while True:
-            vt = v + a * dv
+
+        def acceptable(vt, a_test):
+            """filter + switching / Armijo / sufficient-decrease tests (18)-(20) at a trial point -> (ok, armijo, theta_trial, c_trial)"""
             with np.errstate(all="ignore"):
                 ft, gt = orc.eval_f(vt[:n]), orc.eval_g(vt[:n])
-                tht = np.abs(cons(vt, gt)).sum() if m else 0.0
+                ct = cons(vt, gt)
+                tht = np.abs(ct).sum() if m else 0.0
                 phit = ft - mu * lnsum(vt)
-            ok = False
-            if np.isfinite([ft, tht, phit]).all() and tht <= theta_max:
-                if not any(tht >= ft_ and phit >= fp_ for ft_, fp_ in filt):
-                    sw = dphi < 0 and a * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]      # (19)
-                    if theta <= theta_min and sw:
-                        ok = phit - phi - o["eta_phi"] * a * dphi <= slack                                 # (20)
-                        armijo = ok
-                    else:
-                        ok = tht <= (1 - o["gamma_theta"]) * theta or phit - (phi - o["gamma_phi"] * theta) <= slack   # (18)
+            if not (np.isfinite([ft, tht, phit]).all() and tht <= theta_max):
+                return False, False, tht, ct
+            if any(tht >= ft_ and phit >= fp_ for ft_, fp_ in filt):
+                return False, False, tht, ct
+            sw = dphi < 0 and a_test * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]          # (19)
+            if theta <= theta_min and sw:
+                ok_ = phit - phi - o["eta_phi"] * a_test * dphi <= slack                                   # (20)
+                return ok_, ok_, tht, ct
+            return (tht <= (1 - o["gamma_theta"]) * theta or phit - (phi - o["gamma_phi"] * theta) <= slack), False, tht, ct   # (18)
+
+        while True:
+            ok, armijo, tht, ct = acceptable(v + a * dv, a)
             if ok:
                 accepted = True
                 break
+            if ls == 0 and o["max_soc"] > 0 and np.isfinite(tht) and tht >= theta:
+                # second-order correction, A-5.5 .. A-5.9: the same matrix, c_soc = alpha c_soc + c(trial point)
+                csoc, th_old, a_soc = c, theta, a
+                for p_soc in range(o["max_soc"]):
+                    csoc = a_soc * csoc + ct
+                    dvs, dlams, dzLs, dzUs, a_soc, azs = newton(csoc)
+                    ok, arm_s, ths, ct = acceptable(v + a_soc * dvs, a)
+                    if ok:
+                        dv, dlam, dzL, dzU, az, a, armijo = dvs, dlams, dzLs, dzUs, azs, a_soc, arm_s
+                        accepted, n_soc = True, p_soc + 1
+                        break
+                    if not np.isfinite(ths) or ths > o["kappa_soc"] * th_old:
+                        break
+                    th_old = ths
+                if accepted:
+                    break
             a *= 0.5
             ls += 1
             if a < amin or ls > o["max_ls"]:
@@ -321,12 +425,11 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             break
         v = np.where(free, v + a * dv, v)
         lam = lam + a * dlam
-        ks = o["kappa_sigma"]
         dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
-        zL = np.where(lo, np.maximum(np.minimum(zL + az * dzL, ks * mu / dl), mu / (ks * dl)), 0.0)    # (16)
-        zU = np.where(up, np.maximum(np.minimum(zU + az * dzU, ks * mu / du), mu / (ks * du)), 0.0)
+        zL, zU = reset16(zL + az * dzL, dl, mu, lo), reset16(zU + az * dzU, du, mu, up)           # (16)
         if not armijo:
             filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))             # (22)
-        trace.append(dict(it=it, f=f, theta=theta, mu=mu, alpha=a, alpha_z=az, delta_w=dw, err0=err0, ls=ls))
+        trace.append(dict(it=it, f=f, theta=theta, mu=mu, alpha=a, alpha_z=az, delta_w=dw, err0=err0, ls=ls, soc=n_soc, dinf=dinf, cinf=cinf, comp=cmax,
+                          smin=float(min(dl[lo].min(initial=1e300), du[up].min(initial=1e300)))))
         it += 1
     return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto)

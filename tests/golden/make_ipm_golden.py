@@ -17,6 +17,10 @@ CASES = {
     "bryson_denham_default_restoration": (lambda: problems.bryson_denham(), dict(tol=1e-6)),
     "hypersensitive_6x10": (lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), dict(tol=1e-8)),
     "quadrotor_2x4": (lambda: problems.quadrotor(2, 4), dict(tol=1e-8)),
+    # the metric problem on a small mesh, from lpopc's default guess (example/launch/Launch.cpp:200-457): needs the bound
+    # relaxation and, depending on rounding, the restoration phase; optimum = 7529.71 kg of final mass (objective -m_f / m_scale)
+    "launch_2x6": (lambda: problems.launch(2, 6), dict(tol=1e-8)),
+    "launch_4x8": (lambda: problems.launch(4, 8), dict(tol=1e-8)),       # ~2 minutes of dense numpy
 }
 
 
