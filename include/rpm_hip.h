@@ -233,7 +233,10 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
  *                       "delta_c" (1e-8, constraint regularisation that makes the pivot-free LDL^T well defined),
  *                       "max_line_search" (40), "trace" (0; keep the first N accepted steps of every instance),
- *                       "restoration" (1), "restoration_max_iter" (60), "acceptable_tol" (1e-6), "acceptable_iter" (15)
+ *                       "restoration" (1), "restoration_max_iter" (300), "restoration_penalty" (1000, Ipopt's rho),
+ *                       "acceptable_tol" (1e-6), "acceptable_iter" (15), "bound_relax_factor" (1e-8, as Ipopt: finite bounds
+ *                       of free unknowns move out by this * max(1, |bound|), so a solution may sit that far outside them),
+ *                       "max_soc" (4, second-order correction steps per iteration; 0 = off)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,
@@ -257,11 +260,11 @@ int rpm_ipm_get_subproblems(rpm_ipm* s, int capacity, int* geom, int* n_sub);
 /* records of the last solve when option "trace" > 0: 8 doubles per accepted step — f, theta = |c|_1, mu, alpha, alpha_z,
  * delta_w, E_0 at the step's start, backtracking steps */
 int rpm_ipm_get_trace(rpm_ipm* s, int instance, int capacity, double* records, int* n_records);
-/* feasibility restorations each instance went through in the last solve (option "restoration", default 1: when the line
- * search gives up at an infeasible point — where Ipopt enters its restoration phase — damped Gauss-Newton steps on
- * 1/2|c|^2 + zeta/2 |D_R (v - v_R)|^2 inside the bounds, from the same KKT kernels with W = zeta D_R^2 + mu/s^2 and -I in
- * the constraint block, until the infeasibility is 0.9 of where it started and the filter accepts the point; simpler than
- * Ipopt's l1 restoration NLP) */
+/* restoration phases each instance went through in the last solve (option "restoration", default 1: when the line search
+ * gives up at an infeasible point the instance switches, as Ipopt does, to  min rho |p + n|_1 + zeta/2 |D_R (v - v_R)|^2
+ * s.t. c(v) - p + n = 0, p, n >= 0 and the bounds  — solved by the same interior-point kernels with p, n eliminated from the
+ * Newton system — until the infeasibility is 0.9 of where it entered and the original filter accepts the point; least-squares
+ * multipliers on return.  Trace records of restoration iterations carry -1 in the backtracking field.  DESIGN.md f-2) */
 int rpm_ipm_get_restorations(rpm_ipm* s, int* per_instance);
 /* device time of the last solve spent in the factorisation and in the substitution kernels (HIP events on the solver's
  * stream, summed over its iterations), for roofline figures */

@@ -3,9 +3,10 @@
 // reference tree, so what is built here is a restatement of its published algorithm (Waechter & Biegler, Math. Program.
 // 106, 2006: primal-dual barrier, fraction-to-the-boundary rule, filter line search, inertia correction) for a batch of
 // independent instances of one transcription — the MPC sweep of BASELINE config 5 — with every iterate, multiplier,
-// KKT matrix and factor resident in HBM.  Not restated: Ipopt's l1 restoration NLP (a Gauss-Newton feasibility
-// restoration built from the same kernels takes its place), second-order corrections, the
-// adaptive barrier strategy (monotone Fiacco-McCormick here), scaling.  See DESIGN.md §f-2.
+// KKT matrix and factor resident in HBM.  Restated beyond the basic iteration: bound_relax_factor, the second-order correction,
+// the restoration phase (paper section 3.3, with a Gauss-Newton model of the constraint curvature) and least-squares
+// multipliers on leaving it.  Not restated: the adaptive barrier strategy (monotone Fiacco-McCormick here), scaling,
+// the watchdog.  See DESIGN.md §f-2.
 //
 // The KKT matrix of a collocation NLP is banded once the unknowns are ordered along time: node k's states, controls,
 // slacks and multipliers sit together, a defect row reaches the nodes of its own mesh interval only.  What does not
