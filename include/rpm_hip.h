@@ -340,6 +340,9 @@ int rpm_synchronize(rpm_engine* e);
  * "ipm_nested"       -1 (default: when the structure allows) | 0 | 1 (must), read by rpm_ipm_create: factor the KKT matrices by
  *                    nested dissection over the mesh intervals (one workgroup per interval and instance instead of one per
  *                    instance: the metric problem's single instance uses 256 CUs instead of one; 0 = one band + border matrix)
+ * "ipm_nested_group" 0 (default: automatic) | positions per group: with nested dissection the separator system (block
+ *                    tridiagonal along time) of a long mesh is cut once more into groups of this many of its positions, each
+ *                    eliminated by a workgroup of its own (automatic: when that system is >= 512 long, groups of ~sqrt(length * bandwidth))
  * "zero_copy"        1 (default): with page-locked caller arrays the tile kernel reads x straight from the caller's array and
  *                    stores g straight into it (no copy operations: one launch + one synchronisation per rpm_eval_g);
  *                    0: staged through the engine's HBM buffers with copy-engine transfers

@@ -148,6 +148,61 @@ size_t factor_lds_of(int b, int nb) {   // = kkt_factor_lds_bytes (rpm_ipm_kerne
   return (size_t(b + 8) * W + W * (W + 1) + W * W + W + 2 * size_t(nb) * W + size_t(nb) * nb) * sizeof(double);
 }
 long long sub_at(const KktSubHost& g, int i, int j) { return g.koff + (long long)j * g.CS + (i < g.Nb ? i - j : g.b + 1 + i - g.Nb); }
+
+// Where a position of the separator system (level-2 position a: separators in time order, then the global border) lives once
+// that system is cut into groups (IpmPlan::n_l2 > 0), and the storage slot of a pair of such positions.
+struct L3Map {
+  const IpmPlan& p;
+  int KI;                                   // index of the first level-2 sub-problem in p.subs
+  explicit L3Map(const IpmPlan& pl) : p(pl), KI(int(pl.subs.size()) - 1 - pl.n_l2) {}
+  int group(int a) const { return std::min(a / p.l3_S, p.l3_G - 1); }
+  bool interior(int a) const {
+    if (a >= p.l3_Nb2) return false;
+    const int g = group(a);
+    return g == p.l3_G - 1 || a - g * p.l3_S < p.l3_S - p.l3_w;
+  }
+  int local(int a) const { return a - group(a) * p.l3_S; }                      // interior index inside its group
+  int last_pos(int a) const {                                                   // position in the last level (a not interior)
+    if (a >= p.l3_Nb2) return (p.l3_G - 1) * p.l3_w + (a - p.l3_Nb2);
+    const int g = group(a);
+    return g * p.l3_w + (a - (g * p.l3_S + p.l3_S - p.l3_w));
+  }
+  int n_prev(int g) const { return g > 0 ? p.l3_w : 0; }
+  int n_own(int g) const { return g < p.l3_G - 1 ? p.l3_w : 0; }
+  int lborder(int g, int a) const {                                             // local border index of a (not interior) seen from group g, or -1
+    if (a >= p.l3_Nb2) return n_prev(g) + n_own(g) + (a - p.l3_Nb2);
+    const int ga = group(a), idx = a - (ga * p.l3_S + p.l3_S - p.l3_w);
+    if (ga == g - 1) return idx;
+    if (ga == g) return n_prev(g) + idx;
+    return -1;
+  }
+  int rhs_pos(int a) const {
+    if (interior(a)) return p.subs[KI + group(a)].roff + local(a);
+    return p.l3_base + last_pos(a);
+  }
+  long long slot(int a, int c) const {
+    const KktSubHost& G3 = p.subs.back();
+    const bool ia = interior(a), ic = interior(c);
+    if (!ia && !ic) {
+      int pa = last_pos(a), pc = last_pos(c);
+      if (pa < pc) std::swap(pa, pc);
+      if (pa < G3.Nb && pa - pc > G3.b) return -1;
+      return sub_at(G3, pa, pc);
+    }
+    if (ia && ic) {
+      if (group(a) != group(c)) return -1;
+      int la = local(a), lc = local(c);
+      if (la < lc) std::swap(la, lc);
+      const KktSubHost& g = p.subs[KI + group(a)];
+      if (la - lc > g.b) return -1;
+      return sub_at(g, la, lc);
+    }
+    const int in = ia ? a : c, out = ia ? c : a, g = group(in);
+    const int lb = lborder(g, out);
+    if (lb < 0) return -1;
+    return sub_at(p.subs[KI + g], p.subs[KI + g].Nb + lb, local(in));
+  }
+};
 }  // namespace
 
 static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
@@ -256,8 +311,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
   }
   const int l2base = cur;
   for (int u = 0; u < p.Nt; ++u)
-    if (ivl_of[u] < 0) { C.loc[u] = l2pos[u]; p.pos[u] = l2base + l2pos[u]; }
-  p.Nt_alloc = l2base + Nb2 + p.nb;
+    if (ivl_of[u] < 0) C.loc[u] = l2pos[u];      // p.pos of these follows once the separator system's own layout is known
   p.Nb = Nb2;   // reported by rpm_ipm_get_info as the banded part of level 2
 
   // local border index of a separator / border unknown seen from interval I, or -1
@@ -293,6 +347,21 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
   for (int I = 0; I < KI; ++I)   // the Schur complements couple an interval's separator with the next one's states
     if (!iv[I].last) b2 = std::max(b2, int(sep[I].size()) + nstate0[I + 1] - 1);
 
+  // ---- third level?  (the separator system of a long mesh is cut again, at the matrix level: rpm_ipm.hpp)
+  {
+    const int w = std::max(b2, 1);
+    int S = e.opt_ipm_nested_group;
+    if (S == 0 && Nb2 >= 512) {                  // automatic: group size ~ sqrt(Nb2 * w), the minimum of (S - w) + (Nb2 / S) w block columns
+      S = int(std::sqrt(double(Nb2) * w));
+      S = (S + 15) / 16 * 16;
+    }
+    if (S > 0) {
+      S = std::max(S, 3 * w);
+      const int G = Nb2 / S;                     // the last group takes the remainder
+      if (G >= 2) { p.n_l2 = G; p.l3_S = S; p.l3_w = w; p.l3_G = G; p.l3_Nb2 = Nb2; }
+    }
+  }
+
   // ---- sub-problem geometry and storage
   long long koff = 0;
   p.subs.clear();
@@ -311,21 +380,47 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
     p.subs.push_back(g);
   }
   {
-    KktSubHost g;
-    g.Nb = Nb2;
-    g.nb = p.nb;
-    g.Nt = Nb2 + p.nb;
-    g.b = std::max(b2, IPM_PLAN_W);
-    if (g.b > g.Nb - 1) g.b = std::max(g.Nb - 1, 0);
-    g.CS = g.b + 1 + g.nb;
-    g.CS += g.CS & 1;
-    g.koff = koff;
-    g.roff = l2base;
-    koff += (long long)g.Nt * g.CS;
-    p.subs.push_back(g);
-    p.b = g.b;
-    p.CS = g.CS;
+    int roff = l2base;
+    auto push = [&](int Nb_, int nb_, int b_) {
+      KktSubHost g;
+      g.Nb = Nb_;
+      g.nb = nb_;
+      g.Nt = Nb_ + nb_;
+      g.b = std::max(b_, IPM_PLAN_W);
+      if (g.b > g.Nb - 1) g.b = std::max(g.Nb - 1, 0);
+      g.CS = g.b + 1 + g.nb;
+      g.CS += g.CS & 1;
+      g.koff = koff;
+      g.roff = roff;
+      koff += (long long)g.Nt * g.CS;
+      roff += g.Nt;
+      p.subs.push_back(g);
+    };
+    if (p.n_l2) {
+      for (int g = 0; g < p.l3_G; ++g) {
+        const int n_g = g < p.l3_G - 1 ? p.l3_S - p.l3_w : Nb2 - g * p.l3_S;
+        push(n_g, (g > 0 ? p.l3_w : 0) + (g < p.l3_G - 1 ? p.l3_w : 0) + p.nb, b2);
+      }
+      p.l3_base = roff;
+      push((p.l3_G - 1) * p.l3_w, p.nb, 2 * p.l3_w - 1);
+    } else {
+      push(Nb2, p.nb, b2);
+    }
+    p.b = p.subs.back().b;
+    p.CS = p.subs.back().CS;
+    p.Nt_alloc = roff;
   }
+  const L3Map M3(p);
+  auto l2_rhs = [&](int a) { return p.n_l2 ? M3.rhs_pos(a) : l2base + a; };
+  auto l2_slot = [&](int a, int c) -> long long {
+    if (p.n_l2) return M3.slot(a, c);
+    if (a < c) std::swap(a, c);
+    const KktSubHost& G2 = p.subs.back();
+    if (a < Nb2 && a - c > G2.b) return -1;
+    return sub_at(G2, a, c);
+  };
+  for (int u = 0; u < p.Nt; ++u)
+    if (ivl_of[u] < 0) p.pos[u] = l2_rhs(l2pos[u]);
   p.storage_nd = koff;
   if (p.storage_nd > INT32_MAX) return fail("KKT storage of one instance exceeds 2^31 doubles");
   p.max_rows = 0;
@@ -336,7 +431,6 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
   }
 
   // ---- storage slot of every entry
-  const KktSubHost& G2 = p.subs.back();
   auto dst = [&](int ua, int uc) -> long long {
     const int Ia = ivl_of[ua], Ic = ivl_of[uc];
     if (Ia >= 0 && Ic >= 0) {
@@ -352,10 +446,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
       if (lb < 0) return -1;
       return sub_at(p.subs[I], p.subs[I].Nb + lb, C.loc[ui]);
     }
-    int a = l2pos[ua], c = l2pos[uc];
-    if (a < c) std::swap(a, c);
-    if (a < Nb2 && a - c > G2.b) return -1;
-    return sub_at(G2, a, c);
+    return l2_slot(l2pos[ua], l2pos[uc]);
   };
   bool missing = false;
   auto dst_i = [&](int ua, int uc) -> int {
@@ -391,11 +482,15 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
           if (sep_state[u]) l2_of[q++] = l2pos[u];
       for (int j = 0; j < p.nb; ++j) l2_of[q++] = Nb2 + j;
       for (int r = 0; r < g.nb; ++r) {
-        for (int c = 0; c <= r; ++c) all.emplace_back(sub_at(G2, l2_of[r], l2_of[c]), int(sub_at(g, g.Nb + r, g.Nb + c)));
-        rall.emplace_back(l2base + l2_of[r], g.roff + g.Nb + r);
+        for (int c = 0; c <= r; ++c) {
+          const long long o = l2_slot(l2_of[r], l2_of[c]);
+          if (o < 0) return fail("nested dissection: a Schur complement entry of an interval has no slot in the separator system's layout");
+          all.emplace_back(o, int(sub_at(g, g.Nb + r, g.Nb + c)));
+        }
+        rall.emplace_back(l2_rhs(l2_of[r]), g.roff + g.Nb + r);
         p.gap_pos.push_back(g.roff + g.Nb + r);
         p.rs_dst.push_back(g.roff + g.Nb + r);
-        p.rs_src.push_back(l2base + l2_of[r]);
+        p.rs_src.push_back(l2_rhs(l2_of[r]));
       }
     }
     std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
@@ -420,6 +515,48 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
     }
     p.rg_ptr.push_back(int(p.rg_src.size()));
     if (rall.empty()) p.rg_ptr.assign(1, 0);
+  }
+  if (p.n_l2) {   // second stage: the group sub-problems' Schur complements -> the last level, in group order
+    const KktSubHost& G3 = p.subs.back();
+    std::vector<std::pair<long long, int>> all;
+    std::vector<std::pair<int, int>> rall;
+    for (int g = 0; g < p.l3_G; ++g) {
+      const KktSubHost& q = p.subs[KI + g];
+      std::vector<int> l3_of;                      // last-level position of local border index
+      if (g > 0) for (int j = 0; j < p.l3_w; ++j) l3_of.push_back((g - 1) * p.l3_w + j);
+      if (g < p.l3_G - 1) for (int j = 0; j < p.l3_w; ++j) l3_of.push_back(g * p.l3_w + j);
+      for (int j = 0; j < p.nb; ++j) l3_of.push_back(G3.Nb + j);
+      for (int r = 0; r < q.nb; ++r) {
+        for (int c = 0; c <= r; ++c) {
+          if (l3_of[r] < G3.Nb && l3_of[r] - l3_of[c] > G3.b) return fail("nested dissection: third-level band too narrow");
+          all.emplace_back(sub_at(G3, l3_of[r], l3_of[c]), int(sub_at(q, q.Nb + r, q.Nb + c)));
+        }
+        rall.emplace_back(p.l3_base + l3_of[r], q.roff + q.Nb + r);
+        p.gap_pos.push_back(q.roff + q.Nb + r);
+        p.rs2_dst.push_back(q.roff + q.Nb + r);
+        p.rs2_src.push_back(p.l3_base + l3_of[r]);
+      }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+    p.cg2_ptr.push_back(0);
+    for (size_t i = 0; i < all.size(); ++i) {
+      if (i == 0 || all[i].first != all[i - 1].first) {
+        if (i) p.cg2_ptr.push_back(int(p.cg2_src.size()));
+        p.cg2_dst.push_back(int(all[i].first));
+      }
+      p.cg2_src.push_back(all[i].second);
+    }
+    p.cg2_ptr.push_back(int(p.cg2_src.size()));
+    std::stable_sort(rall.begin(), rall.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
+    p.rg2_ptr.push_back(0);
+    for (size_t i = 0; i < rall.size(); ++i) {
+      if (i == 0 || rall[i].first != rall[i - 1].first) {
+        if (i) p.rg2_ptr.push_back(int(p.rg2_src.size()));
+        p.rg2_dst.push_back(rall[i].first);
+      }
+      p.rg2_src.push_back(rall[i].second);
+    }
+    p.rg2_ptr.push_back(int(p.rg2_src.size()));
   }
   // Jacobian by column, entries of a column in COO order
   p.jt_ptr.assign(p.n + 1, 0);
@@ -455,7 +592,7 @@ long long ipm_plan_offset(const IpmPlan& p, int ua, int uc) {
     return p.at(a, c);
   }
   const KktSubHost& G2 = p.subs.back();
-  const int Nb2 = G2.Nb;
+  const int Nb2 = p.n_l2 ? p.l3_Nb2 : G2.Nb;
   auto lborder = [&](int I, int u) -> int {
     if (p.nd_sep[u] == I) return p.nd_loc[u] - p.nd_sep0[I];
     if (!p.nd_last[I] && p.nd_sep[u] == I + 1) return p.nd_sep_state[u] ? p.nd_nsep[I] + (p.nd_loc[u] - p.nd_sep0[I + 1]) : -1;
@@ -477,6 +614,7 @@ long long ipm_plan_offset(const IpmPlan& p, int ua, int uc) {
     return sub_at(p.subs[I], p.subs[I].Nb + lb, p.nd_loc[ui]);
   }
   int a = p.nd_loc[ua], c = p.nd_loc[uc];
+  if (p.n_l2) return L3Map(p).slot(a, c);
   if (a < c) std::swap(a, c);
   if (a < Nb2 && a - c > G2.b) return -1;
   return sub_at(G2, a, c);

@@ -56,7 +56,14 @@ struct IpmPlan {
   int nd = 0;
   int Nt_alloc = 0;                   // length of the right-hand-side vector: Nt plus the level-1 border work spaces
   long long storage_nd = 0;           // doubles of KKT storage per instance (level-1 blocks, then level 2)
-  std::vector<KktSubHost> subs;       // level-1 sub-problems, then ONE level-2 entry (the last)
+  std::vector<KktSubHost> subs;       // level-1 sub-problems, [level-2 groups,] then ONE entry for the last level
+  // ---- optional third level (n_l2 > 0): the separator system of a long mesh is itself banded (block tridiagonal), so it is cut
+  // again, at the matrix level: consecutive groups of l3_S of its positions, the trailing l3_w (= its half bandwidth) of every
+  // group but the last form that group's separator.  Group interiors are level-2 sub-problems (border = the previous
+  // group's separator, its own, the global border), factored up to their corners by a workgroup each; all group separators in
+  // order + the global border are the last level.  Delta-III 4 x 64 x 16: one chain of 112 block columns -> 8 + 16.
+  int n_l2 = 0, l3_S = 0, l3_w = 0, l3_G = 0, l3_Nb2 = 0, l3_base = 0;
+  std::vector<int> cg2_ptr, cg2_src, cg2_dst, rg2_ptr, rg2_src, rg2_dst, rs2_dst, rs2_src;   // second gather / scatter stage (level 2 -> last level)
   std::vector<int> cg_ptr, cg_src;    // corner gather: level-2 storage offset cg_dst[i] += sum of K[cg_src[cg_ptr[i] .. cg_ptr[i+1])]
   std::vector<int> cg_dst;
   std::vector<int> rg_ptr, rg_src;    // right-hand-side gather: rhs[rg_dst[i]] += sum of rhs[rg_src[...]]  (level-1 border work spaces)
@@ -73,7 +80,7 @@ struct IpmPlan {
 };
 
 // rpm_ipm.cpp (host only): ordering, band width and the scatter maps from the engine's layout
-int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why, int nested = 0);
+int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why, int nested = 0);   // nested: 0 one band, 1 by mesh interval, third level when the separator system is long (engine option ipm_nested_group)
 void ipm_plan_group_hessian(IpmPlan& p);   // hg_* from hes_dst
 // storage offset of the entry between unknowns ua, uc ([0,n) x, [n,nv) slacks, [nv,nv+m) multipliers); -1 if the layout has no slot for it
 long long ipm_plan_offset(const IpmPlan& p, int ua, int uc);

@@ -61,6 +61,8 @@ struct IpmDev {
   const int *pos, *row_slack, *slack_row, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
   const int *hg_ptr, *hg_src, *hg_dst;   // Hessian entries grouped by storage slot
   int n_hg;
+  const int* long_cols;                  // Jacobian columns of more than 256 entries (a workgroup each in ipm_jt_lambda_kernel)
+  int n_long;
   const double *gl, *gu;
   // per-instance state
   double *v, *vl, *vu, *zL, *zU, *lam, *dv, *dlam, *dzL, *dzU, *glag, *c, *rhs, *K, *filt;
@@ -78,13 +80,15 @@ struct IpmDev {
   // factorisation sub-problems: one (the whole band + border matrix) or, with nested dissection, n_l1 interval blocks
   // followed by the separator system; pivot signs of every sub-problem land in piv[(instance * n_sub + sub) * 3 + {+,-,bad}]
   const KktSub* subs;
-  int n_sub, n_l1;          // n_sub = n_l1 + 1; n_l1 = 0: no dissection
+  int n_sub, n_l1, n_l2;    // n_sub = n_l1 + n_l2 + 1; n_l1 = 0: no dissection; n_l2 > 0: the separator system is cut into groups once more
   int* piv;
   const int *cg_ptr, *cg_src, *cg_dst;   // corner gather (level-1 Schur complements into level 2)
   const int *rg_ptr, *rg_src, *rg_dst;   // right-hand-side gather
   const int *rs_dst, *rs_src;            // solution scatter into the level-1 border work spaces
   const int* gap_pos;                    // positions of those work spaces (zeroed before the forward sweep)
   int n_cg, n_rg, n_rs, n_gap;
+  const int *cg2_ptr, *cg2_src, *cg2_dst, *rg2_ptr, *rg2_src, *rg2_dst, *rs2_dst, *rs2_src;   // second stage (groups -> last level)
+  int n_cg2, n_rg2, n_rs2;
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
 };
 

@@ -103,18 +103,31 @@ __global__ void ipm_pack_x_kernel(IpmDev D) {
 // multiplier reset (16) of a bound multiplier z for the slack s
 __device__ inline double reset16(double z, double s, double mu, double ks) { return fmax(fmin(z, ks * mu / s), mu / (ks * s)); }
 
-// grad f + A^T lambda by column (the restoration problem has no grad f), every workgroup a slice of the unknowns: on the metric
-// problem this gather over 800 k Jacobian entries took 7.7 ms inside the one-workgroup residual kernel
-__global__ void ipm_jt_lambda_kernel(IpmDev D) {
+// grad f + A^T lambda by column (the restoration problem has no grad f).  A thread per unknown for the short columns; the long
+// ones — t0, tf, the final states: every defect row of a phase, 7 168 entries on the metric problem, which one thread walked
+// in 1.4 ms — take a workgroup each (blockIdx.x >= the thread-per-unknown blocks), summed in a fixed order.
+constexpr int IPM_LONG_COLUMN = 256;
+__global__ __launch_bounds__(256) void ipm_jt_lambda_kernel(IpmDev D, int n_thread_blocks) {
+  __shared__ double sh[4];
   const int bi = blockIdx.y;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
+  const double *lam = D.lam + size_t(bi) * D.m, *jac = D.jac + size_t(bi) * D.sv;
+  const bool resto = S.mode == 2;
+  if (int(blockIdx.x) >= n_thread_blocks) {
+    const int i = D.long_cols[blockIdx.x - n_thread_blocks];
+    double acc = 0.0;
+    for (int q = D.jt_ptr[i] + threadIdx.x; q < D.jt_ptr[i + 1]; q += blockDim.x) acc += jac[D.jt_ent[q]] * lam[D.jt_row[q]];
+    acc = block_red(acc, 0, sh);
+    if (threadIdx.x == 0) D.glag[size_t(bi) * D.nv + i] = (resto ? 0.0 : D.grad[size_t(bi) * D.n + i]) + acc;
+    return;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D.nv) return;
-  const double *lam = D.lam + size_t(bi) * D.m, *jac = D.jac + size_t(bi) * D.sv;
   double acc;
   if (i < D.n) {
-    acc = S.mode == 2 ? 0.0 : D.grad[size_t(bi) * D.n + i];
+    if (D.jt_ptr[i + 1] - D.jt_ptr[i] > IPM_LONG_COLUMN) return;
+    acc = resto ? 0.0 : D.grad[size_t(bi) * D.n + i];
     for (int q = D.jt_ptr[i]; q < D.jt_ptr[i + 1]; ++q) acc += jac[D.jt_ent[q]] * lam[D.jt_row[q]];
   } else {
     acc = -lam[D.slack_row[i - D.n]];
@@ -1165,7 +1178,8 @@ void ipm_launch_pack_x(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_pack_x_kernel, dim3(unsigned((D.n + 255) / 256), unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_jt_lambda_kernel, dim3(unsigned((D.nv + 255) / 256), unsigned(D.B)), dim3(256), 0, st, D);
+  const int tb = (D.nv + 255) / 256;
+  hipLaunchKernelGGL(ipm_jt_lambda_kernel, dim3(unsigned(tb + D.n_long), unsigned(D.B)), dim3(256), 0, st, D, tb);
   hipLaunchKernelGGL(ipm_residual_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
@@ -1254,13 +1268,18 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
     launch_factor_subs(D, 0, 1, 0, tiles_per_wave, lds_bytes, st);
     return;
   }
+  auto corners = [&](const int* ptr, const int* src, const int* dst, int n) {
+    if (!n) return;
+    const unsigned blocks = unsigned(std::max(1, std::min(1024, (n + 255) / 256)));
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1);
+  };
   launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);                 // every interval up to its corner
-  if (D.n_cg) {
-    const unsigned blocks = unsigned(std::max(1, std::min(1024, (D.n_cg + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, D.cg_ptr, D.cg_src, D.cg_dst,
-                       D.n_cg, D.inst, 1);
+  corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg);
+  if (D.n_l2) {
+    launch_factor_subs(D, D.n_l1, D.n_l2, 1, tiles_per_wave, lds_bytes, st);          // every group of separators up to its corner
+    corners(D.cg2_ptr, D.cg2_src, D.cg2_dst, D.n_cg2);
   }
-  launch_factor_subs(D, D.n_l1, 1, 0, tiles_per_wave, lds_bytes, st);                 // separators + border
+  launch_factor_subs(D, D.n_l1 + D.n_l2, 1, 0, tiles_per_wave, lds_bytes, st);        // last level: (group) separators + border
 }
 void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
   if (D.n_l1 == 0) {
@@ -1273,15 +1292,24 @@ void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
     hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, dst, src, n, mode, D.inst,
                        check_status);
   };
+  auto gather = [&](const int* ptr, const int* src, const int* dst, int n) {
+    if (!n) return;
+    const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0);
+  };
   vec(D.gap_pos, nullptr, D.n_gap, 0);                                                 // border work spaces start at zero
   launch_solve_subs(D, 0, D.n_l1, 1, check_status, st);                                // forward, every interval
-  if (D.n_rg) {
-    const unsigned blocks = unsigned(std::max(1, std::min(256, (D.n_rg + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, D.rg_ptr, D.rg_src, D.rg_dst,
-                       D.n_rg, D.inst, 0);
+  gather(D.rg_ptr, D.rg_src, D.rg_dst, D.n_rg);
+  if (D.n_l2) {
+    launch_solve_subs(D, D.n_l1, D.n_l2, 1, check_status, st);                         // forward, every group
+    gather(D.rg2_ptr, D.rg2_src, D.rg2_dst, D.n_rg2);
   }
-  launch_solve_subs(D, D.n_l1, 1, 0, check_status, st);                                // separators + border
-  vec(D.rs_dst, D.rs_src, D.n_rs, 1);                                                  // their solution into the work spaces
+  launch_solve_subs(D, D.n_l1 + D.n_l2, 1, 0, check_status, st);                       // last level
+  if (D.n_l2) {
+    vec(D.rs2_dst, D.rs2_src, D.n_rs2, 1);                                             // its solution into the groups' work spaces
+    launch_solve_subs(D, D.n_l1, D.n_l2, 2, check_status, st);                         // backward, every group
+  }
+  vec(D.rs_dst, D.rs_src, D.n_rs, 1);                                                  // separator / border values into the intervals' work spaces
   launch_solve_subs(D, 0, D.n_l1, 2, check_status, st);                                // backward, every interval
 }
 

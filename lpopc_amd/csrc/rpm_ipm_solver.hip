@@ -131,6 +131,13 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc_c(h, &D.jt_ent, p.jt_ent)); A_(ipm_alloc_c(h, &D.jt_row, p.jt_row));
   A_(ipm_alloc_c(h, &D.hg_ptr, p.hg_ptr)); A_(ipm_alloc_c(h, &D.hg_src, p.hg_src)); A_(ipm_alloc_c(h, &D.hg_dst, p.hg_dst));
   D.n_hg = int(p.hg_dst.size());
+  {
+    std::vector<int> long_cols;
+    for (int i = 0; i < p.n; ++i)
+      if (p.jt_ptr[i + 1] - p.jt_ptr[i] > 256) long_cols.push_back(i);   // = IPM_LONG_COLUMN (rpm_ipm_kernels.hip)
+    D.n_long = int(long_cols.size());
+    A_(ipm_alloc_c(h, &D.long_cols, long_cols));
+  }
   A_(ipm_alloc_c(h, &D.gl, e.gl)); A_(ipm_alloc_c(h, &D.gu, e.gu));
   A_(ipm_alloc(h, &D.v, B * p.nv)); A_(ipm_alloc(h, &D.vl, B * p.nv)); A_(ipm_alloc(h, &D.vu, B * p.nv));
   A_(ipm_alloc(h, &D.zL, B * p.nv)); A_(ipm_alloc(h, &D.zU, B * p.nv)); A_(ipm_alloc(h, &D.lam, B * p.m));
@@ -159,7 +166,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
       subs.push_back(KktSub{KktGeom{p.Nt, p.Nb, p.nb, p.b, p.CS}, 0, 0});
     }
     D.n_sub = int(subs.size());
-    D.n_l1 = p.nd ? D.n_sub - 1 : 0;
+    D.n_l2 = p.nd ? p.n_l2 : 0;
+    D.n_l1 = p.nd ? D.n_sub - 1 - D.n_l2 : 0;
     D.max_sub_nt = 0;
     for (const KktSub& q : subs) D.max_sub_nt = std::max(D.max_sub_nt, q.g.Nt);
     A_(ipm_alloc_c(h, &D.subs, subs));
@@ -168,6 +176,10 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     A_(ipm_alloc_c(h, &D.rg_ptr, p.rg_ptr)); A_(ipm_alloc_c(h, &D.rg_src, p.rg_src)); A_(ipm_alloc_c(h, &D.rg_dst, p.rg_dst));
     A_(ipm_alloc_c(h, &D.rs_dst, p.rs_dst)); A_(ipm_alloc_c(h, &D.rs_src, p.rs_src)); A_(ipm_alloc_c(h, &D.gap_pos, p.gap_pos));
     D.n_cg = int(p.cg_dst.size()); D.n_rg = int(p.rg_dst.size()); D.n_rs = int(p.rs_dst.size()); D.n_gap = int(p.gap_pos.size());
+    A_(ipm_alloc_c(h, &D.cg2_ptr, p.cg2_ptr)); A_(ipm_alloc_c(h, &D.cg2_src, p.cg2_src)); A_(ipm_alloc_c(h, &D.cg2_dst, p.cg2_dst));
+    A_(ipm_alloc_c(h, &D.rg2_ptr, p.rg2_ptr)); A_(ipm_alloc_c(h, &D.rg2_src, p.rg2_src)); A_(ipm_alloc_c(h, &D.rg2_dst, p.rg2_dst));
+    A_(ipm_alloc_c(h, &D.rs2_dst, p.rs2_dst)); A_(ipm_alloc_c(h, &D.rs2_src, p.rs2_src));
+    D.n_cg2 = int(p.cg2_dst.size()); D.n_rg2 = int(p.rg2_dst.size()); D.n_rs2 = int(p.rs2_dst.size());
   }
 #undef A_
   if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt), 4 * sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc"; return fail(RPM_E_DEVICE); }

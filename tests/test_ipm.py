@@ -150,11 +150,12 @@ def _random_kkt_dense(ipm, n, B, seed):
     return dense, sign, int(inside.sum())
 
 
-ND_LAYOUTS = LAYOUTS + [("launch_ragged", lambda: problems.launch(), 1), ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), 2)]
+ND_LAYOUTS = LAYOUTS + [("launch_ragged", lambda: problems.launch(), 1), ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), 2),
+                        ("quadrotor_24x4", lambda: problems.quadrotor(24, 4), 2), ("launch_16x4", lambda: problems.launch(16, 4), 1)]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nested", [0, 1], ids=["band", "nested"])
+@pytest.mark.parametrize("nested", [0, 1, 2], ids=["band", "nested", "nested_3_levels"])
 @pytest.mark.parametrize("name,make,B", ND_LAYOUTS, ids=[c[0] for c in ND_LAYOUTS])
 def test_kkt_factorisation_layouts_against_numpy(built, name, make, B, nested):
     """Band + border LDL^T and the nested dissection over the mesh intervals (every interval eliminated by its own
@@ -169,8 +170,13 @@ def test_kkt_factorisation_layouts_against_numpy(built, name, make, B, nested):
         for i, (mesh, nodes) in enumerate(meshes):
             problems.set_mesh(prob.GetPhase(i), mesh, nodes)
     eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
-    eng.set_option("ipm_nested", nested)
+    eng.set_option("ipm_nested", min(nested, 1))
+    if nested == 2:                  # the separator system cut once more, into groups of 48 of its positions (at least 3 bandwidths)
+        eng.set_option("ipm_nested_group", 48)
     ipm = BatchedIPM(eng)
+    if nested == 2 and name in ("quadrotor_24x4", "launch_16x4"):
+        n_intervals = sum(len(prob.GetPhase(i).GetNodesPerInterval()) for i in range(prob.GetPhaseNum()))
+        assert ipm.subproblems().shape[0] >= n_intervals + 3               # intervals, >= 2 groups, last level
     dense, sign, filled = _random_kkt_dense(ipm, eng.n, B, 11)
     assert filled > 4 * sign.size
     rhs = np.random.RandomState(5).uniform(-1, 1, size=(B, sign.size))
@@ -618,6 +624,6 @@ def test_device_solves_the_metric_problem(built):
     g = orc.Oracle(problems.launch(64, 16)).eval_g(r["x"][0])
     _, _, gl, gu = orc.Oracle(problems.launch(64, 16)).bounds()
     assert max((gl - g).max(), (g - gu).max()) < 1e-7
-    assert ipm.subproblems().shape[0] == 257
+    assert ipm.subproblems().shape[0] == 256 + 11 + 1          # interval blocks, groups of the separator system, last level
     ipm.close()
     eng.close()
