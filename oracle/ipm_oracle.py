@@ -8,7 +8,7 @@ algorithm for large-scale nonlinear programming", Math. Program. 106 (2006) — 
   optimality error (5)/(6), barrier update (7), tau (8), primal-dual system (13) with dz from (12), fraction to the
   boundary (15), multiplier reset (16), filter acceptance (18)-(20), filter update (22), alpha_min (23), inertia
   correction Algorithm IC, initial point section 3.6 (bound_push / bound_frac), constants = Ipopt 3.12 defaults.
-Restated in round 2 (what the metric problem, Delta-III, turned out to need — tools/exp/ has the experiments):
+Restated in round 2 (what the metric problem, Delta-III, turned out to need — tests/experiments/ has the experiments):
   * bound_relax_factor (Ipopt option, default 1e-8): every finite bound of a free variable / inequality row is moved out
     by 1e-8 max(1,|bound|) before anything else.  Delta-III has no strict interior without it (burn rates and phase
     durations are fixed, so each phase's final mass EQUALS its lower bound by the dynamics alone);
@@ -21,7 +21,7 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     lambda = 0 when they exceed 1e3).  One simplification: the restoration problem's Hessian leaves out the constraint
     curvature sum lambda_j Hess c_j (a Gauss-Newton model of it: no inertia correction is ever needed there).
 Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): adaptive barrier update (the reference sets
-mu_strategy=adaptive; monotone here — a LOQO-rule variant in tools/exp/ converges on Delta-III too, in twice the
+mu_strategy=adaptive; monotone here — a LOQO-rule variant in tests/experiments/ converges on Delta-III too, in twice the
 iterations), NLP scaling, least-squares multipliers at the very first iterate (lambda_0 = 0), watchdog.  One deviation:
 the constraint regularisation delta_c = 1e-8 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
