@@ -108,7 +108,7 @@ __device__ inline double reset16(double z, double s, double mu, double ks) { ret
 // in 1.4 ms — take a workgroup each (blockIdx.x >= the thread-per-unknown blocks), summed in a fixed order.
 constexpr int IPM_LONG_COLUMN = 256;
 __global__ __launch_bounds__(256) void ipm_jt_lambda_kernel(IpmDev D, int n_thread_blocks) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   const int bi = blockIdx.y;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void ipm_jt_lambda_kernel(IpmDev D, int n_thre
   }
   D.glag[size_t(bi) * D.nv + i] = acc;
 }
-__global__ __launch_bounds__(256) void ipm_residual_kernel(IpmDev D) {
-  __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
+  __shared__ double sh[16];
   __shared__ int verdict;       // restoration: 0 stay, 1 leave it (least-squares multipliers next), 2 stop
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
@@ -822,8 +822,8 @@ __device__ inline double alpha_min23(const IpmOpts& op, double theta, double the
   return op.gamma_alpha * amin;
 }
 
-__global__ __launch_bounds__(256) void ipm_direction_kernel(IpmDev D) {
-  __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
+  __shared__ double sh[16];
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
   const int status = S.status, mode = S.mode;
@@ -924,8 +924,8 @@ __global__ void ipm_soc_rhs_kernel(IpmDev D) {
     rhs[D.pos[i]] = -r;
   }
 }
-__global__ __launch_bounds__(256) void ipm_soc_direction_kernel(IpmDev D) {
-  __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void ipm_soc_direction_kernel(IpmDev D) {
+  __shared__ double sh[16];
   const int bi = blockIdx.x;
   IpmInst& S = D.inst[bi];
   const int go = S.status == 0 && S.soc_req;
@@ -949,8 +949,8 @@ __global__ void ipm_trial_kernel(IpmDev D) {
   const size_t o = size_t(bi) * D.nv + i;
   D.xt[size_t(bi) * D.n + i] = S.soc_on ? D.v[o] + S.alpha_soc * D.dv2[o] : D.v[o] + S.alpha * D.dv[o];
 }
-__global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
-  __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
+  __shared__ double sh[16];
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
   const int go = S.status == 0 && !S.accepted, mode = S.mode, soc = S.soc_on;
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(256) void ipm_accept_kernel(IpmDev D) {
 }
 
 // ------------------------------------------------------------------------------------------------ step
-__global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
+__global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   const int bi = blockIdx.x, t = threadIdx.x;
   IpmInst& S = D.inst[bi];
   // every thread reads the instance's verdicts BEFORE thread 0 changes any of them (a late wave must not see
@@ -1168,6 +1168,9 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmDev D) {
 
 
 // ------------------------------------------------------------------------------------------------ launchers
+// threads per instance of the one-workgroup-per-instance vector kernels: a few large instances (the metric problem: n = 41 k)
+// get 16 waves each, a sweep of many small ones 4
+static unsigned vec_threads(const IpmDev& D) { return D.B <= 32 && D.nv >= 4096 ? 1024u : 256u; }
 void ipm_launch_init(const IpmDev& D, const double* d_x0, hipStream_t st) {
   hipLaunchKernelGGL(ipm_init_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D, d_x0);
 }
@@ -1180,7 +1183,7 @@ void ipm_launch_pack_x(const IpmDev& D, hipStream_t st) {
 void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
   const int tb = (D.nv + 255) / 256;
   hipLaunchKernelGGL(ipm_jt_lambda_kernel, dim3(unsigned(tb + D.n_long), unsigned(D.B)), dim3(256), 0, st, D, tb);
-  hipLaunchKernelGGL(ipm_residual_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_residual_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
   const int assemble_blocks = std::max(1, std::min(64, (nnz_max + 255) / 256));
@@ -1192,23 +1195,23 @@ void ipm_launch_inertia(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_inertia_kernel, dim3(unsigned((D.B + 255) / 256)), dim3(256), 0, st, D);
 }
 void ipm_launch_direction(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_direction_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_direction_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_trial(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_trial_kernel, dim3(unsigned((D.n + 255) / 256), unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_accept(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_accept_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_accept_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_update(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_update_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_update_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st) {
   const int blocks = std::max(1, std::min(64, (std::max(D.nv, D.m) + 255) / 256));
   hipLaunchKernelGGL(ipm_soc_rhs_kernel, dim3(unsigned(blocks), unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_soc_direction_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_soc_direction_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
   if (p.nd) return p.max_factor_lds;
