@@ -393,8 +393,11 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
 #ifndef IPM_LB
 #define IPM_LB 3   // waves per SIMD the 4-tile factorisation is compiled for
 #endif
-template <int MT>           // 16-row tiles per wave: 4 (block columns of up to 256 rows, 3 workgroups per CU), 6 (384 rows, 2 per CU: at 3 it spills 91 VGPRs) or 8 (512 rows)
-__global__ __launch_bounds__(256, MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1)) void kkt_factor_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0,
+// MT 16-row tiles per wave, NW waves: <4,4> block columns of up to 256 rows, 3 workgroups per CU; <6,4> 384 rows, 2 per CU (at 3 it
+// spills 91 VGPRs); <8,4> 512 rows; <3,8> 384 rows over 8 waves — for a few large instances (the metric problem: 268 workgroups
+// on 256 CUs), where a second wave per SIMD halves every wave's share of a block column
+template <int MT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1))) void kkt_factor_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0,
                                                                                int n_here, int n_sub, IpmInst* inst, int* piv, int partial) {
   // workgroup = (instance, sub-problem sub0 + s).  partial: nested dissection level 1 — eliminate the band part only and
   // leave the Schur complement of the border x border corner, unfactored, in the corner's storage.
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1)) void kkt
     int lstep[MT], kfirst[MT], gfirst[MT], rrow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int q0 = (wv + 4 * i) * 16, q = q0 + lr;
+      const int q0 = (wv + NW * i) * 16, q = q0 + lr;
       const bool valid = q < rows;
       const int r = q < w ? J0 + q : (q - w < nrb ? J1 + (q - w) : G.Nb + (q - w - nrb));
       const bool border = r >= G.Nb;
@@ -532,11 +535,11 @@ __global__ __launch_bounds__(256, MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1)) void kkt
     // panel rows: Y^T = L11^-1 A^T (4 products with the accumulator as B operand), L21^T = D^-1 Y^T
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      if ((wv + 4 * i) * 16 >= rows) continue;
+      if ((wv + NW * i) * 16 >= rows) continue;
       d4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * W + 4 * g + lq], acc[i][g], y, 0, 0, 0);
-      const int q = (wv + 4 * i) * 16 + lr, r = rrow[i];
+      const int q = (wv + NW * i) * 16 + lr, r = rrow[i];
       if (r < 0 || q < w) continue;
       const bool border = r >= G.Nb;
 #pragma unroll
@@ -1220,6 +1223,7 @@ size_t kkt_factor_lds_bytes(const IpmPlan& p) {
 }
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;
+  if (tiles_per_wave == 38) return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
   return hipFuncSetAttribute(tiles_per_wave == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>)
                              : tiles_per_wave == 6 ? reinterpret_cast<const void*>(kkt_factor_kernel<6>)
                                                    : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
@@ -1249,7 +1253,9 @@ __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __res
 
 static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partial, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
   const dim3 grid(unsigned(D.B) * unsigned(n_here));
-  if (tiles_per_wave == 4)
+  if (tiles_per_wave == 38)
+    hipLaunchKernelGGL((kkt_factor_kernel<3, 8>), grid, dim3(512), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
+  else if (tiles_per_wave == 4)
     hipLaunchKernelGGL(kkt_factor_kernel<4>, grid, dim3(256), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
   else if (tiles_per_wave == 6)
     hipLaunchKernelGGL(kkt_factor_kernel<6>, grid, dim3(256), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
