@@ -236,7 +236,9 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       "restoration" (1), "restoration_max_iter" (300), "restoration_penalty" (1000, Ipopt's rho),
  *                       "acceptable_tol" (1e-6), "acceptable_iter" (15), "bound_relax_factor" (1e-8, as Ipopt: finite bounds
  *                       of free unknowns move out by this * max(1, |bound|), so a solution may sit that far outside them),
- *                       "max_soc" (4, second-order correction steps per iteration; 0 = off)
+ *                       "max_soc" (4, second-order correction steps per iteration; 0 = off),
+ *                       "mu_strategy" (0 monotone Fiacco-McCormick rule; 1 adaptive = what lpopc asks Ipopt for,
+ *                       Core/LpNLPSolver.cpp:28, with the LOQO oracle and the kkt-error globalisation: DESIGN.md f-2)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,

@@ -26,6 +26,8 @@ struct IpmOpts {
   double bound_relax = 1e-8;         // Ipopt's bound_relax_factor: finite bounds of free unknowns move out by this * max(1, |bound|)
   int max_soc = 4;                   // second-order correction steps per iteration (paper A-5.5 .. A-5.9)
   double kappa_soc = 0.99;
+  int mu_adaptive = 0;               // 1: Ipopt's mu_strategy=adaptive with the LOQO oracle and the kkt-error globalisation (oracle/ipm_oracle.py)
+  double mu_max_fact = 1e3, mu_red_fact = 0.9999, mu_init_factor = 0.8;
 };
 
 struct IpmInst {
@@ -39,6 +41,8 @@ struct IpmInst {
   double mu_r, th_r, thr_max, thr_min, phi_r; // restoration: its own barrier parameter, infeasibility |c - p + n|_1, filter bounds, barrier objective
   int nrfilt, soc_on, soc_req, soc_p, use_soc, n_soc;   // restoration filter entries; second-order correction state
   double alpha_soc, az_soc, th_old_soc;
+  double mu_max, refs[4];            // adaptive barrier update: upper bound of mu, KKT errors of the last accepted iterates
+  int fixed_mode, nrefs;             // 0 = free mode (mu from the oracle every iteration), 1 = monotone rule until progress resumes
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv, *lam = D.lam + size_t(bi) * D.m;
   const double *g = D.g + size_t(bi) * D.sg, *glag = D.glag + size_t(bi) * D.nv;
   double dinf = 0, cinf = 0, th1 = 0, cmax = 0, cmin = 1e300, sl = 0, sz = 0, ln = 0, bad = 0, nzb = 0;
+  double csq = 0, dsq = 0, psum = 0, psq = 0, nfree = 0;      // 2-norms for the adaptive barrier update's KKT error
   // pass 1: constraint values and what does not depend on the multipliers
   for (int r = t; r < D.m; r += blockDim.x) {
     const int s = D.row_slack[r];
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     if (!(fabs(cr) < 1e300)) bad = 1;
     cinf = fmax(cinf, fabs(cr));
     th1 += fabs(cr);
+    csq += cr * cr;
   }
   cinf = block_red(cinf, 1, sh); th1 = block_red(th1, 0, sh);
   if (mode_in == 2) {
@@ -241,17 +243,23 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     const double acc = glag[i];               // grad f + A^T lambda (ipm_jt_lambda_kernel)
     const double l = vl[i], u = vu[i];
     if (l != u) {
-      dinf = fmax(dinf, fabs(acc - zL[i] + zU[i]));
+      const double dres = acc - zL[i] + zU[i];
+      dinf = fmax(dinf, fabs(dres));
+      dsq += dres * dres; nfree += 1;
       if (!(fabs(acc) < 1e300)) bad = 1;
       if (l > -IPM_INF) {
         const double d = v[i] - l, pr = zL[i] * d;
-        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zL[i]; ln += log(d); nzb += 1;
+        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zL[i]; ln += log(d); nzb += 1; psum += pr; psq += pr * pr;
       }
       if (u < IPM_INF) {
         const double d = u - v[i], pr = zU[i] * d;
-        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zU[i]; ln += log(d); nzb += 1;
+        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zU[i]; ln += log(d); nzb += 1; psum += pr; psq += pr * pr;
       }
     }
+  }
+  if (D.o.mu_adaptive) {
+    csq = block_red(csq, 0, sh); dsq = block_red(dsq, 0, sh); psum = block_red(psum, 0, sh); psq = block_red(psq, 0, sh);
+    nfree = block_red(nfree, 0, sh);
   }
   for (int r = t; r < D.m; r += blockDim.x) sl += fabs(lam[r]);
   dinf = block_red(dinf, 1, sh);
@@ -276,7 +284,31 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   }
   const double mu_min = o.tol / 10.0;
   double mu = S.mu;
-  for (int guard = 0; guard < 64; ++guard) {
+  bool from_oracle = false;
+  if (o.mu_adaptive && nzb > 0) {      // Ipopt's adaptive update: LOQO oracle, kkt-error globalisation (oracle/ipm_oracle.py)
+    const double avg = psum / nzb;
+    if (S.mu_max == 0.0) S.mu_max = o.mu_max_fact * avg;
+    const double kkt_err = dsq / fmax(1.0, nfree) + (D.m ? csq / D.m : 0.0) + psq / nzb;
+    bool progress = S.nrefs < 4;
+    for (int k = 0; !progress && k < S.nrefs; ++k) progress = kkt_err <= o.mu_red_fact * S.refs[k];
+    double mu_new = -1.0;
+    if (progress) {
+      S.fixed_mode = 0;
+      if (S.nrefs < 4) S.refs[S.nrefs++] = kkt_err;
+      else { S.refs[0] = S.refs[1]; S.refs[1] = S.refs[2]; S.refs[2] = S.refs[3]; S.refs[3] = kkt_err; }
+      const double xi = cmin / avg, fac = fmin(0.05 * (1.0 - xi) / xi, 2.0);
+      mu_new = fmax(mu_min, fmin(0.1 * fac * fac * fac * avg, S.mu_max));
+    } else if (!S.fixed_mode) {        // no progress in the free mode: the monotone rule takes over from here
+      S.fixed_mode = 1;
+      mu_new = fmax(mu_min, fmin(o.mu_init_factor * avg, S.mu_max));
+    }
+    if (mu_new >= 0.0) {
+      if (mu_new != mu) S.nfilt = 0;
+      mu = mu_new;
+      from_oracle = true;
+    }
+  }
+  for (int guard = 0; !from_oracle && guard < 64; ++guard) {
     const double comp = nzb > 0 ? fmax(fabs(cmax - mu), fabs(cmin - mu)) : 0.0;
     const double emu = fmax(fmax(dinf / sd, cinf), comp / sc);
     if (!(emu <= o.kappa_eps * mu) || mu <= mu_min) break;

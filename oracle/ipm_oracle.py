@@ -20,9 +20,16 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     of where it entered and the original filter accepts the point; then least-squares multipliers (section 3.6,
     lambda = 0 when they exceed 1e3).  One simplification: the restoration problem's Hessian leaves out the constraint
     curvature sum lambda_j Hess c_j (a Gauss-Newton model of it: no inertia correction is ever needed there).
-Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): adaptive barrier update (the reference sets
-mu_strategy=adaptive; monotone here — a LOQO-rule variant in tests/experiments/ converges on Delta-III too, in twice the
-iterations), NLP scaling, least-squares multipliers at the very first iterate (lambda_0 = 0), watchdog.  One deviation:
+  * mu_strategy = "adaptive" (what the reference asks Ipopt for, Core/LpNLPSolver.cpp:28) as an OPTION, default "monotone":
+    Ipopt's adaptive update (Nocedal, Waechter, Waltz, SIAM J. Optim. 19, 2009) with the LOQO oracle (Ipopt's mu_oracle=loqo:
+    mu = sigma * average complementarity, sigma = 0.1 min(0.05 (1 - xi) / xi, 2)^3, xi = smallest / average complementarity)
+    and the kkt-error globalisation (free mode while the KKT error — 2-norm-squared of dual / primal infeasibility and
+    complementarity, each divided by its length — is below 0.9999 of one of the last 4 accepted values, otherwise the
+    monotone rule from mu = 0.8 * average complementarity until it is again); the filter is emptied whenever mu changes.
+    Ipopt's default oracle there is the quality function (two more solves and a line search over sigma per iteration): not restated.
+    Not the default here because the monotone rule needs half the iterations on Delta-III.
+Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle, NLP scaling,
+least-squares multipliers at the very first iterate (lambda_0 = 0), watchdog.  One deviation:
 the constraint regularisation delta_c = 1e-8 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
 Parity status: UNPINNED by the reference (it holds no solver traces); pinned here by known optima and by scipy.
@@ -41,7 +48,9 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-8, delta_w_first=1e-4, delta_w_min=1e-20,
                 delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=300, kappa_resto=0.9,
                 acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense", bound_relax_factor=1e-8, max_soc=4, kappa_soc=0.99,
-                resto_rho=1000.0, mult_reset=1e3)
+                resto_rho=1000.0, mult_reset=1e3,
+                mu_strategy="monotone", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
+                adaptive_mu_monotone_init_factor=0.8)
 
 
 def _n_positive(K):
@@ -147,6 +156,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         return float(np.min(-tau_ * w_[k] / dw_[k])) if k.any() else 1.0
 
     n_resto = n_acc = 0
+    free_mode, refs, mu_max = True, [], None          # mu_strategy = adaptive
 
     def _restore():
         """Ipopt's restoration phase (paper section 3.3) with p, n eliminated from the Newton system; see the module header.
@@ -304,13 +314,39 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         if it == 0:
             theta_max, theta_min = 1e4 * max(1.0, theta), 1e-4 * max(1.0, theta)
         mu_min = o["tol"] / 10.0
-        for _ in range(64):
-            comp = max(abs(cmax - mu), abs(cmin - mu)) if nzb else 0.0
-            emu = max(dinf / sd, cinf, comp / sc)
-            if not (emu <= o["kappa_eps"] * mu) or mu <= mu_min:
-                break
-            mu = max(mu_min, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))                        # (7)
-            filt = []
+        adaptive = o["mu_strategy"] == "adaptive" and nzb > 0
+        oracle_mu = None
+        if adaptive:
+            avg = float(prods.mean())
+            if mu_max is None:
+                mu_max = o["mu_max_fact"] * avg
+            dres = (glag - zL + zU)[free]
+            kkt_err = float(dres @ dres) / max(1, dres.size) + (float(c @ c) / m if m else 0.0) + float(prods @ prods) / nzb
+            full = len(refs) >= o["adaptive_mu_kkterror_red_iters"]
+            progress = (not full) or any(kkt_err <= o["adaptive_mu_kkterror_red_fact"] * r_ for r_ in refs)
+            if progress:
+                free_mode = True
+                refs.append(kkt_err)
+                if len(refs) > o["adaptive_mu_kkterror_red_iters"]:
+                    refs.pop(0)
+                xi = float(prods.min()) / avg
+                sigma_l = 0.1 * min(0.05 * (1.0 - xi) / xi, 2.0) ** 3
+                oracle_mu = max(mu_min, min(sigma_l * avg, mu_max))
+            elif free_mode:                     # no progress in the free mode: the monotone rule takes over from here
+                free_mode = False
+                oracle_mu = max(mu_min, min(o["adaptive_mu_monotone_init_factor"] * avg, mu_max))
+        if oracle_mu is not None:
+            if oracle_mu != mu:
+                filt = []
+            mu = oracle_mu
+        else:
+            for _ in range(64):
+                comp = max(abs(cmax - mu), abs(cmin - mu)) if nzb else 0.0
+                emu = max(dinf / sd, cinf, comp / sc)
+                if not (emu <= o["kappa_eps"] * mu) or mu <= mu_min:
+                    break
+                mu = max(mu_min, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))                        # (7)
+                filt = []
         tau = max(o["tau_min"], 1.0 - mu)                                                         # (8)
         phi = f - mu * ln
         hv = orc.eval_h(x, 1.0, lam)

@@ -607,6 +607,58 @@ def test_device_reproduces_ipm_fixture(built, path):
     eng.close()
 
 
+ADAPTIVE = [("bryson_denham_default", lambda: problems.bryson_denham(), 1e-8), ("brachistochrone", lambda: problems.brachistochrone(2, 10), 1e-8),
+            ("quadrotor_3x6", lambda: problems.quadrotor(3, 6, pref=(0.4, 0.8, -0.6)), 1e-8),
+            ("hypersensitive", lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), 1e-8)]
+
+
+@pytest.mark.parametrize("name,make,tol", ADAPTIVE, ids=[c[0] for c in ADAPTIVE])
+def test_restatement_adaptive_barrier_update(name, make, tol):
+    """mu_strategy = adaptive (what the reference asks Ipopt for; LOQO oracle, kkt-error globalisation) ends where the monotone
+    rule ends on the convex / well-behaved problems, in no more than 1.5 x the iterations."""
+    o = orc.Oracle(make(), _exact())
+    a = ipm_oracle.solve(o, o.starting_point(), tol=tol, mu_strategy="adaptive")
+    b = ipm_oracle.solve(o, o.starting_point(), tol=tol)
+    assert a["status"] == 0 and b["status"] == 0
+    assert abs(a["obj"] - b["obj"]) <= 1e-6 * max(1.0, abs(b["obj"]))
+    assert a["iterations"] <= 1.5 * b["iterations"] + 2
+    assert len(set(round(np.log10(t["mu"]), 3) for t in a["trace"])) > len(set(round(np.log10(t["mu"]), 3) for t in b["trace"]))   # mu moves every iteration
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,tol", ADAPTIVE, ids=[c[0] for c in ADAPTIVE])
+def test_device_adaptive_barrier_update_against_restatement(built, name, make, tol):
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = make()
+    o = orc.Oracle(prob, _exact())
+    ref = ipm_oracle.solve(o, o.starting_point(), tol=tol, mu_strategy="adaptive")
+    eng = NLPEngine(prob, _exact(), n_instances=2, device=0)
+    ipm = BatchedIPM(eng, tol=tol, mu_strategy=1, trace=100)
+    r = ipm.solve(np.tile(o.starting_point(), (2, 1)))
+    assert (r["status"] == 0).all() and ref["status"] == 0
+    assert (np.abs(r["iterations"].astype(int) - ref["iterations"]) <= 1).all()
+    assert np.max(np.abs(r["obj"] - ref["obj"])) <= 1e-8 * max(1.0, abs(ref["obj"]))
+    tr = ipm.trace(0)
+    # the same barrier parameters from the oracle's rule, step by step (from the second step on the constraint Hessians — second
+    # differences that differ by 1e-9 .. 1e-3 between CPU and GPU — enter, and the two paths run ~1e-4 apart to the same optimum)
+    for k in range(min(4, len(tr), len(ref["trace"]))):
+        assert abs(tr[k, 2] - ref["trace"][k]["mu"]) <= (1e-6 if k < 2 else 1e-2) * ref["trace"][k]["mu"], (k, tr[k, 2], ref["trace"][k]["mu"])
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_device_solves_delta_iii_with_the_adaptive_update(built):
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    eng = NLPEngine(problems.launch(4, 8), _exact(), device=0)
+    ipm = BatchedIPM(eng, max_iter=1500, mu_strategy=1)
+    r = ipm.solve(eng.get_starting_point()[None, :])
+    assert r["status"][0] in (0, 1), (r["status"], r["iterations"], r["kkt_error"])
+    assert abs(-r["obj"][0] * 301454.0 - 7529.71) < 0.01
+    ipm.close()
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_device_solves_the_metric_problem(built):
     """BASELINE's metric problem at full size — Delta-III, 4 phases x 64 intervals x 16 LGR points, n = 40 996, KKT order
