@@ -484,6 +484,32 @@ def test_device_restoration_against_restatement(built):
 
 
 @pytest.mark.gpu
+def test_instances_of_a_batch_switch_modes_independently(built):
+    """One batch, three starts: lpopc's guess (the line search gives up -> restoration phase -> least-squares multipliers), the
+    converged solution (a few regular iterations), a perturbed guess.  Every kernel takes the mode per instance; the solve loop
+    on the host does not know about modes at all."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = problems.bryson_denham()
+    o = orc.Oracle(prob, _exact())
+    ref = ipm_oracle.solve(o, o.starting_point(), tol=1e-6)
+    assert ref["status"] == 0 and ref["restorations"] >= 1
+    x0 = np.stack([o.starting_point(), ref["x"], o.starting_point() * (1 + 1e-2 * np.random.RandomState(2).uniform(-1, 1, o.n))])
+    eng = NLPEngine(prob, _exact(), n_instances=3, device=0)
+    ipm = BatchedIPM(eng, tol=1e-6)
+    r = ipm.solve(x0)
+    assert (r["status"] == 0).all(), r["status"]
+    assert np.max(np.abs(r["obj"] - ref["obj"])) <= 1e-5 * abs(ref["obj"])
+    n_resto = ipm.restorations()
+    assert n_resto[0] == ref["restorations"] and n_resto[1] == 0
+    assert r["iterations"][1] < r["iterations"][0] - 5
+    for bi in (1, 2):                                     # each against the restatement run from its own start
+        rb = ipm_oracle.solve(o, x0[bi], tol=1e-6)
+        assert rb["status"] == 0 and abs(r["obj"][bi] - rb["obj"]) <= 1e-5 * abs(rb["obj"])
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_sweep_with_per_instance_targets(built):
     """An MPC sweep whose instances differ in the problem constants (tracking target): the device solver against the
     restatement run on separately built problems; the batched Hessian uses every instance's own constants too."""
