@@ -33,6 +33,12 @@ __device__ inline double block_red(double v, int kind, double* sh) {   // 0 sum,
   for (int i = 1; i < int(blockDim.x >> 6); ++i) r = kind == 0 ? r + sh[i] : (kind == 1 ? fmax(r, sh[i]) : fmin(r, sh[i]));
   return r;
 }
+// value of `v` in lane `lane` of the wave (lane uniform; a constant after unrolling): two v_readlane_b32 instead of the
+// ds_bpermute pair of __shfl
+__device__ inline double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline bool has_lo(double l, double u) { return l > -IPM_INF && l != u; }
 __device__ inline bool has_up(double l, double u) { return u < IPM_INF && l != u; }
 
@@ -455,6 +461,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6
   const int nb = G.nb;
   const int wv = t >> 6, lr = t & 15, lq = (t & 63) >> 4;
 #ifdef IPM_TIMING
+#ifndef IPM_TIMING_SUB
+#define IPM_TIMING_SUB (-1)   // which sub-problem's workgroup reports its phase clocks (-1: the last level's)
+#endif
   long long tc[6] = {0, 0, 0, 0, 0, 0}, t_prev = wall_clock64();
 #define IPM_TICK(i) do { __syncthreads(); const long long _n = wall_clock64(); tc[i] += _n - t_prev; t_prev = _n; } while (0)
 #else
@@ -538,13 +547,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6
       }
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        // all cross-lane reads of the step first (they are independent), then the arithmetic
-        const double dk = __shfl(row[k], k, 16);                   // pivot: row k's own diagonal
+        // all cross-lane reads of the step first (they are independent), then the arithmetic.  The four groups of 16 lanes hold
+        // the same rows, so lane j of the wave serves everybody: scalar reads (v_readlane) instead of LDS-routed shuffles
+        const double dk = readlane_d(row[k], k);                   // pivot: row k's own diagonal
         double ajk[W], mkj[W];
 #pragma unroll
-        for (int j = k + 1; j < W; ++j) ajk[j] = __shfl(row[k], j, 16);     // a(j, k) before scaling
+        for (int j = k + 1; j < W; ++j) ajk[j] = readlane_d(row[k], j);     // a(j, k) before scaling
 #pragma unroll
-        for (int j = 0; j <= k; ++j) mkj[j] = __shfl(inv[j], k, 16);        // row k of the inverse so far
+        for (int j = 0; j <= k; ++j) mkj[j] = readlane_d(inv[j], k);        // row k of the inverse so far
         const double lik = lr > k ? row[k] / dk : 0.0;
 #pragma unroll
         for (int j = k + 1; j < W; ++j)
@@ -593,13 +603,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6
     }
     __syncthreads();
     IPM_TICK(3);
-    for (int idx = t; idx < nb * nb; idx += nt) {          // corner -= L_border D L_border^T of this block column
-      const int r = idx / nb, c2 = idx % nb;
-      if (r < c2) continue;
-      double s = 0.0;
+    {   // corner -= L_border D L_border^T of this block column: the 16 x 16 tiles of its lower triangle dealt to the waves, four
+        // matrix products each (the scalar form — 16 FMAs per entry fed by LDS reads 128 bytes apart, a 16-way bank conflict —
+        // was 73 % of a separator group's factorisation and 23 % of an interval's)
+      const int nbt = (nb + 15) >> 4, ntl = nbt * (nbt + 1) / 2;
+      for (int tl = wv; tl < ntl; tl += NW) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+        const int tj = tl - ti * (ti + 1) / 2, ra = ti * 16 + lr, cb = tj * 16 + lr;
+        d4 cacc;
 #pragma unroll
-      for (int c = 0; c < W; ++c) s = __builtin_fma(BL[r * W + c], BY[c2 * W + c], s);
-      C[idx] -= s;
+        for (int g = 0; g < 4; ++g) {
+          const int rr = ti * 16 + lq + 4 * g;
+          cacc[g] = (rr < nb && cb < nb) ? C[rr * nb + cb] : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const double a = ra < nb ? -BL[ra * W + 4 * g + lq] : 0.0, bq = cb < nb ? BY[cb * W + 4 * g + lq] : 0.0;
+          cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, cacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rr = ti * 16 + lq + 4 * g;
+          if (rr < nb && cb <= rr) C[rr * nb + cb] = cacc[g];
+        }
+      }
     }
     __syncthreads();
     IPM_TICK(4);
@@ -615,6 +643,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6
     if (nbad) atomicAdd(&cnt[2], nbad);
     __syncthreads();
     if (t < 3) piv[(size_t(bi) * n_sub + sidx) * 3 + t] = cnt[t];
+#ifdef IPM_TIMING
+    if (t == 0 && sidx == IPM_TIMING_SUB)
+      for (int i = 0; i < 6; ++i) inst[bi].dbg[i] = tc[i];
+#endif
     return;
   }
   for (int k = 0; k < nb; ++k) {                            // the corner, unblocked, in LDS
@@ -663,7 +695,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6
   IPM_TICK(5);
   if (t < 3) piv[(size_t(bi) * n_sub + sidx) * 3 + t] = cnt[t];
 #ifdef IPM_TIMING
-  if (t == 0)
+  if (t == 0 && (IPM_TIMING_SUB < 0 || sidx == IPM_TIMING_SUB))
     for (int i = 0; i < 6; ++i) inst[bi].dbg[i] = tc[i];
 #endif
 }

@@ -520,6 +520,10 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   if (d_lambda) IPM_TRY(h, hipMemcpyAsync(d_lambda, D.lam, size_t(B) * p.m * sizeof(double), hipMemcpyDeviceToDevice, st));
   IPM_TRY(h, hipMemcpyAsync(h->h_inst.data(), D.inst, size_t(B) * sizeof(IpmInst), hipMemcpyDeviceToHost, st));
   IPM_TRY(h, hipStreamSynchronize(st));
+#ifdef IPM_TIMING
+  fprintf(stderr, "last factorisation of instance 0, phase clocks [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld\n",
+          h->h_inst[0].dbg[0], h->h_inst[0].dbg[1], h->h_inst[0].dbg[2], h->h_inst[0].dbg[3], h->h_inst[0].dbg[4], h->h_inst[0].dbg[5]);
+#endif
   for (unsigned bi = 0; bi < B; ++bi) {
     const IpmInst& S = h->h_inst[bi];
     if (obj) obj[bi] = S.f;
