@@ -429,13 +429,13 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
 // in LDS, is updated right-looking and factored there.  Operand maps (cdna_hip_programming.md §3): A: lane l holds
 // A[l&15][l>>4], B: B[l>>4][l&15], C/D: row (l>>4) + 4 reg, column l&15.
 #ifndef IPM_LB
-#define IPM_LB 3   // waves per SIMD the 4-tile factorisation is compiled for
+#define IPM_LB 2   // waves per SIMD the 4-tile factorisation is compiled for (3: 168 VGPRs, 52 of them spilled since the pivots moved to v_readlane)
 #endif
 // MT 16-row tiles per wave, NW waves: <4,4> block columns of up to 256 rows, 3 workgroups per CU; <6,4> 384 rows, 2 per CU (at 3 it
 // spills 91 VGPRs); <8,4> 512 rows; <3,8> 384 rows over 8 waves — for a few large instances (the metric problem: 268 workgroups
 // on 256 CUs), where a second wave per SIMD halves every wave's share of a block column
 template <int MT, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1))) void kkt_factor_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1))) void kkt_factor_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0,
                                                                                int n_here, int n_sub, IpmInst* inst, int* piv, int partial) {
   // workgroup = (instance, sub-problem sub0 + s).  partial: nested dissection level 1 — eliminate the band part only and
   // leave the Schur complement of the border x border corner, unfactored, in the corner's storage.
@@ -1288,6 +1288,7 @@ size_t kkt_factor_lds_bytes(const IpmPlan& p) {
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;
   if (tiles_per_wave == 38) return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+  if (tiles_per_wave == 28) return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
   return hipFuncSetAttribute(tiles_per_wave == 4 ? reinterpret_cast<const void*>(kkt_factor_kernel<4>)
                              : tiles_per_wave == 6 ? reinterpret_cast<const void*>(kkt_factor_kernel<6>)
                                                    : reinterpret_cast<const void*>(kkt_factor_kernel<IPM_MT>),
@@ -1317,7 +1318,9 @@ __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __res
 
 static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partial, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
   const dim3 grid(unsigned(D.B) * unsigned(n_here));
-  if (tiles_per_wave == 38)
+  if (tiles_per_wave == 28)
+    hipLaunchKernelGGL((kkt_factor_kernel<2, 8>), grid, dim3(512), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
+  else if (tiles_per_wave == 38)
     hipLaunchKernelGGL((kkt_factor_kernel<3, 8>), grid, dim3(512), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
   else if (tiles_per_wave == 4)
     hipLaunchKernelGGL(kkt_factor_kernel<4>, grid, dim3(256), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);

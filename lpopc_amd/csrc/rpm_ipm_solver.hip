@@ -2,6 +2,7 @@
 // iteration three counters come back from the device, nothing else) and the rpm_ipm_* entry points of the C ABI.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -194,6 +195,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   h->factor_mt = p.max_rows <= 256 ? 4 : (p.max_rows <= 384 ? 6 : IPM_MT);
   // a few large instances: fewer sub-problems than two per CU -> 8 waves per workgroup, 3 tiles each (code 38: <3, 8>)
   if (p.nd && p.max_rows > 256 && p.max_rows <= 384 && B * p.subs.size() <= 512) h->factor_mt = 38;
+  if (const char* fm = std::getenv("RPM_IPM_FACTOR_VARIANT")) h->factor_mt = std::atoi(fm);   // experiments: 4, 6, 8, 28 (<2,8>), 38 (<3,8>)
   if (p.max_rows > 4 * IPM_MT * 16) {
     h->err = "band + border of " + std::to_string(p.max_rows - IPM_W) + " rows exceeds the factorisation's 512 rows per block column";
     return fail(RPM_E_UNSUPPORTED);
