@@ -448,8 +448,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
   const KktGeom G = sub.g;
   double* K = Kall + size_t(bi) * kstride + sub.koff;
   extern __shared__ double lds[];
-  double* T = lds;                              // (b + 8) x W
-  double* Dg = T + size_t(G.b + 8) * W;         // W x (W + 1)
+  double* T = lds;                              // (b + 24) x W
+  double* Dg = T + size_t(G.b + 24) * W;        // W x (W + 1)
   double* Mi = Dg + W * (W + 1);                // W x W: L11^-1, row-major
   double* invd = Mi + W * W;                    // W
   double* BL = invd + W;                        // nb x W: L of the border rows in the current block column
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
     const int kbase = max(J0 - G.b, 0), nk = J0 - kbase, ngrp = (nk + 3) >> 2;
     const int nrb = max(min(J1 - 1 + G.b, G.Nb - 1) - J1 + 1, 0), rows = w + nrb + nb, ntile = (rows + 15) >> 4;
 #pragma unroll 4
-    for (int idx = t; idx < (ngrp + 1) * 4 * W; idx += nt) {
+    for (int idx = t; idx < (ngrp + 4) * 4 * W; idx += nt) {      // zero rows behind the last column: the k-loop reads up to 3 groups past it
       const int kk = idx / W, c = idx % W, k = kbase + kk, j = J0 + c;
       T[idx] = (kk < nk && c < w && j - k <= G.b) ? K[G.at(j, k)] * K[G.at(k, k)] : 0.0;
     }
@@ -507,27 +507,36 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
       }
     }
     {
-      // two column groups of L in flight per tile while the previous two are multiplied
+      // KD column groups of L in flight per tile while the previous KD are multiplied (4 where the registers allow: the loop
+      // waits on loads that come from the L2 / Infinity Cache, 2 waves per SIMD hide little of that)
+      constexpr int KD = MT <= 4 ? 4 : 2;
       auto ld = [&](int i, int kg) -> double {
         const int kk = 4 * kg + lq;
         return (kg >= gfirst[i] && kk >= kfirst[i] && kk < nk) ? lp[i][size_t(kk) * lstep[i]] : 0.0;
       };
-      double b0[MT], b1[MT];
+      double bq[KD][MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) { b0[i] = ld(i, 0); b1[i] = ld(i, 1); }
-      for (int kg = 0; kg < ngrp; kg += 2) {
-        const double a0 = -T[(4 * kg + lq) * W + lr], a1 = -T[(4 * kg + 4 + lq) * W + lr];
-        double n0[MT], n1[MT];
+      for (int j = 0; j < KD; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) { n0[i] = ld(i, kg + 2); n1[i] = ld(i, kg + 3); }
+        for (int i = 0; i < MT; ++i) bq[j][i] = ld(i, j);
+      for (int kg = 0; kg < ngrp; kg += KD) {
+        double a[KD], nq[KD][MT];
+#pragma unroll
+        for (int j = 0; j < KD; ++j) a[j] = -T[(4 * (kg + j) + lq) * W + lr];
+#pragma unroll
+        for (int j = 0; j < KD; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) nq[j][i] = ld(i, kg + KD + j);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          if (kg + 1 < gfirst[i]) continue;
-          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[i], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[i], acc[i], 0, 0, 0);
+          if (kg + KD - 1 < gfirst[i]) continue;
+#pragma unroll
+          for (int j = 0; j < KD; ++j) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bq[j][i], acc[i], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) { b0[i] = n0[i]; b1[i] = n1[i]; }
+        for (int j = 0; j < KD; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) bq[j][i] = nq[j][i];
       }
     }
     IPM_TICK(1);
@@ -1282,7 +1291,7 @@ void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st) {
 }
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
   if (p.nd) return p.max_factor_lds;
-  return (size_t(p.b + 8) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
+  return (size_t(p.b + 24) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
           size_t(p.nb) * p.nb) * sizeof(double);
 }
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
