@@ -149,6 +149,25 @@ size_t factor_lds_of(int b, int nb) {   // = kkt_factor_lds_bytes (rpm_ipm_kerne
 }
 long long sub_at(const KktSubHost& g, int i, int j) { return g.koff + (long long)j * g.CS + (i < g.Nb ? i - j : g.b + 1 + i - g.Nb); }
 
+// destinations with long source lists first (order among them and among the rest unchanged); returns how many
+int long_lists_first(std::vector<int>& ptr, std::vector<int>& src, std::vector<int>& dst, int threshold = 32) {
+  const int n = int(dst.size());
+  std::vector<int> order;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int i = 0; i < n; ++i)
+      if ((ptr[i + 1] - ptr[i] >= threshold) == (pass == 0)) order.push_back(i);
+  std::vector<int> nptr(1, 0), nsrc, ndst;
+  int n_long = 0;
+  for (int i : order) {
+    if (ptr[i + 1] - ptr[i] >= threshold) ++n_long;
+    nsrc.insert(nsrc.end(), src.begin() + ptr[i], src.begin() + ptr[i + 1]);
+    nptr.push_back(int(nsrc.size()));
+    ndst.push_back(dst[i]);
+  }
+  ptr.swap(nptr); src.swap(nsrc); dst.swap(ndst);
+  return n_long;
+}
+
 // Where a position of the separator system (level-2 position a: separators in time order, then the global border) lives once
 // that system is cut into groups (IpmPlan::n_l2 > 0), and the storage slot of a pair of such positions.
 struct L3Map {
@@ -504,6 +523,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
     }
     p.cg_ptr.push_back(int(p.cg_src.size()));
     if (all.empty()) p.cg_ptr.assign(1, 0);
+    p.n_cg_long = long_lists_first(p.cg_ptr, p.cg_src, p.cg_dst);
     std::stable_sort(rall.begin(), rall.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
     p.rg_ptr.push_back(0);
     for (size_t i = 0; i < rall.size(); ++i) {
@@ -547,6 +567,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
       p.cg2_src.push_back(all[i].second);
     }
     p.cg2_ptr.push_back(int(p.cg2_src.size()));
+    p.n_cg2_long = long_lists_first(p.cg2_ptr, p.cg2_src, p.cg2_dst);
     std::stable_sort(rall.begin(), rall.end(), [](const auto& a, const auto& c) { return a.first < c.first; });
     p.rg2_ptr.push_back(0);
     for (size_t i = 0; i < rall.size(); ++i) {

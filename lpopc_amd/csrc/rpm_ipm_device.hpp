@@ -93,6 +93,7 @@ struct IpmDev {
   int n_cg, n_rg, n_rs, n_gap;
   const int *cg2_ptr, *cg2_src, *cg2_dst, *rg2_ptr, *rg2_src, *rg2_dst, *rs2_dst, *rs2_src;   // second stage (groups -> last level)
   int n_cg2, n_rg2, n_rs2;
+  int n_cg_long, n_cg2_long;             // leading corner-gather destinations with >= 32 sources (a wave each)
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
 };
 

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   double dinf = 0, cinf = 0, th1 = 0, cmax = 0, cmin = 1e300, sl = 0, sz = 0, ln = 0, bad = 0, nzb = 0;
   double csq = 0, dsq = 0, psum = 0, psq = 0, nfree = 0;      // 2-norms for the adaptive barrier update's KKT error
   // pass 1: constraint values and what does not depend on the multipliers
+  #pragma unroll 4
   for (int r = t; r < D.m; r += blockDim.x) {
     const int s = D.row_slack[r];
     const double cr = s < 0 ? g[r] - D.gl[r] : g[r] - v[D.n + s];
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     const double *pp = D.pp + size_t(bi) * D.m, *nn = D.nn + size_t(bi) * D.m, *zp = D.zp + size_t(bi) * D.m, *zn = D.zn + size_t(bi) * D.m;
     const double *vR = D.vR + size_t(bi) * D.nv, *dr2 = D.dr2 + size_t(bi) * D.nv;
     double thr = 0, rinf = 0, spn = 0, lnpn = 0, qd = 0;
+    #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) {
       const double rc = D.c[size_t(bi) * D.m + r] - pp[r] + nn[r];
       thr += fabs(rc); rinf = fmax(rinf, fabs(rc));
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
       const double p1 = zp[r] * pp[r], p2 = zn[r] * nn[r];
       cmax = fmax(cmax, fmax(p1, p2)); cmin = fmin(cmin, fmin(p1, p2));
     }
+    #pragma unroll 4
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double acc = glag[i];             // A^T lambda only (ipm_jt_lambda_kernel): the proximity term is added where zeta is known
       const double l = vl[i], u = vu[i];
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     if (verdict != 1) return;
     // leaving the restoration: bound multipliers clipped against the ORIGINAL mu, then one pass that only computes
     // least-squares multipliers (mode 3; paper section 3.6) before the regular iteration resumes at this point
+    #pragma unroll 4
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double l = vl[i], u = vu[i];
       if (l == u) continue;
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     return;
   }
   // pass 2: gradient of the Lagrangian, complementarity products
+  #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double acc = glag[i];               // grad f + A^T lambda (ipm_jt_lambda_kernel)
     const double l = vl[i], u = vu[i];
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     csq = block_red(csq, 0, sh); dsq = block_red(dsq, 0, sh); psum = block_red(psum, 0, sh); psq = block_red(psq, 0, sh);
     nfree = block_red(nfree, 0, sh);
   }
+  #pragma unroll 4
   for (int r = t; r < D.m; r += blockDim.x) sl += fabs(lam[r]);
   dinf = block_red(dinf, 1, sh);
   cmax = block_red(cmax, 1, sh); cmin = block_red(cmin, 2, sh); sl = block_red(sl, 0, sh); sz = block_red(sz, 0, sh);
@@ -859,6 +865,7 @@ __device__ inline void newton_step(const IpmDev& D, int bi, const double* sol, d
   const size_t o = size_t(bi) * D.nv;
   const int t = threadIdx.x;
   double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
+  #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
     double d = 0.0, dl = 0.0, du = 0.0;
@@ -886,6 +893,7 @@ __device__ inline void newton_step(const IpmDev& D, int bi, const double* sol, d
     dzL[o + i] = dl;
     dzU[o + i] = du;
   }
+  #pragma unroll 4
   for (int r = t; r < D.m; r += blockDim.x) dlam[size_t(bi) * D.m + r] = sol[D.pos[D.nv + r]];
   *amax_o = block_red(amax, 2, sh); *az_o = block_red(az, 2, sh); *dphi_o = block_red(dphi, 0, sh); *bad_o = block_red(bad, 1, sh);
 }
@@ -910,9 +918,11 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
   const double* sol = D.rhs + size_t(bi) * D.Nt;
   if (mode == 3) {              // least-squares multipliers on leaving the restoration; lambda = 0 when they are large (section 3.6)
     double mx = 0.0;
+    #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) mx = fmax(mx, fabs(sol[D.pos[D.nv + r]]));
     mx = block_red(mx, 1, sh);
     const bool keep = mx <= D.o.mult_reset;       // false for NaN as well
+    #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] = keep ? sol[D.pos[D.nv + r]] : 0.0;
     if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = 1; S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
     return;
@@ -920,6 +930,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
   if (mode == 2) {              // restoration: step in (v, lambda) from the reduced system, p and n recovered from it
     const double rho = D.o.resto_rho, zeta = S.zeta;
     double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
+    #pragma unroll 4
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
       double d = 0.0, dl = 0.0, du = 0.0;
@@ -943,6 +954,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
       }
       D.dv[o + i] = d; D.dzL[o + i] = dl; D.dzU[o + i] = du;
     }
+    #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) {
       const double pp = D.pp[om + r], nn = D.nn[om + r], zp = D.zp[om + r], zn = D.zn[om + r], lam = D.lam[om + r];
       const double sp = zp / pp, sn = zn / nn, dlam = sol[D.pos[D.nv + r]];
@@ -1037,6 +1049,7 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   const double* dvp = soc ? D.dv2 : D.dv;
   double th = 0.0, ln = 0.0, bad = 0.0, qd = 0.0, spn = 0.0, lnpn = 0.0;
   const bool resto = mode == 2;
+  #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
     if (l == u) continue;
@@ -1045,6 +1058,7 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
     if (u < IPM_INF) ln += log(u - vt);
     if (resto) { const double dd = vt - D.vR[o + i]; qd += D.dr2[o + i] * dd * dd; }
   }
+  #pragma unroll 4
   for (int r = t; r < D.m; r += blockDim.x) {
     const int s = D.row_slack[r];
     const double gr = D.gt[size_t(bi) * D.sg + r];
@@ -1157,6 +1171,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   }
   if (s_enter) {          // the line search gave up at an infeasible point: start the restoration phase from it
     const double rho = D.o.resto_rho, mu_r = fmax(s_mu, s_cinf);
+    #pragma unroll 4
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double vi = D.v[o + i], sc = fmax(1.0, fabs(vi));
       D.vR[o + i] = vi;
@@ -1164,6 +1179,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
       D.zL[o + i] = fmin(rho, D.zL[o + i]);
       D.zU[o + i] = fmin(rho, D.zU[o + i]);
     }
+    #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) {     // (33), (34): the p, n that minimise the restoration's barrier objective at v_R
       const double c = D.c[om + r], h2 = (mu_r - rho * c) / (2.0 * rho);
       const double nn = h2 + sqrt(h2 * h2 + mu_r * c / (2.0 * rho)), pp = c + nn;
@@ -1185,6 +1201,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   if (!s_accepted) return;
   if (s_mode == 2) {
     const double a = s_alpha, az = s_alpha_z, mu = s_mu_r;
+    #pragma unroll 4
     for (int i = t; i < D.nv; i += blockDim.x) {
       const double l = D.vl[o + i], u = D.vu[o + i];
       if (l == u) continue;
@@ -1193,6 +1210,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
       if (l > -IPM_INF) D.zL[o + i] = reset16(D.zL[o + i] + az * D.dzL[o + i], vi - l, mu, ks);
       if (u < IPM_INF) D.zU[o + i] = reset16(D.zU[o + i] + az * D.dzU[o + i], u - vi, mu, ks);
     }
+    #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) {
       const double pp = D.pp[om + r] + a * D.dpp[om + r], nn = D.nn[om + r] + a * D.dnn[om + r];
       D.pp[om + r] = pp; D.nn[om + r] = nn;
@@ -1218,6 +1236,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   }
   const double a = s_alpha, az = s_alpha_z, mu = s_mu;
   const double *dv = s_soc ? D.dv2 : D.dv, *dlam = s_soc ? D.dlam2 : D.dlam, *dzL = s_soc ? D.dzL2 : D.dzL, *dzU = s_soc ? D.dzU2 : D.dzU;
+  #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double l = D.vl[o + i], u = D.vu[o + i];
     if (l == u) continue;
@@ -1226,6 +1245,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
     if (l > -IPM_INF) D.zL[o + i] = reset16(D.zL[o + i] + az * dzL[o + i], vi - l, mu, ks);   // (16)
     if (u < IPM_INF) D.zU[o + i] = reset16(D.zU[o + i] + az * dzU[o + i], u - vi, mu, ks);
   }
+  #pragma unroll 4
   for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] += a * dlam[om + r];
   if (t == 0) {
     if (!S.armijo && S.nfilt < IPM_FMAX) {       // (22)
@@ -1305,12 +1325,22 @@ hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
 }
 // ---- nested dissection glue: sums in a fixed (interval) order, so the factorisation stays deterministic ----------------------
 // K[dst[i]] += sum_j K[src[j]], j in [ptr[i], ptr[i+1]): the level-1 Schur complements into the separator system
+// Destinations are sorted by the length of their source lists (build_ipm_plan_nd): the first n_long of them (>= 32 sources: the
+// global border's corner entries collect one contribution from EVERY interval, 256 on the metric problem) take a wave each —
+// lanes stride the list, partial sums combined in a fixed butterfly order — the rest a thread each.
 __global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int* __restrict__ ptr, const int* __restrict__ src,
-                                      const int* __restrict__ dst, int n, const IpmInst* inst, int need_refactor) {
+                                      const int* __restrict__ dst, int n, const IpmInst* inst, int need_refactor, int n_long) {
   const int bi = blockIdx.y;
   if (inst[bi].status != 0 || (need_refactor && !inst[bi].refactor)) return;
   double* K = Kall + size_t(bi) * kstride;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n_long; i += n_waves) {
+    double acc = 0.0;
+    for (int j = ptr[i] + lane; j < ptr[i + 1]; j += 64) acc += K[src[j]];
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) K[dst[i]] += acc;
+  }
+  for (int i = n_long + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     double acc = K[dst[i]];
     for (int j = ptr[i]; j < ptr[i + 1]; ++j) acc += K[src[j]];
     K[dst[i]] = acc;
@@ -1353,16 +1383,16 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
     launch_factor_subs(D, 0, 1, 0, tiles_per_wave, lds_bytes, st);
     return;
   }
-  auto corners = [&](const int* ptr, const int* src, const int* dst, int n) {
+  auto corners = [&](const int* ptr, const int* src, const int* dst, int n, int n_long) {
     if (!n) return;
     const unsigned blocks = unsigned(std::max(1, std::min(1024, (n + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1);
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1, n_long);
   };
   launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);                 // every interval up to its corner
-  corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg);
+  corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg, D.n_cg_long);
   if (D.n_l2) {
     launch_factor_subs(D, D.n_l1, D.n_l2, 1, tiles_per_wave, lds_bytes, st);          // every group of separators up to its corner
-    corners(D.cg2_ptr, D.cg2_src, D.cg2_dst, D.n_cg2);
+    corners(D.cg2_ptr, D.cg2_src, D.cg2_dst, D.n_cg2, D.n_cg2_long);
   }
   launch_factor_subs(D, D.n_l1 + D.n_l2, 1, 0, tiles_per_wave, lds_bytes, st);        // last level: (group) separators + border
 }
@@ -1380,7 +1410,7 @@ void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
   auto gather = [&](const int* ptr, const int* src, const int* dst, int n) {
     if (!n) return;
     const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0);
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0, 0);
   };
   vec(D.gap_pos, nullptr, D.n_gap, 0);                                                 // border work spaces start at zero
   launch_solve_subs(D, 0, D.n_l1, 1, check_status, st);                                // forward, every interval

@@ -181,6 +181,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     A_(ipm_alloc_c(h, &D.rg2_ptr, p.rg2_ptr)); A_(ipm_alloc_c(h, &D.rg2_src, p.rg2_src)); A_(ipm_alloc_c(h, &D.rg2_dst, p.rg2_dst));
     A_(ipm_alloc_c(h, &D.rs2_dst, p.rs2_dst)); A_(ipm_alloc_c(h, &D.rs2_src, p.rs2_src));
     D.n_cg2 = int(p.cg2_dst.size()); D.n_rg2 = int(p.rg2_dst.size()); D.n_rs2 = int(p.rs2_dst.size());
+    D.n_cg_long = p.n_cg_long; D.n_cg2_long = p.n_cg2_long;
   }
 #undef A_
   if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt), 4 * sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc"; return fail(RPM_E_DEVICE); }

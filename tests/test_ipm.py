@@ -373,9 +373,9 @@ def test_application_loop_with_the_device_solver(built, tmp_path):
 def test_climb_at_the_reference_tolerance_and_delta3_verdict(built):
     """Minimum-time climb (table look-ups, finite-difference derivatives): the noise floor of the dual infeasibility is
     ~1e-7, so it converges at the reference's default Ipopt-tol = 1e-6 (Core/LpNLPWrapper.hpp:73), on the device and in
-    the restatement, to the same optimum.  Delta-III from its default guess needs Ipopt's restoration phase (the
-    restatement stops the same way; which iteration gives up depends on rounding in the second-difference Hessian): the
-    device solver must come back with a verdict — never hang, never report garbage as converged."""
+    the restatement, to the same optimum.  Delta-III on a small mesh with an iteration limit it may or may not reach
+    (the path from lpopc's default guess is chaotic): the device solver must come back with a verdict — the published
+    optimum when it says converged, a finite point and an honest status otherwise; never a hang, never garbage as converged."""
     from lpopc_amd.engine import BatchedIPM, NLPEngine
     prob = problems.min_time_climb(2, 6)
     eng = NLPEngine(prob, _exact(), device=0)
@@ -390,9 +390,10 @@ def test_climb_at_the_reference_tolerance_and_delta3_verdict(built):
     eng = NLPEngine(problems.launch(2, 5), _exact(), device=0)
     ipm = BatchedIPM(eng, max_iter=150)
     r = ipm.solve(eng.get_starting_point()[None, :])
-    assert r["status"][0] in (0, 2, 3)
-    if r["status"][0] == 0:
-        assert r["kkt_error"][0] <= 1e-8
+    assert r["status"][0] in (0, 1, 2, 3)
+    if r["status"][0] in (0, 1):
+        assert r["kkt_error"][0] <= (1e-8 if r["status"][0] == 0 else 1e-6)
+        assert abs(-r["obj"][0] * 301454.0 - 7529.71) < 0.05
     else:
         assert r["kkt_error"][0] > 1e-8 and np.isfinite(r["x"]).all()
     ipm.close()
