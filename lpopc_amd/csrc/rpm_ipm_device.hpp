@@ -8,7 +8,7 @@
 namespace rpm {
 
 constexpr int IPM_W = 16;        // block width of the factorisation
-constexpr int IPM_FMAX = 256;    // filter entries kept per instance
+constexpr int IPM_FMAX = 1024;   // filter entries kept per instance (the filter empties whenever mu changes; a long Delta-III phase at one mu adds hundreds)
 constexpr int IPM_TRACE = 8;     // doubles per trace record: f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks
 constexpr double IPM_INF = 1e19; // Ipopt's nlp_lower_bound_inf / nlp_upper_bound_inf
 

@@ -1075,17 +1075,24 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   }
   th = block_red(th, 0, sh); ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh);
   if (resto) { qd = block_red(qd, 0, sh); spn = block_red(spn, 0, sh); lnpn = block_red(lnpn, 0, sh); }
-  if (t != 0) return;
   const IpmOpts& op = D.o;
+  // is the trial point dominated by a filter entry?  (every thread holds the reduced sums; the entries — hundreds on a long
+  // Delta-III solve — are dealt to the threads instead of being walked by thread 0)
+  const double phit_all = resto ? op.resto_rho * spn + 0.5 * S.zeta * qd - S.mu_r * (ln + lnpn) : D.objt[bi] - S.mu * ln;
+  double dom = 0.0;
+  {
+    const double* F = (resto ? D.rfilt : D.filt) + size_t(bi) * 2 * IPM_FMAX;
+    const int nf = resto ? S.nrfilt : S.nfilt;
+    for (int k = t; k < nf; k += blockDim.x)
+      if (th >= F[2 * k] && phit_all >= F[2 * k + 1]) dom = 1.0;
+  }
+  const bool dominated = block_red(dom, 1, sh) != 0.0;
+  if (t != 0) return;
   if (resto) {                  // the restoration problem's own filter line search
-    const double phit = op.resto_rho * spn + 0.5 * S.zeta * qd - S.mu_r * (ln + lnpn);
+    const double phit = phit_all;
     const double slack = 10.0 * 2.220446049250313e-16 * fabs(S.phi_r);
     bool ok = false;
     if (bad == 0 && fabs(phit) < 1e300 && th <= S.thr_max) {
-      bool dominated = false;
-      const double* F = D.rfilt + size_t(bi) * 2 * IPM_FMAX;
-      for (int k = 0; k < S.nrfilt; ++k)
-        if (th >= F[2 * k] && phit >= F[2 * k + 1]) dominated = true;
       if (!dominated) {
         const bool sw = S.dphi < 0 && a * pow(-S.dphi, op.s_phi) > op.delta * pow(S.th_r, op.s_theta);
         if (S.th_r <= S.thr_min && sw) {
@@ -1105,15 +1112,11 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   }
   const double ft = D.objt[bi];
   if (!(fabs(ft) < 1e300) || !(fabs(ln) < 1e300)) bad = 1;
-  const double phit = ft - S.mu * ln;
+  const double phit = phit_all;
   const double slack = 10.0 * 2.220446049250313e-16 * fabs(S.phi);     // Ipopt's rounding allowance in the phi comparisons
   const double a_test = S.alpha;       // the switching / Armijo tests of a corrected step use the uncorrected step length (A-5.7)
   bool ok = false;
   if (bad == 0 && th <= S.theta_max) {
-    bool dominated = false;
-    const double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
-    for (int k = 0; k < S.nfilt; ++k)
-      if (th >= F[2 * k] && phit >= F[2 * k + 1]) dominated = true;
     if (!dominated) {
       const bool sw = S.dphi < 0 && a_test * pow(-S.dphi, op.s_phi) > op.delta * pow(S.theta, op.s_theta);   // (19)
       if (S.theta <= S.theta_min && sw) {
