@@ -109,7 +109,7 @@ class Ctx:
         return [float(v) for v in t.cpu()]
 
 
-def timed_regions(ctx, step, K, warmup, use_graph=True, min_s=None, max_regions=400):
+def timed_regions(ctx, step, K, warmup, use_graph=True, min_s=None, max_regions=4000):
     """W warm-up steps, then regions of EXACTLY K steps each (one hipGraph replay when the steps can be captured), each
     bracketed by barrier + synchronize, repeated until min_s seconds have been timed.  Returns wall seconds and device
     milliseconds per region (MAX over ranks), and how the steps were launched."""
@@ -156,10 +156,13 @@ def timed_regions(ctx, step, K, warmup, use_graph=True, min_s=None, max_regions=
         return el, ev0.elapsed_time(ev1)
 
     first = region()
-    n = int(min(max_regions, max(5, math.ceil(min_s / max(first[0], 1e-6)))))
+    second = region()
+    # the first region runs slower than the steady state (it set the count too low for min_s in round 1's first cut): the count
+    # comes from the faster of the first two, with a margin
+    n = int(min(max_regions, max(5, math.ceil(1.15 * min_s / max(min(first[0], second[0]), 1e-6)))))
     n = int(ctx.max_over_ranks([float(n)])[0])   # the same count on every rank
-    wall, dev = [first[0]], [first[1]]
-    for _ in range(n - 1):
+    wall, dev = [first[0], second[0]], [first[1], second[1]]
+    for _ in range(n - 2):
         a, b = region()
         wall.append(a)
         dev.append(b)
