@@ -70,17 +70,32 @@ class DeviceIPMSolver:
     reference passes it.  Needs hessian-approximation=exact (eval_h).  Its multipliers are the NLP's (lambda of the
     primal-dual system), so costates and the Hamiltonian extracted from them are meaningful."""
 
-    def __init__(self, tol=1e-6, maxiter=3000):
+    def __init__(self, tol=1e-6, maxiter=3000, retry_bound_relax=(1e-7, 1e-6), **solver_options):
         self.tol, self.maxiter = float(tol), int(maxiter)
+        # Degenerate bounds (Delta-III: masses pinned to their bounds by the dynamics) make the multipliers non-unique; now and
+        # then a path ends with a slack collapsed against its 1e-8-relaxed bound and the line search stalls (status 3; DESIGN.md
+        # f-2).  The same solve with the bounds moved out a little further takes another path: an explicit, recorded retry here,
+        # not something the C ABI does behind the caller's back.
+        self.retry_bound_relax = tuple(retry_bound_relax)
+        self.solver_options = solver_options
 
     def SolveNlp(self, nlp):
         from .engine import BatchedIPM
-        ipm = BatchedIPM(nlp, tol=self.tol, max_iter=self.maxiter)
-        try:
-            r = ipm.solve(nlp.get_starting_point())
-            self.last = dict(r, stats=ipm.stats(), info=ipm.info())
-        finally:
-            ipm.close()
+        x0 = nlp.get_starting_point()
+        self.attempts = []
+        for relax in (None,) + self.retry_bound_relax:
+            opts = dict(self.solver_options)
+            if relax is not None:
+                opts["bound_relax_factor"] = relax
+            ipm = BatchedIPM(nlp, tol=self.tol, max_iter=self.maxiter, **opts)
+            try:
+                r = ipm.solve(x0)
+                self.last = dict(r, stats=ipm.stats(), info=ipm.info())
+            finally:
+                ipm.close()
+            self.attempts.append((relax, int(r["status"][0]), int(r["iterations"][0])))
+            if int(r["status"][0]) in (0, 1):
+                break
         nlp.finalize_solution(int(r["status"][0]), r["x"][0], r["lambda"][0], float(r["obj"][0]))
         return int(r["status"][0]) in (0, 1)      # Solve_Succeeded / Solved_To_Acceptable_Level
 

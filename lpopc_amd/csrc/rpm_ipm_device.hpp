@@ -28,6 +28,7 @@ struct IpmOpts {
   double kappa_soc = 0.99;
   int mu_adaptive = 0;               // 1: Ipopt's mu_strategy=adaptive with the LOQO oracle and the kkt-error globalisation (oracle/ipm_oracle.py)
   double mu_max_fact = 1e3, mu_red_fact = 0.9999, mu_init_factor = 0.8;
+  double sigma_cap = 0.0;            // experiment: cap z/s in the KKT matrix (0 = off)
 };
 
 struct IpmInst {
@@ -43,6 +44,7 @@ struct IpmInst {
   double alpha_soc, az_soc, th_old_soc;
   double mu_max, refs[4];            // adaptive barrier update: upper bound of mu, KKT errors of the last accepted iterates
   int fixed_mode, nrefs;             // 0 = free mode (mu from the oracle every iteration), 1 = monotone rule until progress resumes
+  int n_recalc, pad3;                // least-squares multipliers recomputed after a line search that failed at a feasible point (at most 3 times)
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 

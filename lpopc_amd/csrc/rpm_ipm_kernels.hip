@@ -147,6 +147,10 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
   const int mode_in = S.mode;
+  if (mode_in == 3) {           // recalc_y: a pass that only recomputes the multipliers at this point (set by ipm_update_kernel)
+    if (t == 0) { S.refactor = 1; S.delta_w = 0.0; atomicAdd(&D.cnt[0], 1); }
+    return;
+  }
   const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
   const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv, *lam = D.lam + size_t(bi) * D.m;
   const double *g = D.g + size_t(bi) * D.sg, *glag = D.glag + size_t(bi) * D.nv;
@@ -382,8 +386,9 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
           diag += w2;
           r += w2 * (v[i] - D.vR[size_t(bi) * D.nv + i]);
         }
-        if (l > -IPM_INF) { const double d = v[i] - l; diag += zL[i] / d; r -= mu / d; }
-        if (u < IPM_INF) { const double d = u - v[i]; diag += zU[i] / d; r += mu / d; }
+        const double cap = D.o.sigma_cap > 0 ? D.o.sigma_cap : 1e300;
+        if (l > -IPM_INF) { const double d = v[i] - l; diag += fmin(zL[i] / d, cap); r -= mu / d; }
+        if (u < IPM_INF) { const double d = u - v[i]; diag += fmin(zU[i] / d, cap); r += mu / d; }
       }
     }
     unsafeAtomicAdd(&K[D.diag_dst[i]], diag);
@@ -924,7 +929,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
     const bool keep = mx <= D.o.mult_reset;       // false for NaN as well
     #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] = keep ? sol[D.pos[D.nv + r]] : 0.0;
-    if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = 1; S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
+    if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = S.skip_update == -1 ? 2 : 1; S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
     return;
   }
   if (mode == 2) {              // restoration: step in (v, lambda) from the reduced system, p and n recovered from it
@@ -1150,6 +1155,7 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   if (S.alpha < S.alpha_min || S.ls > op.max_ls) {
     if (S.err0 <= op.acceptable_tol) S.status = 6;             // nothing left to gain: Ipopt reports the acceptable level here too
     else if (op.resto && S.theta > op.tol) S.enter_resto = 1;  // Ipopt switches to its restoration phase here
+    else if (op.resto && S.n_recalc < 3) S.enter_resto = 2;    // feasible but the multipliers are off: recompute them (recalc_y)
     else S.status = 3;
     return;
   }
@@ -1168,8 +1174,12 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   if (s_status != 0) return;
   const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
   const double ks = D.o.kappa_sigma;
-  if (s_skip) {           // this pass only replaced lambda (least-squares multipliers after the restoration)
-    if (t == 0) { S.skip_update = 0; S.n_resto += 1; }
+  if (s_skip) {           // this pass only replaced lambda (least-squares multipliers after the restoration, or recalc_y)
+    if (t == 0) { if (s_skip == 1) S.n_resto += 1; else S.n_recalc += 1; S.skip_update = 0; }
+    return;
+  }
+  if (s_enter == 2) {     // recalc_y: the next pass computes least-squares multipliers at this point, nothing else
+    if (t == 0) { S.mode = 3; S.enter_resto = 0; S.skip_update = -1; }
     return;
   }
   if (s_enter) {          // the line search gave up at an infeasible point: start the restoration phase from it

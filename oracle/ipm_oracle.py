@@ -18,7 +18,8 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     filter) with p, n eliminated from the Newton system — [[zeta D_R^2 + Sigma_v, A^T], [A, -(Sigma_p^-1 + Sigma_n^-1)]],
     the same matrix structure as (13) — starting values (33)/(34), return when the infeasibility is kappa_resto = 0.9
     of where it entered and the original filter accepts the point; then least-squares multipliers (section 3.6,
-    lambda = 0 when they exceed 1e3).  One simplification: the restoration problem's Hessian leaves out the constraint
+    lambda = 0 when they exceed 1e3); the same least-squares multipliers (Ipopt's recalc_y) up to 3 times when the line
+    search gives up at a FEASIBLE point.  One simplification: the restoration problem's Hessian leaves out the constraint
     curvature sum lambda_j Hess c_j (a Gauss-Newton model of it: no inertia correction is ever needed there).
   * mu_strategy = "adaptive" (what the reference asks Ipopt for, Core/LpNLPSolver.cpp:28) as an OPTION, default "monotone":
     Ipopt's adaptive update (Nocedal, Waechter, Waltz, SIAM J. Optim. 19, 2009) with the LOQO oracle (Ipopt's mu_oracle=loqo:
@@ -50,7 +51,7 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense", bound_relax_factor=1e-8, max_soc=4, kappa_soc=0.99,
                 resto_rho=1000.0, mult_reset=1e3,
                 mu_strategy="monotone", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
-                adaptive_mu_monotone_init_factor=0.8)
+                adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3)
 
 
 def _n_positive(K):
@@ -155,8 +156,16 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         k = dw_ < 0
         return float(np.min(-tau_ * w_[k] / dw_[k])) if k.any() else 1.0
 
-    n_resto = n_acc = 0
+    n_resto = n_acc = n_recalc = 0
     free_mode, refs, mu_max = True, [], None          # mu_strategy = adaptive
+
+    def ls_multipliers(xr, jR):
+        """least-squares multipliers (section 3.6): [[I, A^T], [A, -delta_c]] [w; lambda] = -[grad f - zL + zU; 0]; 0 when they exceed mult_reset"""
+        gf = np.zeros(nv)
+        gf[:n] = orc.eval_grad_f(xr)
+        K = kkt(np.ones(nv), None, jac_dense(jR), o["delta_c"] * np.ones(m))
+        sol = np.linalg.solve(K, -np.concatenate([np.where(free, gf - zL + zU, 0.0), np.zeros(m)]))
+        return sol[nv:] if np.max(np.abs(sol[nv:])) <= o["mult_reset"] else np.zeros(m)
 
     def _restore():
         """Ipopt's restoration phase (paper section 3.3) with p, n eliminated from the Newton system; see the module header.
@@ -188,12 +197,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
                 dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
                 zL = reset16(np.minimum(zL, 1e3), dl, mu, lo)
                 zU = reset16(np.minimum(zU, 1e3), du, mu, up)
-                # least-squares multipliers (section 3.6): [[I, A^T], [A, -delta_c]] [w; lambda] = -[grad f - zL + zU; 0]
-                gf = np.zeros(nv)
-                gf[:n] = orc.eval_grad_f(xr)
-                K = kkt(np.ones(nv), None, jac_dense(jR), o["delta_c"] * np.ones(m))
-                sol = np.linalg.solve(K, -np.concatenate([np.where(free, gf - zL + zU, 0.0), np.zeros(m)]))
-                lam = sol[nv:] if np.max(np.abs(sol[nv:])) <= o["mult_reset"] else np.zeros(m)
+                lam = ls_multipliers(xr, jR)
                 n_resto += 1
                 return None
             if itr == o["resto_max"]:
@@ -457,6 +461,14 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             status = _restore()
             if status is None:
                 continue
+        elif not accepted and status == 3 and o["resto"] and n_recalc < o["max_recalc_y"]:
+            # the line search gave up at a FEASIBLE point (theta <= tol: nothing for the restoration phase to do) whose
+            # multipliers are off — seen at the end of Delta-III solves, the primal variables converged, the dual infeasibility
+            # O(10).  Ipopt's recalc_y: least-squares multipliers at this point, then on with the regular iteration.
+            lam = ls_multipliers(x, jv)
+            n_recalc += 1
+            status = None
+            continue
         if not accepted:
             break
         v = np.where(free, v + a * dv, v)
@@ -468,4 +480,5 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         trace.append(dict(it=it, f=f, theta=theta, mu=mu, alpha=a, alpha_z=az, delta_w=dw, err0=err0, ls=ls, soc=n_soc, dinf=dinf, cinf=cinf, comp=cmax,
                           smin=float(min(dl[lo].min(initial=1e300), du[up].min(initial=1e300)))))
         it += 1
-    return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto)
+    return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto,
+                multiplier_recalculations=n_recalc)

@@ -687,6 +687,26 @@ def test_device_solves_delta_iii_with_the_adaptive_update(built):
 
 
 @pytest.mark.gpu
+def test_delta_iii_mesh_ladder_with_the_recorded_retry(built):
+    """Delta-III from lpopc's default guess on a ladder of meshes through DeviceIPMSolver (NLPSolver::SolveNlp on the device):
+    every mesh ends at the published optimum.  The path is chaotic and the problem degenerate: with the
+    round's final build the 4 x 8 x 8 mesh stalls at Ipopt's bound_relax_factor 1e-8 (status 3) and is solved by the
+    solver's recorded retry with 1e-7; the others need no retry."""
+    from lpopc_amd.application import DeviceIPMSolver
+    from lpopc_amd.engine import NLPEngine
+    retried = 0
+    for K, Nk in ((2, 6), (4, 8), (8, 8), (16, 8)):
+        eng = NLPEngine(problems.launch(K, Nk), _exact(), device=0)
+        solver = DeviceIPMSolver(tol=1e-8, maxiter=3000)
+        assert solver.SolveNlp(eng), (K, Nk, solver.attempts)
+        _, _, obj = eng.get_solution()
+        assert int(solver.last["status"][0]) in (0, 1) and abs(-obj * 301454.0 - 7529.71) < 0.01, (K, Nk, obj, solver.attempts)
+        retried += len(solver.attempts) - 1
+        eng.close()
+    assert retried <= 2
+
+
+@pytest.mark.gpu
 def test_device_solves_the_metric_problem(built):
     """BASELINE's metric problem at full size — Delta-III, 4 phases x 64 intervals x 16 LGR points, n = 40 996, KKT order
     73 801 — from lpopc's default guess (example/launch/Launch.cpp:200-457), on the device: nested dissection over the 256 mesh
