@@ -700,15 +700,21 @@ constexpr int pl_role_groups(int R) { return (R + (R + 11) / 12 - 1) / ((R + 11)
 // 16-iterate launch) against 2 x (6 + 2) at 128 VGPRs (35.0), one role per wave 12 + 4 (36.3) and 3 x (4 + 1) (38.6).
 // Larger problems: one half, the fewest equal passes (R = 18: 9 + 2 waves, 3 per SIMD).
 struct PlShape { int NH, RG, NDMA; };
+#ifndef RPM_PL_BIG_RG
+#define RPM_PL_BIG_RG 0   // experiment: compute waves of the one-half shape (0 = the fewest equal passes)
+#endif
+#ifndef RPM_PL_BIG_MINWAVES
+#define RPM_PL_BIG_MINWAVES 0   // experiment: waves per SIMD the one-half shape is compiled for (0 = whatever fits)
+#endif
 constexpr PlShape pl_shape(int R) {
-  return R <= 12 ? PlShape{2, 4, 2} : PlShape{1, pl_role_groups(R), 2};
+  return R <= 12 ? PlShape{2, 4, 2} : PlShape{1, RPM_PL_BIG_RG ? RPM_PL_BIG_RG : pl_role_groups(R), 2};
 }
 
 // (Tried for the one-half shape, R > 12 roles: __launch_bounds__(..., 6) so that two 11-wave workgroups share a CU and one's
 // store phases overlap the other's dynamics.  The quadrotor kernel needs ~156 VGPRs; at 80 it spills 76 of them and the
 // 1024-instance sweep takes 89.9 us instead of 51 — DESIGN.md §4.)
 template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN, bool DXM = false>
-__global__ __launch_bounds__(NH * 64 * (RG + NDMA)) void rpm_tile_pl_kernel(
+__global__ __launch_bounds__(NH * 64 * (RG + NDMA), (NH == 1 && RPM_PL_BIG_MINWAVES) ? RPM_PL_BIG_MINWAVES : 1) void rpm_tile_pl_kernel(
     const KParams K, int n_inst, const double* __restrict__ xall, double* __restrict__ gall,
     double* __restrict__ vall) {
   constexpr int T = 64;   // a role of a tile is one wave
