@@ -231,7 +231,8 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  * only three counters cross PCIe.  The engine must be created with hessian_approximation = exact; set the engine's
  * "instance_align" before rpm_ipm_create.
  *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
- *                       "delta_c" (1e-8, constraint regularisation that makes the pivot-free LDL^T well defined),
+ *                       "delta_c" (1e-9, constraint regularisation that makes the pivot-free LDL^T well defined; keep it
+ *                       well below bound_relax_factor),
  *                       "max_line_search" (40), "trace" (0; keep the first N accepted steps of every instance),
  *                       "restoration" (1), "restoration_max_iter" (300), "restoration_penalty" (1000, Ipopt's rho),
  *                       "acceptable_tol" (1e-6), "acceptable_iter" (15), "bound_relax_factor" (1e-8, as Ipopt: finite bounds

@@ -16,7 +16,7 @@ struct IpmOpts {
   double tol = 1e-8, mu_init = 0.1, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99;
   double bound_push = 1e-2, bound_frac = 1e-2, kappa_sigma = 1e10, s_max = 100.0;
   double gamma_theta = 1e-5, gamma_phi = 1e-8, eta_phi = 1e-8, delta = 1.0, s_theta = 1.1, s_phi = 2.3, gamma_alpha = 0.05;
-  double delta_c = 1e-8, delta_w_first = 1e-4, delta_w_min = 1e-20, delta_w_max = 1e40, kw_inc_first = 100.0, kw_inc = 8.0,
+  double delta_c = 1e-9, delta_w_first = 1e-4, delta_w_min = 1e-20, delta_w_max = 1e40, kw_inc_first = 100.0, kw_inc = 8.0,
          kw_dec = 1.0 / 3.0;
   int max_iter = 3000, max_ls = 40;
   double acceptable_tol = 1e-6;      // Ipopt: "solved to acceptable level" after acceptable_iter consecutive such iterations

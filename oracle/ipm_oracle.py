@@ -31,7 +31,7 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     Not the default here because the monotone rule needs half the iterations on Delta-III.
 Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle, NLP scaling,
 least-squares multipliers at the very first iterate (lambda_0 = 0), watchdog.  One deviation:
-the constraint regularisation delta_c = 1e-8 is always on
+the constraint regularisation delta_c = 1e-9 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
 Parity status: UNPINNED by the reference (it holds no solver traces); pinned here by known optima and by scipy.
 
@@ -46,7 +46,7 @@ INF = 1e19
 
 DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, bound_push=1e-2,
                 bound_frac=1e-2, kappa_sigma=1e10, s_max=100.0, gamma_theta=1e-5, gamma_phi=1e-8, eta_phi=1e-8, delta=1.0,
-                s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-8, delta_w_first=1e-4, delta_w_min=1e-20,
+                s_theta=1.1, s_phi=2.3, gamma_alpha=0.05, delta_c=1e-9, delta_w_first=1e-4, delta_w_min=1e-20,
                 delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=300, kappa_resto=0.9,
                 acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense", bound_relax_factor=1e-8, max_soc=4, kappa_soc=0.99,
                 resto_rho=1000.0, mult_reset=1e3,

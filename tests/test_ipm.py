@@ -690,8 +690,8 @@ def test_device_solves_delta_iii_with_the_adaptive_update(built):
 def test_delta_iii_mesh_ladder_with_the_recorded_retry(built):
     """Delta-III from lpopc's default guess on a ladder of meshes through DeviceIPMSolver (NLPSolver::SolveNlp on the device):
     every mesh ends at the published optimum.  The path is chaotic and the problem degenerate: with the
-    round's final build the 4 x 8 x 8 mesh stalls at Ipopt's bound_relax_factor 1e-8 (status 3) and is solved by the
-    solver's recorded retry with 1e-7; the others need no retry."""
+    earlier constraint regularisation delta_c = 1e-8 the 4 x 8 x 8 mesh stalled (status 3) and was solved by the solver's
+    recorded retry with bound_relax_factor 1e-7; with delta_c = 1e-9, the default since, no mesh of the ladder needs it."""
     from lpopc_amd.application import DeviceIPMSolver
     from lpopc_amd.engine import NLPEngine
     retried = 0
