@@ -23,6 +23,9 @@ eng = NLPEngine(problems.launch(K, Nk), o, device=0)
 eng.set_option("ipm_nested", nested)
 ipm = BatchedIPM(eng, max_iter=iters, trace=iters, **extra)
 x0 = eng.get_starting_point()[None, :]
+if os.environ.get("IPM_PERTURB_SEED"):     # the path is chaotic: a start perturbed by 1e-10 (relative) is another sample of it
+    import numpy as np
+    x0 = x0 * (1 + 1e-10 * np.random.RandomState(int(os.environ["IPM_PERTURB_SEED"])).uniform(-1, 1, x0.shape))
 ipm.solve(x0)           # warm-up: module load
 t0 = time.perf_counter()
 r = ipm.solve(x0)
