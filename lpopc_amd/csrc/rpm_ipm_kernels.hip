@@ -3,12 +3,15 @@
 // instance for the vector work and for the band + border LDL^T; the NLP callbacks are the engine's own batched launches.
 //
 // Per iteration (Waechter & Biegler 2006, the equation numbers below are that paper's):
-//   residuals, optimality error E_0 / E_mu (5), barrier update (7), tau (8)      ipm_residual_kernel
+//   grad f + A^T lambda; residuals, optimality error E_0 / E_mu (5), barrier update (7) or the          ipm_jt_lambda_kernel,
+//     adaptive rule, tau (8); in restoration mode the same for the restoration problem + the test to leave it   ipm_residual_kernel
 //   W = eval_h(x, 1, lambda); K = [[W + Sigma + dw I, A^T], [A, -dc I]] (13)     ipm_assemble_kernel
-//   LDL^T without pivoting + inertia check / correction (Algorithm IC)           kkt_factor_kernel, ipm_inertia_kernel
-//   direction, dz (12), fraction to the boundary (15), alpha_min (23)            kkt_solve_kernel, ipm_direction_kernel
-//   filter line search (18)-(20), (22)                                           ipm_trial_kernel, ipm_accept_kernel
-//   step, multiplier reset (16), filter update                                   ipm_update_kernel
+//     (restoration: [[zeta D_R^2 + Sigma, A^T], [A, -(Sigma_p^-1 + Sigma_n^-1)]]; least-squares multipliers: [[I, A^T], [A, -dc I]])
+//   LDL^T without pivoting (one band, or nested dissection over the mesh intervals and, on long meshes, over groups of their
+//     separators) + inertia check / correction (Algorithm IC)                    kkt_factor_kernel, kkt_gather_add_kernel, ipm_inertia_kernel
+//   direction, dz (12), fraction to the boundary (15), alpha_min (23)            kkt_solve_kernel, kkt_vec_kernel, ipm_direction_kernel
+//   filter line search (18)-(20), (22), second-order correction (A-5.5 .. 5.9)   ipm_trial_kernel, ipm_accept_kernel, ipm_soc_rhs_kernel, ipm_soc_direction_kernel
+//   step, multiplier reset (16), filter update, entry into the restoration phase ipm_update_kernel
 #include <algorithm>
 #include <cmath>
 #include <cstring>
