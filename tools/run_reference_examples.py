@@ -1,7 +1,7 @@
 """The reference's own example programs, with the options their main() sets, end to end on the device:
 example/bryson-denham/BrysonDenham.cpp:77-78 (hessian-approximation=exact, max-grid-num=20) and
 example/hypersensitive/HyperSensitive.cpp:53-57 (exact, first-derive=analytic, mesh-refine-methods=hp-Liu,
-max-grid-num=20, tf = 5000).  Every NLP is solved by the device interior-point solver (rpm_ipm_*), extraction, error
+max-grid-num=20, tf = 5000), and example/launch/Launch.cpp (no options; exact Hessian here).  Every NLP is solved by the device interior-point solver (rpm_ipm_*), extraction, error
 estimate and refinement run on the GPU too.  python tools/run_reference_examples.py"""
 import os
 import sys
@@ -46,3 +46,6 @@ if __name__ == "__main__":
     W = quad(lambda x: x ** 3 + np.sqrt(x ** 6 + x ** 2), 0, 1.0)[0]
     run("hypersensitive", problems.hypersensitive(), {"hessian-approximation": "exact", "first-derive": "analytic",
                                                       "mesh-refine-methods": "hp-Liu", "max-grid-num": 20}, V + W)
+    # example/launch/Launch.cpp sets no option at all (the reference then runs Ipopt's limited-memory Hessian; the device solver
+    # needs eval_h): its mesh, its guess, default refinement — the published optimum is 7529.712 kg = -0.0249779 in its mass unit
+    run("launch (Delta-III)", problems.launch(), {"hessian-approximation": "exact"}, -7529.712 / 301454.0)
