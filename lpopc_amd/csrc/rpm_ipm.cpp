@@ -29,6 +29,32 @@ void ipm_plan_group_hessian(IpmPlan& p) {
   if (!all.empty()) p.hg_ptr.push_back(int(p.hg_src.size()));
 }
 
+// Unknowns that must join the border because the Hessian couples them across collocation nodes.  A Lagrangian Hessian of this
+// transcription couples variables of ONE node with each other and with the border (t0, tf, final states, parameters); the one
+// exception is the reference's linkage Hessian, which indexes the right phase's initial states with the LEFT phase's node count
+// (LpHessian.cpp:1150, kept bug-for-bug): when linked phases have different node totals — every mesh hp-Liu refinement produces —
+// those entries land on states in the middle of the right phase.  Both endpoints of such an entry (at most nx per linkage) are
+// promoted; the band / the interval structure then holds for everything else.
+static std::vector<char> promoted_to_border(const Engine& e) {
+  std::vector<long long> node(e.n, -1);          // global node index of a variable, -1 = border already
+  long long base = 0;
+  for (int ip = 0; ip < e.P; ++ip) {
+    const PhaseDev& q = e.phd[ip];
+    for (int i = 0; i < q.nx; ++i)
+      for (int k = 0; k < q.N; ++k) node[q.x_state0 + i * (q.N + 1) + k] = base + k;
+    for (int j = 0; j < q.nu; ++j)
+      for (int k = 0; k < q.N; ++k) node[q.x_control0 + j * q.N + k] = base + k;
+    base += q.N;
+  }
+  std::vector<char> pr(e.n, 0);
+  for (int k = 0; k < e.nnz_h; ++k) {
+    const int a = e.hes_i[k], c = e.hes_j[k];
+    if (e.xl[a] == e.xu[a] || e.xl[c] == e.xu[c]) continue;
+    if (node[a] >= 0 && node[c] >= 0 && node[a] != node[c]) pr[a] = pr[c] = 1;
+  }
+  return pr;
+}
+
 int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why, int nested) {
   if (nested) return build_ipm_plan_nd(e, p, why);
   p = IpmPlan();
@@ -65,6 +91,11 @@ int build_ipm_plan(Engine& e, IpmPlan& p, std::string* why, int nested) {
       if (p.row_slack[row] >= 0) key[p.n + p.row_slack[row]] = node_base + r % q.N;
     }
     node_base += q.N;
+  }
+  {
+    const std::vector<char> pr = promoted_to_border(e);
+    for (int u = 0; u < p.n; ++u)
+      if (pr[u]) key[u] = -1;
   }
   // order: by node, inside a node variables, slacks, multipliers; the border keeps variables, slacks, multipliers
   std::vector<int> band, border;
@@ -286,6 +317,11 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
       place(p.nv + row, k);
       if (p.row_slack[row] >= 0) place(p.n + p.row_slack[row], k);
     }
+  }
+  {
+    const std::vector<char> pr = promoted_to_border(e);
+    for (int u = 0; u < p.n; ++u)
+      if (pr[u]) { ivl_of[u] = -1; sep_of[u] = -1; sep_state[u] = 0; key[u] = -1; }
   }
   const int KI = int(iv.size());
   auto type_of = [&](int u) { return u < p.n ? 0 : (u < p.nv ? 1 : 2); };

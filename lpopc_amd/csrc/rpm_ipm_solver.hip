@@ -112,7 +112,10 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   h->attached = true;
   std::string why;
   rc = build_ipm_plan(e, h->plan, &why, e.opt_ipm_nested != 0);
-  if (rc && e.opt_ipm_nested == -1) rc = build_ipm_plan(e, h->plan, &why, 0);   // automatic: no interval structure to dissect -> one band
+  // automatic: no interval structure to dissect, or sub-problems the factorisation kernel cannot hold (rows per block column, LDS:
+  // e.g. a border grown by promoted unknowns on top of the intervals' separators) -> one band
+  if (e.opt_ipm_nested == -1 && (rc || h->plan.max_rows > 4 * IPM_MT * 16 || kkt_factor_lds_bytes(h->plan) > 150 * 1024))
+    rc = build_ipm_plan(e, h->plan, &why, 0);
   if (rc) {
     e.err = "rpm_ipm_create: " + why;
     delete h;

@@ -150,7 +150,7 @@ def _random_kkt_dense(ipm, n, B, seed):
     return dense, sign, int(inside.sum())
 
 
-ND_LAYOUTS = LAYOUTS + [("launch_ragged", lambda: problems.launch(), 1), ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), 2),
+ND_LAYOUTS = LAYOUTS + [("launch_ragged", lambda: problems.launch(), 1), ("launch_unequal", lambda: problems.launch(), 1), ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), 2),
                         ("quadrotor_24x4", lambda: problems.quadrotor(24, 4), 2), ("launch_16x4", lambda: problems.launch(16, 4), 1)]
 
 
@@ -169,8 +169,16 @@ def test_kkt_factorisation_layouts_against_numpy(built, name, make, B, nested):
         meshes = [([-1, -0.6, 0.1, 1], [5, 8, 2]), ([-1, 0.5, 1], [7, 8]), ([-1, 1], [15]), ([-1, -0.9, -0.5, 0.0, 1], [3, 4, 3, 5])]
         for i, (mesh, nodes) in enumerate(meshes):
             problems.set_mesh(prob.GetPhase(i), mesh, nodes)
+    if name == "launch_unequal":
+        # unequal node totals (what hp-Liu refinement produces): the mis-indexed link-Hessian entries couple states of different
+        # nodes of the right phase; their endpoints are promoted to the border (promoted_to_border, rpm_ipm.cpp)
+        meshes = [([-1, -0.6, 0.1, 1], [5, 8, 4]), ([-1, 0.5, 1], [7, 6]), ([-1, 0.2, 1], [6, 5]), ([-1, -0.9, -0.5, 0.0, 1], [3, 4, 6, 5])]
+        for i, (mesh, nodes) in enumerate(meshes):
+            problems.set_mesh(prob.GetPhase(i), mesh, nodes)
     eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
-    eng.set_option("ipm_nested", min(nested, 1))
+    # (launch_unequal: the promoted unknowns bring the border to 107 rows; with the intervals' separators on top of that the
+    # corner no longer fits the LDS of the interval blocks, and the automatic mode — tested here — falls back to one band)
+    eng.set_option("ipm_nested", -1 if (name == "launch_unequal" and nested) else min(nested, 1))
     if nested == 2:                  # the separator system cut once more, into groups of 48 of its positions (at least 3 bandwidths)
         eng.set_option("ipm_nested_group", 48)
     ipm = BatchedIPM(eng)
@@ -684,6 +692,25 @@ def test_device_solves_delta_iii_with_the_adaptive_update(built):
     assert abs(-r["obj"][0] * 301454.0 - 7529.71) < 0.01
     ipm.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_reference_launch_example_with_hp_liu_refinement_on_the_device(built):
+    """example/launch/Launch.cpp (Delta-III on its own 4 x 1 x 20 mesh and guess) through the reference's outer loop with
+    mesh-refine-methods=hp-Liu: every grid's NLP solved by rpm_ipm_*, error estimate and refinement on the GPU; the refined
+    meshes have different node totals per phase, so the link-Hessian's mis-indexed entries are promoted to the border."""
+    from lpopc_amd.application import LpopcApplication, console_not_print
+    app = LpopcApplication(console_not_print)
+    prob = problems.launch()
+    app.SetOptimalControlProblem(prob)
+    app.Options().SetStringValue("hessian-approximation", "exact")
+    app.Options().SetStringValue("mesh-refine-methods", "hp-Liu")
+    app.Options().SetIntegerValue("max-grid-num", 8)
+    app.SolveOptimalProblem()                       # raises if a solve fails or the grid limit is hit
+    assert app.meshrefiner_.CurrentGrid() >= 1
+    assert abs(-app.objective * 301454.0 - 7529.71) < 0.06
+    totals = [int(np.sum(prob.GetPhase(i).GetNodesPerInterval())) for i in range(4)]
+    assert len(set(totals)) > 1, totals
 
 
 @pytest.mark.gpu

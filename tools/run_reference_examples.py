@@ -49,3 +49,7 @@ if __name__ == "__main__":
     # example/launch/Launch.cpp sets no option at all (the reference then runs Ipopt's limited-memory Hessian; the device solver
     # needs eval_h): its mesh, its guess, default refinement — the published optimum is 7529.712 kg = -0.0249779 in its mass unit
     run("launch (Delta-III)", problems.launch(), {"hessian-approximation": "exact"}, -7529.712 / 301454.0)
+    # (ph refinement hands the 20-node intervals back unchanged — the truncated degree increment, LpPhMeshRefineAlg.cpp:81 — until the
+    # grid limit stops the run, as the reference would.)  With hp-Liu refinement the loop ends by itself:
+    run("launch (Delta-III), hp-Liu", problems.launch(), {"hessian-approximation": "exact", "mesh-refine-methods": "hp-Liu", "max-grid-num": 8},
+        -7529.712 / 301454.0)
