@@ -293,8 +293,9 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   const double sc = nzb > 0 ? fmax(o.s_max, sz / nzb) / o.s_max : 1.0;
   S.err0 = fmax(fmax(dinf / sd, cinf), nzb > 0 ? cmax / sc : 0.0);
   if (bad != 0) { S.status = 5; return; }
-  if (S.err0 <= o.tol) { S.status = 1; return; }
-  S.n_acc = S.err0 <= o.acceptable_tol ? S.n_acc + 1 : 0;
+  const double cm = nzb > 0 ? cmax : 0.0;
+  if (S.err0 <= o.tol && dinf <= o.dual_inf_tol && cinf <= o.constr_viol_tol && cm <= o.compl_inf_tol) { S.status = 1; return; }
+  S.n_acc = (S.err0 <= o.acceptable_tol && dinf <= o.acc_dual_inf_tol && cinf <= o.acc_constr_viol_tol && cm <= o.acc_compl_inf_tol) ? S.n_acc + 1 : 0;
   if (o.acceptable_iter > 0 && S.n_acc >= o.acceptable_iter) { S.status = 6; return; }
   if (S.iter >= o.max_iter) { S.status = 2; return; }
   if (S.iter == 0) {

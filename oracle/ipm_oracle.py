@@ -5,7 +5,8 @@ What it restates: the algorithm of Ipopt 3.12.3, the solver the reference calls 
 Core/LpNLPSolver.cpp:13-53).  Ipopt is a third-party dependency that is absent from /root/reference, so this follows
 its published description — A. Waechter, L. T. Biegler, "On the implementation of an interior-point filter line-search
 algorithm for large-scale nonlinear programming", Math. Program. 106 (2006) — equation numbers below are the paper's:
-  optimality error (5)/(6), barrier update (7), tau (8), primal-dual system (13) with dz from (12), fraction to the
+  optimality error (5)/(6) with Ipopt's unscaled thresholds beside it (dual_inf_tol 1, constr_viol_tol 1e-4, compl_inf_tol 1e-4),
+  barrier update (7), tau (8), primal-dual system (13) with dz from (12), fraction to the
   boundary (15), multiplier reset (16), filter acceptance (18)-(20), filter update (22), alpha_min (23), inertia
   correction Algorithm IC, initial point section 3.6 (bound_push / bound_frac), constants = Ipopt 3.12 defaults.
 Restated in round 2 (what the metric problem, Delta-III, turned out to need — tests/experiments/ has the experiments):
@@ -51,7 +52,9 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense", bound_relax_factor=1e-8, max_soc=4, kappa_soc=0.99,
                 resto_rho=1000.0, mult_reset=1e3,
                 mu_strategy="monotone", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
-                adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3)
+                adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3,
+                dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,                      # Ipopt's unscaled termination thresholds
+                acceptable_dual_inf_tol=1e10, acceptable_constr_viol_tol=1e-2, acceptable_compl_inf_tol=1e-2)
 
 
 def _n_positive(K):
@@ -305,10 +308,12 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         ln = lnsum(v)
         if not np.isfinite([f, ln, dinf, cinf]).all():
             status = 5
-        elif err0 <= o["tol"]:
+        elif err0 <= o["tol"] and dinf <= o["dual_inf_tol"] and cinf <= o["constr_viol_tol"] and (cmax if nzb else 0.0) <= o["compl_inf_tol"]:
             status = 0
         else:
-            n_acc = n_acc + 1 if err0 <= o["acceptable_tol"] else 0            # Ipopt: acceptable_tol 1e-6, acceptable_iter 15
+            acc_ok = err0 <= o["acceptable_tol"] and dinf <= o["acceptable_dual_inf_tol"] and cinf <= o["acceptable_constr_viol_tol"] and \
+                (cmax if nzb else 0.0) <= o["acceptable_compl_inf_tol"]
+            n_acc = n_acc + 1 if acc_ok else 0            # Ipopt: acceptable_tol 1e-6, acceptable_iter 15
             if o["acceptable_iter"] > 0 and n_acc >= o["acceptable_iter"]:
                 status = 1
             elif it >= o["max_iter"]:
