@@ -176,7 +176,7 @@ struct NdClass {
 };
 size_t factor_lds_of(int b, int nb) {   // = kkt_factor_lds_bytes (rpm_ipm_kernels.hip)
   const size_t W = IPM_PLAN_W;
-  return (size_t(b + 24) * W + W * (W + 1) + W * W + W + 2 * size_t(nb) * W + size_t(nb) * nb) * sizeof(double);
+  return (size_t(b + 24) * W + W * (W + 1) + W * W + W + 2 * size_t(nb) * W + size_t(nb) * (nb + 1) / 2) * sizeof(double);
 }
 long long sub_at(const KktSubHost& g, int i, int j) { return g.koff + (long long)j * g.CS + (i < g.Nb ? i - j : g.b + 1 + i - g.Nb); }
 

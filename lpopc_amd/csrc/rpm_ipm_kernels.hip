@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
   double* invd = Mi + W * W;                    // W
   double* BL = invd + W;                        // nb x W: L of the border rows in the current block column
   double* BY = BL + size_t(G.nb) * W;           // nb x W: L D
-  double* C = BY + size_t(G.nb) * W;            // nb x nb: the corner (lower triangle used)
+  double* C = BY + size_t(G.nb) * W;            // nb (nb + 1) / 2: the corner's lower triangle, packed by rows
   __shared__ int cnt[3];
   if (t < 3) cnt[t] = 0;
   int npos = 0, nneg = 0, nbad = 0;
@@ -484,9 +484,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 #else
 #define IPM_TICK(i)
 #endif
+  auto ct = [](int r, int c) { return r * (r + 1) / 2 + c; };   // the corner's lower triangle, packed by rows (c <= r)
   for (int idx = t; idx < nb * nb; idx += nt) {
     const int r = idx / nb, c = idx % nb;
-    C[idx] = r >= c ? K[G.at(G.Nb + r, G.Nb + c)] : 0.0;
+    if (r >= c) C[ct(r, c)] = K[G.at(G.Nb + r, G.Nb + c)];
   }
   for (int J0 = 0; J0 < G.Nb;) {
     const int J1 = min(J0 + W, G.Nb), w = J1 - J0;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int rr = ti * 16 + lq + 4 * g;
-          cacc[g] = (rr < nb && cb < nb) ? C[rr * nb + cb] : 0.0;
+          cacc[g] = (rr < nb && cb <= rr) ? C[ct(rr, cb)] : 0.0;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int rr = ti * 16 + lq + 4 * g;
-          if (rr < nb && cb <= rr) C[rr * nb + cb] = cacc[g];
+          if (rr < nb && cb <= rr) C[ct(rr, cb)] = cacc[g];
         }
       }
     }
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
   if (partial) {                                            // level 1 of the nested dissection: hand the corner over as it is
     for (int idx = t; idx < nb * nb; idx += nt) {
       const int r = idx / nb, c = idx % nb;
-      if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[idx];
+      if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[ct(r, c)];
     }
     if (npos) atomicAdd(&cnt[0], npos);
     if (nneg) atomicAdd(&cnt[1], nneg);
@@ -675,13 +676,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
   }
   for (int k = 0; k < nb; ++k) {                            // the corner, unblocked, in LDS
     __syncthreads();
-    const double dk = C[k * nb + k];
+    const double dk = C[ct(k, k)];
     for (int idx = t; idx < nb * nb; idx += nt) {
       const int r = idx / nb, c = idx % nb;
-      if (r > k && c > k && c <= r) C[idx] -= C[r * nb + k] / dk * C[c * nb + k];
+      if (r > k && c > k && c <= r) C[ct(r, c)] -= C[ct(r, k)] / dk * C[ct(c, k)];
     }
     __syncthreads();
-    for (int r = k + 1 + t; r < nb; r += nt) C[r * nb + k] /= dk;
+    for (int r = k + 1 + t; r < nb; r += nt) C[ct(r, k)] /= dk;
   }
   __syncthreads();
   for (int idx = t; idx < nb; idx += nt) {                  // the corner's 16 x 16 diagonal sub-blocks: L -> L^-1, column by column
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
       double v = c0 + i == cj ? 1.0 : 0.0;
 #pragma unroll
       for (int k = 0; k < i; ++k)
-        if (i < w2 && c0 + k >= cj) v = __builtin_fma(-C[(c0 + i) * nb + c0 + k], x[k], v);
+        if (i < w2 && c0 + k >= cj) v = __builtin_fma(-C[ct(c0 + i, c0 + k)], x[k], v);
       x[i] = c0 + i < cj ? 0.0 : v;
     }
     // in place: the 16 columns of a sub-block belong to 16 consecutive lanes of one wave, which has read all of them
@@ -700,14 +701,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < W; ++i)
-      if (i < w2 && c0 + i > cj) C[(c0 + i) * nb + cj] = x[i];
+      if (i < w2 && c0 + i > cj) C[ct(c0 + i, cj)] = x[i];
   }
   __syncthreads();
   for (int idx = t; idx < nb * nb; idx += nt) {
     const int r = idx / nb, c = idx % nb;
-    if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[idx];
+    if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[ct(r, c)];
     if (r == c) {
-      const double dk = C[idx];
+      const double dk = C[ct(r, r)];
       if (dk > 0) ++npos; else if (dk < 0) ++nneg; else ++nbad;
       if (!(fabs(dk) < 1e300)) ++nbad;
     }
@@ -1329,7 +1330,7 @@ void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st) {
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
   if (p.nd) return p.max_factor_lds;
   return (size_t(p.b + 24) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +
-          size_t(p.nb) * p.nb) * sizeof(double);
+          size_t(p.nb) * (p.nb + 1) / 2) * sizeof(double);
 }
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;

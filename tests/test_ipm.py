@@ -176,9 +176,7 @@ def test_kkt_factorisation_layouts_against_numpy(built, name, make, B, nested):
         for i, (mesh, nodes) in enumerate(meshes):
             problems.set_mesh(prob.GetPhase(i), mesh, nodes)
     eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
-    # (launch_unequal: the promoted unknowns bring the border to 107 rows; with the intervals' separators on top of that the
-    # corner no longer fits the LDS of the interval blocks, and the automatic mode — tested here — falls back to one band)
-    eng.set_option("ipm_nested", -1 if (name == "launch_unequal" and nested) else min(nested, 1))
+    eng.set_option("ipm_nested", min(nested, 1))       # (launch_unequal: the promoted unknowns bring the border to 107 rows, 121 in an interval block)
     if nested == 2:                  # the separator system cut once more, into groups of 48 of its positions (at least 3 bandwidths)
         eng.set_option("ipm_nested_group", 48)
     ipm = BatchedIPM(eng)
