@@ -1300,7 +1300,7 @@ void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_residual_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
-  const int assemble_blocks = std::max(1, std::min(64, (nnz_max + 255) / 256));
+  const int assemble_blocks = std::max(1, std::min(D.B <= 32 ? 2048 : 64, (nnz_max + 255) / 256));   // a few large instances: the whole chip
   const int zero_blocks = int(std::max<long long>(1, std::min<long long>(256, D.kstride / 2 / 256 + 1)));
   hipLaunchKernelGGL(ipm_zero_kernel, dim3(unsigned(zero_blocks), unsigned(D.B)), dim3(256), 0, st, D);
   hipLaunchKernelGGL(ipm_assemble_kernel, dim3(unsigned(assemble_blocks), unsigned(D.B)), dim3(256), 0, st, D);
