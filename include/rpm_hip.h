@@ -240,7 +240,8 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       "max_soc" (4, second-order correction steps per iteration; 0 = off),
  *                       "mu_strategy" (0 monotone Fiacco-McCormick rule; 1 adaptive = what lpopc asks Ipopt for,
  *                       Core/LpNLPSolver.cpp:28, with the LOQO oracle and the kkt-error globalisation: DESIGN.md f-2),
- *                       "sigma_cap" (0 = off; experimental clamp on z/s in the KKT matrix)
+ *                       "sigma_cap" (0 = off; experimental clamp on z/s in the KKT matrix),
+ *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,

@@ -29,6 +29,7 @@ struct IpmOpts {
   int mu_adaptive = 0;               // 1: Ipopt's mu_strategy=adaptive with the LOQO oracle and the kkt-error globalisation (oracle/ipm_oracle.py)
   double mu_max_fact = 1e3, mu_red_fact = 0.9999, mu_init_factor = 0.8;
   double sigma_cap = 0.0;            // experiment: cap z/s in the KKT matrix (0 = off)
+  int init_ls_mult = 0;              // 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
   // Ipopt's unscaled termination thresholds, required beside the scaled E_0 <= tol (resp. acceptable_tol)
   double dual_inf_tol = 1.0, constr_viol_tol = 1e-4, compl_inf_tol = 1e-4;
   double acc_dual_inf_tol = 1e10, acc_constr_viol_tol = 1e-2, acc_compl_inf_tol = 1e-2;

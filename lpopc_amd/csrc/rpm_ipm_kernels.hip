@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void ipm_init_kernel(IpmDev D, const double* x
     IpmInst& S = D.inst[bi];
     S = IpmInst{};
     S.mu = D.o.mu_init;
+    if (D.o.init_ls_mult && D.m > 0) { S.mode = 3; S.skip_update = -2; }   // first pass: least-squares multipliers at the starting point
   }
 }
 // slacks start at g(x0), pushed inside the (relaxed) [g_l, g_u] the same way
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
     const bool keep = mx <= D.o.mult_reset;       // false for NaN as well
     #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] = keep ? sol[D.pos[D.nv + r]] : 0.0;
-    if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = S.skip_update == -1 ? 2 : 1; S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
+    if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = S.skip_update == -1 ? 2 : (S.skip_update == -2 ? 3 : 1); S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
     return;
   }
   if (mode == 2) {              // restoration: step in (v, lambda) from the reduced system, p and n recovered from it
@@ -1180,7 +1181,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
   const double ks = D.o.kappa_sigma;
   if (s_skip) {           // this pass only replaced lambda (least-squares multipliers after the restoration, or recalc_y)
-    if (t == 0) { if (s_skip == 1) S.n_resto += 1; else S.n_recalc += 1; S.skip_update = 0; }
+    if (t == 0) { if (s_skip == 1) S.n_resto += 1; else if (s_skip == 2) S.n_recalc += 1; S.skip_update = 0; }
     return;
   }
   if (s_enter == 2) {     // recalc_y: the next pass computes least-squares multipliers at this point, nothing else

@@ -238,6 +238,7 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "bound_relax_factor") { if (!(value >= 0.0)) { h->err = "bound_relax_factor must be >= 0"; return RPM_E_INVALID; } o.bound_relax = value; }
   else if (k == "max_soc") o.max_soc = std::max(0, int(value));
   else if (k == "sigma_cap") o.sigma_cap = value;      // experiment
+  else if (k == "init_ls_multipliers") o.init_ls_mult = value != 0.0;
   else if (k == "mu_strategy") {       // 0 monotone (default), 1 adaptive: LOQO oracle + kkt-error globalisation
     if (value != 0.0 && value != 1.0) { h->err = "mu_strategy: 0 (monotone) or 1 (adaptive)"; return RPM_E_INVALID; }
     o.mu_adaptive = int(value);

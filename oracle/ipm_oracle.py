@@ -31,7 +31,7 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     Ipopt's default oracle there is the quality function (two more solves and a line search over sigma per iteration): not restated.
     Not the default here because the monotone rule needs half the iterations on Delta-III.
 Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle, NLP scaling,
-least-squares multipliers at the very first iterate (lambda_0 = 0), watchdog.  One deviation:
+least-squares multipliers at the very first iterate by default (option init_ls_multipliers; lambda_0 = 0 otherwise), watchdog.  One deviation:
 the constraint regularisation delta_c = 1e-9 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
 Parity status: UNPINNED by the reference (it holds no solver traces); pinned here by known optima and by scipy.
@@ -53,6 +53,7 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 resto_rho=1000.0, mult_reset=1e3,
                 mu_strategy="monotone", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
                 adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3,
+                init_ls_multipliers=0,                # 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
                 dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,                      # Ipopt's unscaled termination thresholds
                 acceptable_dual_inf_tol=1e10, acceptable_constr_viol_tol=1e-2, acceptable_compl_inf_tol=1e-2)
 
@@ -288,6 +289,8 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         return 3
 
     status = None
+    if o["init_ls_multipliers"] and m:
+        lam = ls_multipliers(v[:n], orc.eval_jac_g(v[:n]))
     while True:
         x = v[:n]
         f, grad, g, jv = orc.eval_f(x), orc.eval_grad_f(x), orc.eval_g(x), orc.eval_jac_g(x)
