@@ -26,7 +26,7 @@ struct IpmOpts {
   double bound_relax = 1e-8;         // Ipopt's bound_relax_factor: finite bounds of free unknowns move out by this * max(1, |bound|)
   int max_soc = 4;                   // second-order correction steps per iteration (paper A-5.5 .. A-5.9)
   double kappa_soc = 0.99;
-  int mu_adaptive = 0;               // 1: Ipopt's mu_strategy=adaptive with the LOQO oracle and the kkt-error globalisation (oracle/ipm_oracle.py)
+  int mu_adaptive = 1;               // 1: Ipopt's mu_strategy=adaptive with the LOQO oracle and the kkt-error globalisation (oracle/ipm_oracle.py)
   double mu_max_fact = 1e3, mu_red_fact = 0.9999, mu_init_factor = 0.8;
   double sigma_cap = 0.0;            // experiment: cap z/s in the KKT matrix (0 = off)
   int init_ls_mult = 0;              // 1: least-squares multipliers at the very first iterate too (Ipopt's default start)

@@ -182,11 +182,26 @@ class NLPEngine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.rpm_destroy(self._h)
+            self._L.rpm_destroy(self._h)          # also releases every page-locked registration
             self._h = None
+        self._bufs = {}                           # only now: see _own
 
     def __del__(self):
         self.close()
+
+    def _own(self, name, size):
+        """A result array owned by this object for calls without `out=`.  With pin_host = 1 the library page-locks every
+        host array it is handed and keeps the registration (rpm_hip.h: such arrays must outlive the engine or their
+        eviction); a temporary numpy array would be freed while still registered, and an unmapped range inside the HIP
+        runtime's table of locked memory ends in an abort of the process some copy later.  So temporaries never reach the
+        library: results are written into these buffers, which live until close(), and handed out as copies."""
+        bufs = self.__dict__.setdefault("_bufs", {})
+        b = bufs.get(name)
+        if b is None or b.size != size:
+            if b is not None:
+                bufs.setdefault("_retired", []).append(b)    # still registered: keep it alive
+            b = bufs[name] = np.zeros(size)
+        return b
 
     def _check(self, rc):
         if rc != RPM_OK:
@@ -223,28 +238,33 @@ class NLPEngine:
         return x
 
     def _x(self, x):
+        x0 = x
         x = np.ascontiguousarray(x, dtype=np.float64).ravel()
         if x.size != self.n * self.n_instances:
             raise RpmError(RPM_E_INVALID, "x has %d entries, expected %d" % (x.size, self.n * self.n_instances))
+        if not (isinstance(x0, np.ndarray) and np.shares_memory(x, x0)):     # a converted copy: a temporary (see _own)
+            b = self._own("x", x.size)
+            b[:] = x
+            return b
         return x
 
     def eval_f(self, x, new_x=True):
         x = self._x(x)
-        out = np.zeros(self.n_instances)
+        out = self._own("f", self.n_instances)
         self._check(self._L.rpm_eval_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
-        return out[0] if self.n_instances == 1 else out
+        return float(out[0]) if self.n_instances == 1 else out.copy()
 
     def eval_grad_f(self, x, new_x=True, out=None):
         x = self._x(x)
-        out = np.zeros(self.n * self.n_instances) if out is None else out
-        self._check(self._L.rpm_eval_grad_f(self._h, self.n, _dp(x), int(new_x), _dp(out)))
-        return out
+        res = self._own("grad", self.n * self.n_instances) if out is None else out
+        self._check(self._L.rpm_eval_grad_f(self._h, self.n, _dp(x), int(new_x), _dp(res)))
+        return res.copy() if out is None else out
 
     def eval_g(self, x, new_x=True, out=None):
         x = self._x(x)
-        out = np.zeros(self.m * self.n_instances) if out is None else out
-        self._check(self._L.rpm_eval_g(self._h, self.n, _dp(x), int(new_x), self.m, _dp(out)))
-        return out
+        res = self._own("g", self.m * self.n_instances) if out is None else out
+        self._check(self._L.rpm_eval_g(self._h, self.n, _dp(x), int(new_x), self.m, _dp(res)))
+        return res.copy() if out is None else out
 
     def eval_jac_g_structure(self):
         i, j = np.zeros(self.nnz_jac, dtype=np.int32), np.zeros(self.nnz_jac, dtype=np.int32)
@@ -253,17 +273,17 @@ class NLPEngine:
 
     def eval_jac_g(self, x, new_x=True, out=None):
         x = self._x(x)
-        out = np.zeros(self.nnz_jac * self.n_instances) if out is None else out
-        self._check(self._L.rpm_eval_jac_g(self._h, self.n, _dp(x), int(new_x), self.m, self.nnz_jac, None, None, _dp(out)))
-        return out
+        res = self._own("values", self.nnz_jac * self.n_instances) if out is None else out
+        self._check(self._L.rpm_eval_jac_g(self._h, self.n, _dp(x), int(new_x), self.m, self.nnz_jac, None, None, _dp(res)))
+        return res.copy() if out is None else out
 
     def eval_pair(self, x, g_out=None, values_out=None):
         """rpm_eval_pair: eval_g + eval_jac_g of one x in one call (host arrays) -> (g, values)."""
         x = self._x(x)
-        g = np.zeros(self.m * self.n_instances) if g_out is None else g_out
-        v = np.zeros(self.nnz_jac * self.n_instances) if values_out is None else values_out
+        g = self._own("g", self.m * self.n_instances) if g_out is None else g_out
+        v = self._own("values", self.nnz_jac * self.n_instances) if values_out is None else values_out
         self._check(self._L.rpm_eval_pair(self._h, self.n, _dp(x), self.m, _dp(g), self.nnz_jac, _dp(v)))
-        return g, v
+        return (g.copy() if g_out is None else g_out), (v.copy() if values_out is None else values_out)
 
     def eval_h_structure(self):
         i, j = np.zeros(self.nnz_h, dtype=np.int32), np.zeros(self.nnz_h, dtype=np.int32)
@@ -475,7 +495,7 @@ class BatchedIPM:
     engine's instances at once, iterates and KKT factors resident on the device.  The engine must have been created
     with hessian-approximation=exact."""
 
-    STATUS = {0: "converged", 1: "converged to the acceptable level", 2: "iteration limit", 3: "line search failed (restoration needed)",
+    STATUS = {0: "converged", 1: "converged to the acceptable level", 2: "iteration limit", 3: "line search and restoration phase failed",
               4: "inertia correction failed", 5: "NaN/Inf"}
 
     def __init__(self, engine, **options):
@@ -500,6 +520,8 @@ class BatchedIPM:
             raise RpmError(rc, self._L.rpm_ipm_last_error(self._h).decode())
 
     def set_option(self, key, value):
+        if key == "mu_strategy" and isinstance(value, str):       # Ipopt's spelling, as the restatement takes it
+            value = {"monotone": 0, "adaptive": 1}[value]
         self._chk(self._L.rpm_ipm_set_option(self._h, key.encode(), float(value)))
 
     def set_bounds(self, instance, x_l, x_u):

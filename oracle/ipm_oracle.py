@@ -51,7 +51,7 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 delta_w_max=1e40, kw_inc_first=100.0, kw_inc=8.0, kw_dec=1.0 / 3.0, max_iter=3000, max_ls=40, resto=1, resto_max=300, kappa_resto=0.9,
                 acceptable_tol=1e-6, acceptable_iter=15, linear_solver="dense", bound_relax_factor=1e-8, max_soc=4, kappa_soc=0.99,
                 resto_rho=1000.0, mult_reset=1e3,
-                mu_strategy="monotone", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
+                mu_strategy="adaptive", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
                 adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3,
                 init_ls_multipliers=0,                # 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
                 dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,                      # Ipopt's unscaled termination thresholds

@@ -14,7 +14,8 @@ from lpopc_amd.problem import Options  # noqa: E402
 
 CASES = {
     "bryson_denham_2x8": (lambda: problems.bryson_denham(2, 8), dict(tol=1e-8)),
-    "bryson_denham_default_restoration": (lambda: problems.bryson_denham(), dict(tol=1e-6)),
+    # (the monotone barrier rule: with the default, adaptive, this start needs no restoration phase)
+    "bryson_denham_default_restoration": (lambda: problems.bryson_denham(), dict(tol=1e-6, mu_strategy="monotone")),
     "hypersensitive_6x10": (lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), dict(tol=1e-8)),
     "quadrotor_2x4": (lambda: problems.quadrotor(2, 4), dict(tol=1e-8)),
     # the metric problem on a small mesh, from lpopc's default guess (example/launch/Launch.cpp:200-457): needs the bound

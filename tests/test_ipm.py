@@ -255,7 +255,16 @@ def test_device_solve_against_restatement(built, name, make, B, pert, same_path)
         if same_path:
             assert abs(int(r["iterations"][bi]) - ref["iterations"]) <= 1      # a barrier update decided at rounding level may shift by one
             assert np.max(np.abs(r["x"][bi] - ref["x"])) <= 1e-6 * max(1.0, np.max(np.abs(ref["x"])))
-            assert np.max(np.abs(r["lambda"][bi] - ref["lambda"])) <= 1e-5 * max(1.0, np.max(np.abs(ref["lambda"])))
+            # (rows that only fixed variables enter — e.g. an event on a fixed end point — have no Jacobian entry among the free
+            # unknowns: their multiplier is c / delta_c of a residual at rounding level, 1e5 with nothing behind it; left out)
+            ji, jj = o.jac_structure()
+            xl_, xu_, _, _ = o.bounds()
+            live = np.zeros(o.m, dtype=bool)
+            live[ji[xl_[jj] != xu_[jj]]] = True
+            dl = np.abs(r["lambda"][bi] - ref["lambda"])[live]
+            # (3e-4: Bryson-Denham and the brachistochrone carry multipliers of 1e5 on rows the optimum barely depends on; the two
+            # paths end a rounding-level barrier parameter apart and those multipliers 3e-5 .. 1.4e-4 apart)
+            assert dl.size == 0 or np.max(dl) <= 3e-4 * max(1.0, np.max(np.abs(ref["lambda"][live])))
             # step by step, while both are on the same path (a decision taken at rounding level may part them late): same
             # barrier parameter, inertia corrections and backtracking counts.  The first step uses lambda = 0, so its
             # Hessian is the objective's alone and everything agrees to rounding; from the second step on the constraint
@@ -266,10 +275,12 @@ def test_device_solve_against_restatement(built, name, make, B, pert, same_path)
             assert same >= min(5, ref["iterations"])
             for k in range(same):
                 e = ref["trace"][k]
-                # step 0: both solve the same KKT system (condition ~1e10 with delta_c = 1e-8 next to barrier terms of 1e2) in
+                # step 0: both solve the same KKT system (condition ~1e11 with delta_c = 1e-9 next to barrier terms of 1e2) in
                 # different elimination orders (dense LU there, interval-wise nested dissection here): step lengths to 1e-5
                 rel, ab = (1e-8, 1e-5) if k == 0 else (1e-2, 1e-2)
-                assert abs(tr[k, 2] - e["mu"]) <= 1e-12 * e["mu"] and abs(tr[k, 5] - e["delta_w"]) <= 1e-12 * e["delta_w"], (k, tr[k], e)
+                # (mu comes from the adaptive rule — the iterate's average and smallest complementarity — not from a fixed sequence)
+                # — sigma goes with the cube of (1 - xi) / xi, so a 1 % difference in the smallest complementarity is 3 % in mu)
+                assert abs(tr[k, 2] - e["mu"]) <= (1e-6 if k < 2 else 1e-1) * e["mu"] and abs(tr[k, 5] - e["delta_w"]) <= 1e-12 * e["delta_w"], (k, tr[k], e)
                 assert int(tr[k, 7]) == e["ls"], (k, tr[k], e)
                 assert abs(tr[k, 0] - e["f"]) <= rel * max(1.0, abs(e["f"])), (k, tr[k], e)
                 assert abs(tr[k, 1] - e["theta"]) <= rel * max(1.0, e["theta"]), (k, tr[k], e)
@@ -452,11 +463,13 @@ def test_tiny_and_ragged_layouts(built, name, make):
 
 
 def test_restatement_restoration_rescues_bryson_denham_on_the_default_mesh():
-    """example/bryson-denham as shipped (default 10 x 4 mesh): the filter line search gives up at an infeasible point
-    (theta ~ 4) where Ipopt would enter its restoration phase; the Gauss-Newton feasibility restoration brings it back."""
+    """example/bryson-denham as shipped (default 10 x 4 mesh) under the monotone barrier rule: the filter line search gives up
+    at an infeasible point (theta ~ 4) where Ipopt enters its restoration phase; the restoration phase brings it back.
+    (With the adaptive rule, the default, this start needs no restoration.)"""
     o = orc.Oracle(problems.bryson_denham(), _exact())
-    off = ipm_oracle.solve(o, o.starting_point(), tol=1e-6, resto=0)
-    on = ipm_oracle.solve(o, o.starting_point(), tol=1e-6)
+    off = ipm_oracle.solve(o, o.starting_point(), tol=1e-6, resto=0, mu_strategy="monotone")
+    on = ipm_oracle.solve(o, o.starting_point(), tol=1e-6, mu_strategy="monotone")
+    assert ipm_oracle.solve(o, o.starting_point(), tol=1e-6)["restorations"] == 0
     assert off["status"] == 3 and on["status"] == 0 and on["restorations"] >= 1
     assert abs(on["obj"] - 4.0) < 5e-3                      # coarse mesh
 
@@ -467,8 +480,8 @@ def test_device_restoration_against_restatement(built):
     prob = problems.bryson_denham()
     eng = NLPEngine(prob, _exact(), n_instances=2, device=0)
     o = orc.Oracle(prob, _exact())
-    ref = ipm_oracle.solve(o, o.starting_point(), tol=1e-6)
-    ipm = BatchedIPM(eng, tol=1e-6, trace=200)
+    ref = ipm_oracle.solve(o, o.starting_point(), tol=1e-6, mu_strategy="monotone")     # (the adaptive rule needs no restoration here)
+    ipm = BatchedIPM(eng, tol=1e-6, trace=200, mu_strategy="monotone")
     r = ipm.solve(np.tile(o.starting_point(), (2, 1)))
     assert (r["status"] == 0).all() and ref["status"] == 0
     assert (ipm.restorations() == ref["restorations"]).all() and ref["restorations"] >= 1
@@ -498,11 +511,11 @@ def test_instances_of_a_batch_switch_modes_independently(built):
     from lpopc_amd.engine import BatchedIPM, NLPEngine
     prob = problems.bryson_denham()
     o = orc.Oracle(prob, _exact())
-    ref = ipm_oracle.solve(o, o.starting_point(), tol=1e-6)
+    ref = ipm_oracle.solve(o, o.starting_point(), tol=1e-6, mu_strategy="monotone")
     assert ref["status"] == 0 and ref["restorations"] >= 1
     x0 = np.stack([o.starting_point(), ref["x"], o.starting_point() * (1 + 1e-2 * np.random.RandomState(2).uniform(-1, 1, o.n))])
     eng = NLPEngine(prob, _exact(), n_instances=3, device=0)
-    ipm = BatchedIPM(eng, tol=1e-6)
+    ipm = BatchedIPM(eng, tol=1e-6, mu_strategy="monotone")
     r = ipm.solve(x0)
     assert (r["status"] == 0).all(), r["status"]
     assert np.max(np.abs(r["obj"] - ref["obj"])) <= 1e-5 * abs(ref["obj"])
@@ -510,7 +523,7 @@ def test_instances_of_a_batch_switch_modes_independently(built):
     assert n_resto[0] == ref["restorations"] and n_resto[1] == 0
     assert r["iterations"][1] < r["iterations"][0] - 5
     for bi in (1, 2):                                     # each against the restatement run from its own start
-        rb = ipm_oracle.solve(o, x0[bi], tol=1e-6)
+        rb = ipm_oracle.solve(o, x0[bi], tol=1e-6, mu_strategy="monotone")
         assert rb["status"] == 0 and abs(r["obj"][bi] - rb["obj"]) <= 1e-5 * abs(rb["obj"])
     ipm.close()
     eng.close()
@@ -647,11 +660,11 @@ ADAPTIVE = [("bryson_denham_default", lambda: problems.bryson_denham(), 1e-8), (
 
 @pytest.mark.parametrize("name,make,tol", ADAPTIVE, ids=[c[0] for c in ADAPTIVE])
 def test_restatement_adaptive_barrier_update(name, make, tol):
-    """mu_strategy = adaptive (what the reference asks Ipopt for; LOQO oracle, kkt-error globalisation) ends where the monotone
-    rule ends on the convex / well-behaved problems, in no more than 1.5 x the iterations."""
+    """mu_strategy = adaptive (the default: what the reference asks Ipopt for; LOQO oracle, kkt-error globalisation) ends where
+    the monotone rule ends on the convex / well-behaved problems, in no more than 1.5 x the iterations."""
     o = orc.Oracle(make(), _exact())
     a = ipm_oracle.solve(o, o.starting_point(), tol=tol, mu_strategy="adaptive")
-    b = ipm_oracle.solve(o, o.starting_point(), tol=tol)
+    b = ipm_oracle.solve(o, o.starting_point(), tol=tol, mu_strategy="monotone")
     assert a["status"] == 0 and b["status"] == 0
     assert abs(a["obj"] - b["obj"]) <= 1e-6 * max(1.0, abs(b["obj"]))
     assert a["iterations"] <= 1.5 * b["iterations"] + 2
