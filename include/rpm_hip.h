@@ -238,8 +238,9 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       "acceptable_tol" (1e-6), "acceptable_iter" (15), "bound_relax_factor" (1e-8, as Ipopt: finite bounds
  *                       of free unknowns move out by this * max(1, |bound|), so a solution may sit that far outside them),
  *                       "max_soc" (4, second-order correction steps per iteration; 0 = off),
- *                       "mu_strategy" (0 monotone Fiacco-McCormick rule; 1 adaptive = what lpopc asks Ipopt for,
- *                       Core/LpNLPSolver.cpp:28, with the LOQO oracle and the kkt-error globalisation: DESIGN.md f-2),
+ *                       "mu_strategy" (1, default: adaptive = what lpopc asks Ipopt for, Core/LpNLPSolver.cpp:28, with the
+ *                       LOQO oracle and the kkt-error globalisation; 0: the monotone Fiacco-McCormick rule,
+ *                       three batched iterations fewer on the quadrotor sweep),
  *                       "sigma_cap" (0 = off; experimental clamp on z/s in the KKT matrix),
  *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared

@@ -5,7 +5,7 @@
 // independent instances of one transcription — the MPC sweep of BASELINE config 5 — with every iterate, multiplier,
 // KKT matrix and factor resident in HBM.  Restated beyond the basic iteration: bound_relax_factor, the second-order correction,
 // the restoration phase (paper section 3.3, with a Gauss-Newton model of the constraint curvature) and least-squares
-// multipliers on leaving it, and (option "mu_strategy" 1) Ipopt's adaptive barrier update with the LOQO oracle.  Not restated:
+// multipliers on leaving it, and Ipopt's adaptive barrier update with the LOQO oracle (option "mu_strategy", default 1; 0 = monotone).  Not restated:
 // the quality-function oracle, scaling, the watchdog.  See DESIGN.md §f-2.
 //
 // The KKT matrix of a collocation NLP is banded once the unknowns are ordered along time: node k's states, controls,

@@ -22,14 +22,14 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     lambda = 0 when they exceed 1e3); the same least-squares multipliers (Ipopt's recalc_y) up to 3 times when the line
     search gives up at a FEASIBLE point.  One simplification: the restoration problem's Hessian leaves out the constraint
     curvature sum lambda_j Hess c_j (a Gauss-Newton model of it: no inertia correction is ever needed there).
-  * mu_strategy = "adaptive" (what the reference asks Ipopt for, Core/LpNLPSolver.cpp:28) as an OPTION, default "monotone":
+  * mu_strategy = "adaptive" (what the reference asks Ipopt for, Core/LpNLPSolver.cpp:28), the DEFAULT; "monotone" = rule (7):
     Ipopt's adaptive update (Nocedal, Waechter, Waltz, SIAM J. Optim. 19, 2009) with the LOQO oracle (Ipopt's mu_oracle=loqo:
     mu = sigma * average complementarity, sigma = 0.1 min(0.05 (1 - xi) / xi, 2)^3, xi = smallest / average complementarity)
     and the kkt-error globalisation (free mode while the KKT error — 2-norm-squared of dual / primal infeasibility and
     complementarity, each divided by its length — is below 0.9999 of one of the last 4 accepted values, otherwise the
     monotone rule from mu = 0.8 * average complementarity until it is again); the filter is emptied whenever mu changes.
     Ipopt's default oracle there is the quality function (two more solves and a line search over sigma per iteration): not restated.
-    Not the default here because the monotone rule needs half the iterations on Delta-III.
+    The default because it is what the reference configures and the more robust rule on Delta-III.
 Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle, NLP scaling,
 least-squares multipliers at the very first iterate by default (option init_ls_multipliers; lambda_0 = 0 otherwise), watchdog.  One deviation:
 the constraint regularisation delta_c = 1e-9 is always on

@@ -18,13 +18,14 @@ from lpopc_amd.problem import Options
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_cpu = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 nested = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+mu_strategy = sys.argv[4] if len(sys.argv) > 4 else "adaptive"     # the solver's default; "monotone" needs fewer iterations on this sweep
 o = Options()
 o.SetStringValue("hessian-approximation", "exact")
 prob = problems.quadrotor(8, 8)
 eng = NLPEngine(prob, o, n_instances=B, device=0)
 eng.set_option("instance_align", 16)
 eng.set_option("ipm_nested", nested)
-ipm = BatchedIPM(eng)
+ipm = BatchedIPM(eng, mu_strategy=mu_strategy)
 one = NLPEngine(prob, o, device=0)
 xl, xu, _, _ = one.get_bounds_info()
 x_start = one.get_starting_point()
@@ -53,7 +54,7 @@ st, info, kt = ipm.stats(), ipm.info(), ipm.kernel_times()
 dt = min(times)
 nb, b, nbd = info["band_order"], info["half_bandwidth"], info["border"]
 flops_factor = ipm.factor_flops()        # from the sub-problems' geometry: sum over band columns of r (r + 1), r = rows below the pivot
-out = {"workload": "quadrotor MPC sweep, %d instances x (8x8), per-instance initial states" % B, "instances": B,
+out = {"mu_strategy": mu_strategy, "workload": "quadrotor MPC sweep, %d instances x (8x8), per-instance initial states" % B, "instances": B,
        "factorisation": "nested dissection over the mesh intervals" if nested else "band + border", "sub_problems_per_instance": int(ipm.subproblems().shape[0]),
        "solve_s": dt, "solves_per_s": B / dt, "iterations_min_max": [int(r["iterations"].min()), int(r["iterations"].max())],
        "batched_iterations": st["iterations"], "factorizations": st["factorizations"], "trial_points": st["trial_points"],
