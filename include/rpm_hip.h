@@ -357,8 +357,10 @@ int rpm_synchronize(rpm_engine* e);
  *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —
  *                    so copies run at PCIe rate and the kernels can address them.  At most 8 registrations are kept
  *                    (least recently used is released first; a new range that overlaps an old one replaces it); all are
- *                    released by rpm_destroy.  LIFETIME: a registered array must stay mapped until rpm_destroy or until it
- *                    has been evicted; set 0 if the caller frees and re-allocates these buffers between calls.
+ *                    released by rpm_destroy, or at once by setting the option to 0 (do that BEFORE unmapping a registered
+ *                    array, e.g. a shared segment).  LIFETIME: a registered array must stay mapped until rpm_destroy, its
+ *                    eviction or that release; leave the option 0 if the caller frees and re-allocates these buffers between
+ *                    calls.  (An unmapped range that is still page-locked can end the process in a later copy: DESIGN.md §6.)
  */
 /* Parameter sweeps (n_instances > 1): by default every instance shares the problem functor's constants
  * (rpm_problem_desc.consts — the reference keeps them in file-scope globals, example/launch/Launch.cpp:47-74).  This

@@ -517,7 +517,10 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   const std::string k(key);
   if (k == "fuse_pair") e.opt_fuse_pair = value ? 1 : 0;
   else if (k == "check_finite") e.opt_check_finite = value ? 1 : 0;
-  else if (k == "pin_host") e.opt_pin_host = value ? 1 : 0;
+  else if (k == "pin_host") {
+    e.opt_pin_host = value ? 1 : 0;
+    if (!value) rpm::dev_pin_release_all(e);   // a caller that is about to unmap its arrays turns the option off first
+  }
   else if (k == "dx_mode") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "dx_mode must be 0 (scalar, reference order) or 1 (MFMA)");
     if (value == 1 && e.first_derive == RPM_DERIVE_ANALYTIC)

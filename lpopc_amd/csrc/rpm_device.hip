@@ -423,6 +423,14 @@ int dev_pin_counter(int which) { return which == 0 ? g_pin_reg_ok : (which == 1 
 static void pin_release(const void* ptr) {
   if (hipHostUnregister(const_cast<void*>(ptr)) != hipSuccess) { ++g_pin_unreg_fail; (void)hipGetLastError(); }
 }
+// rpm_set_option "pin_host" 0: every registration goes (a caller about to unmap its arrays — e.g. a shared segment — turns the
+// option off first)
+void dev_pin_release_all(Engine& e) {
+  if (!e.dev) return;
+  for (auto& p : e.dev->pinned) pin_release(p.ptr);
+  e.dev->pinned.clear();
+  (void)hipGetLastError();
+}
 void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
   constexpr size_t PIN_MAX = 8;
   if (!e.opt_pin_host || !ptr || bytes == 0) return nullptr;   // small arrays too: a pageable copy costs ~20 us each way

@@ -264,5 +264,6 @@ int dev_flag_value(Engine& e, int slot);
 int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count);
 int dev_pin_counter(int which);   // process-wide: 0 registrations made, 1 registrations refused, 2 unregistrations refused
 void* dev_pin_host(Engine& e, const void* ptr, size_t bytes);      // page-lock a caller buffer once (best effort); its device alias or nullptr
+void dev_pin_release_all(Engine& e);   // drop every page-locked registration (rpm_set_option "pin_host" 0)
 
 }  // namespace rpm

@@ -181,6 +181,10 @@ class HostConsumerGroup:
                     pass
 
     def close(self):
+        try:
+            self.eng.set_option("pin_host", 0)      # releases the page-locked registrations of the segment BEFORE it is unmapped
+        except Exception:
+            pass
         self.x = self.g = self.values = self.ctrl = None
         try:
             self.dist.barrier()
