@@ -70,6 +70,11 @@ class RpmTNLPT : public Base {
                          const typename Base::IpoptData* /*ip_data*/,
                          typename Base::IpoptCalculatedQuantities* /*ip_cq*/) override {
     rpm_finalize_solution(e_, int(status), n, x, z_L, z_U, m, g, lambda, obj_value);  // LpopcIpopt.cpp:220-246
+    // Ipopt's last call into the TNLP, and its x / g / values arrays (TNLPAdapter's) may be freed before this object is:
+    // release their page-locked registrations now (rpm_hip.h "pin_host": a registered array must not be unmapped), and
+    // turn the option back on for a further OptimizeTNLP with the same object.
+    rpm_set_option(e_, "pin_host", 0);
+    rpm_set_option(e_, "pin_host", 1);
   }
   std::string last_error() const { return rpm_last_error(e_); }
 
