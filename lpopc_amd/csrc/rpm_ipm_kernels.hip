@@ -260,19 +260,19 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
     const double acc = glag[i];               // grad f + A^T lambda (ipm_jt_lambda_kernel)
-    const double l = vl[i], u = vu[i];
+    const double l = vl[i], u = vu[i], vi = v[i], zli = zL[i], zui = zU[i];    // loads ahead of the branch
     if (l != u) {
-      const double dres = acc - zL[i] + zU[i];
+      const double dres = acc - zli + zui;
       dinf = fmax(dinf, fabs(dres));
       dsq += dres * dres; nfree += 1;
       if (!(fabs(acc) < 1e300)) bad = 1;
       if (l > -IPM_INF) {
-        const double d = v[i] - l, pr = zL[i] * d;
-        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zL[i]; ln += log(d); nzb += 1; psum += pr; psq += pr * pr;
+        const double d = vi - l, pr = zli * d;
+        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zli; ln += log(d); nzb += 1; psum += pr; psq += pr * pr;
       }
       if (u < IPM_INF) {
-        const double d = u - v[i], pr = zU[i] * d;
-        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zU[i]; ln += log(d); nzb += 1; psum += pr; psq += pr * pr;
+        const double d = u - vi, pr = zui * d;
+        cmax = fmax(cmax, pr); cmin = fmin(cmin, pr); sz += zui; ln += log(d); nzb += 1; psum += pr; psq += pr * pr;
       }
     }
   }
@@ -878,21 +878,22 @@ __device__ inline void newton_step(const IpmDev& D, int bi, const double* sol, d
   double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
   #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
-    const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
+    const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i], dsol = sol[D.pos[i]], zl = D.zL[o + i], zu = D.zU[o + i];
+    const double gri = i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0;     // every load ahead of the branches (kept in flight by the unrolling)
     double d = 0.0, dl = 0.0, du = 0.0;
     if (l != u) {
-      d = sol[D.pos[i]];
+      d = dsol;
       if (!(fabs(d) < 1e300)) bad = 1;
-      double gphi = i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0;
+      double gphi = gri;
       if (l > -IPM_INF) {
-        const double s = vi - l, z = D.zL[o + i];
+        const double s = vi - l, z = zl;
         dl = mu / s - z - z / s * d;                       // (12)
         amax = ftb(s, d, tau, amax);                       // (15a)
         az = ftb(z, dl, tau, az);                          // (15b)
         gphi -= mu / s;
       }
       if (u < IPM_INF) {
-        const double s = u - vi, z = D.zU[o + i];
+        const double s = u - vi, z = zu;
         du = mu / s - z + z / s * d;
         amax = ftb(s, -d, tau, amax);
         az = ftb(z, du, tau, az);
@@ -1062,9 +1063,9 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   const bool resto = mode == 2;
   #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
-    const double l = D.vl[o + i], u = D.vu[o + i];
-    if (l == u) continue;
-    const double vt = D.v[o + i] + a * dvp[o + i];
+    const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i], di = dvp[o + i];   // loads ahead of the branch: the unrolled
+    if (l == u) continue;                                                                 // iterations keep 16 of them in flight
+    const double vt = vi + a * di;
     if (l > -IPM_INF) ln += log(vt - l);
     if (u < IPM_INF) ln += log(u - vt);
     if (resto) { const double dd = vt - D.vR[o + i]; qd += D.dr2[o + i] * dd * dd; }
@@ -1257,12 +1258,13 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   const double *dv = s_soc ? D.dv2 : D.dv, *dlam = s_soc ? D.dlam2 : D.dlam, *dzL = s_soc ? D.dzL2 : D.dzL, *dzU = s_soc ? D.dzU2 : D.dzU;
   #pragma unroll 4
   for (int i = t; i < D.nv; i += blockDim.x) {
-    const double l = D.vl[o + i], u = D.vu[o + i];
+    const double l = D.vl[o + i], u = D.vu[o + i], v0 = D.v[o + i], di = dv[o + i];
+    const double zl = D.zL[o + i], zu = D.zU[o + i], dl = dzL[o + i], du = dzU[o + i];        // loads ahead of the branch
     if (l == u) continue;
-    const double vi = D.v[o + i] + a * dv[o + i];
+    const double vi = v0 + a * di;
     D.v[o + i] = vi;
-    if (l > -IPM_INF) D.zL[o + i] = reset16(D.zL[o + i] + az * dzL[o + i], vi - l, mu, ks);   // (16)
-    if (u < IPM_INF) D.zU[o + i] = reset16(D.zU[o + i] + az * dzU[o + i], u - vi, mu, ks);
+    if (l > -IPM_INF) D.zL[o + i] = reset16(zl + az * dl, vi - l, mu, ks);   // (16)
+    if (u < IPM_INF) D.zU[o + i] = reset16(zu + az * du, u - vi, mu, ks);
   }
   #pragma unroll 4
   for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] += a * dlam[om + r];
