@@ -81,6 +81,8 @@ struct IpmDev {
   double *vl0, *vu0;  // the caller's bounds; vl, vu are these moved out by bound_relax (ipm_init_kernel)
   double *pp, *nn, *zp, *zn, *dpp, *dnn, *dzp, *dzn;   // restoration: c(v) - p + n = 0, p, n >= 0, their multipliers and steps (m each)
   double* rfilt;      // restoration's own filter
+  double* part;       // partial sums of the vector kernels that run several workgroups per instance (IPM_VEC_BLOCKS x IPM_VEC_PART per instance)
+  int* tick;          // their arrival counters (one per instance, left at zero by the last workgroup)
   double *dv2, *dlam2, *dzL2, *dzU2, *csoc, *ct;       // second-order correction: candidate step, c_soc, c(trial point)
   double* trace;   // per instance trace_cap records of IPM_TRACE doubles (one per accepted step), or NULL
   int trace_cap;
@@ -103,6 +105,8 @@ struct IpmDev {
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
 };
 
+constexpr int IPM_VEC_BLOCKS = 64;   // most workgroups per instance of a vector kernel
+constexpr int IPM_VEC_PART = 24;     // doubles of partial results per workgroup
 constexpr int IPM_MT = 8;   // most 16-row tiles per wave of the factorisation: block columns of up to 4 x 8 x 16 = 512 rows
 
 // launchers (rpm_ipm_kernels.hip); all asynchronous on `st`

@@ -45,6 +45,39 @@ __device__ inline double readlane_d(double v, int lane) {
 __device__ inline bool has_lo(double l, double u) { return l > -IPM_INF && l != u; }
 __device__ inline bool has_up(double l, double u) { return u < IPM_INF && l != u; }
 
+// Several workgroups per instance (gridDim.x = G > 1; blockIdx.y = instance) when a few large instances run: every workgroup
+// takes a slice and leaves its N partial results (kind 0 sum, 1 max, 2 min) in D.part; the LAST one to arrive — a ticket in
+// D.tick — combines them in workgroup order, so the totals do not depend on who finishes last, and carries on alone with the
+// instance's verdicts (true is returned on that workgroup only; with G = 1 always).  Until then nobody has changed the
+// instance record, so every workgroup has read the same flags.
+template <int N>
+__device__ inline bool vec_combine(const IpmDev& D, int bi, double (&vals)[N], const int (&kind)[N]) {
+  static_assert(N <= IPM_VEC_PART, "IPM_VEC_PART");
+  const int G = gridDim.x;
+  if (G == 1) return true;
+  __shared__ int last_arrival;
+  double* P = D.part + size_t(bi) * IPM_VEC_BLOCKS * IPM_VEC_PART;
+  if (threadIdx.x == 0) {
+    double* mine = P + size_t(blockIdx.x) * IPM_VEC_PART;
+#pragma unroll
+    for (int k = 0; k < N; ++k) mine[k] = vals[k];
+    __threadfence();
+    last_arrival = atomicAdd(&D.tick[bi], 1) == G - 1;
+  }
+  __syncthreads();
+  if (!last_arrival) return false;
+  __threadfence();
+#pragma unroll
+  for (int k = 0; k < N; ++k) vals[k] = kind[k] == 0 ? 0.0 : (kind[k] == 1 ? -1e300 : 1e300);
+  for (int b = 0; b < G; ++b) {
+    const double* q = P + size_t(b) * IPM_VEC_PART;
+#pragma unroll
+    for (int k = 0; k < N; ++k) vals[k] = kind[k] == 0 ? vals[k] + q[k] : (kind[k] == 1 ? fmax(vals[k], q[k]) : fmin(vals[k], q[k]));
+  }
+  if (threadIdx.x == 0) D.tick[bi] = 0;
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ start
 // x pushed into the interior of its bounds (Ipopt 3.12 bound_push / bound_frac, paper section 3.6), z = 1, lambda = 0.  The
 // bounds themselves first move out by bound_relax * max(1, |bound|) (Ipopt's bound_relax_factor): vl0 / vu0 keep the caller's.
@@ -147,12 +180,13 @@ __global__ __launch_bounds__(256) void ipm_jt_lambda_kernel(IpmDev D, int n_thre
 __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   __shared__ double sh[16];
   __shared__ int verdict;       // restoration: 0 stay, 1 leave it (least-squares multipliers next), 2 stop
-  const int bi = blockIdx.x, t = threadIdx.x;
+  // (several workgroups per instance when a few large instances run: slices i0, i0 + stride, ...; vec_combine)
+  const int bi = blockIdx.y, t = threadIdx.x, i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
   const int mode_in = S.mode;
   if (mode_in == 3) {           // recalc_y: a pass that only recomputes the multipliers at this point (set by ipm_update_kernel)
-    if (t == 0) { S.refactor = 1; S.delta_w = 0.0; atomicAdd(&D.cnt[0], 1); }
+    if (t == 0 && blockIdx.x == 0) { S.refactor = 1; S.delta_w = 0.0; atomicAdd(&D.cnt[0], 1); }
     return;
   }
   const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
@@ -162,7 +196,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   double csq = 0, dsq = 0, psum = 0, psq = 0, nfree = 0;      // 2-norms for the adaptive barrier update's KKT error
   // pass 1: constraint values and what does not depend on the multipliers
   #pragma unroll 4
-  for (int r = t; r < D.m; r += blockDim.x) {
+  for (int r = i0; r < D.m; r += stride) {
     const int s = D.row_slack[r];
     const double cr = s < 0 ? g[r] - D.gl[r] : g[r] - v[D.n + s];
     D.c[size_t(bi) * D.m + r] = cr;
@@ -180,7 +214,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     const double *vR = D.vR + size_t(bi) * D.nv, *dr2 = D.dr2 + size_t(bi) * D.nv;
     double thr = 0, rinf = 0, spn = 0, lnpn = 0, qd = 0;
     #pragma unroll 4
-    for (int r = t; r < D.m; r += blockDim.x) {
+    for (int r = i0; r < D.m; r += stride) {
       const double rc = D.c[size_t(bi) * D.m + r] - pp[r] + nn[r];
       thr += fabs(rc); rinf = fmax(rinf, fabs(rc));
       spn += pp[r] + nn[r];
@@ -190,7 +224,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
       cmax = fmax(cmax, fmax(p1, p2)); cmin = fmin(cmin, fmin(p1, p2));
     }
     #pragma unroll 4
-    for (int i = t; i < D.nv; i += blockDim.x) {
+    for (int i = i0; i < D.nv; i += stride) {
       const double acc = glag[i];             // A^T lambda only (ipm_jt_lambda_kernel): the proximity term is added where zeta is known
       const double l = vl[i], u = vu[i];
       if (l == u) continue;
@@ -204,6 +238,13 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
     thr = block_red(thr, 0, sh); rinf = block_red(rinf, 1, sh); spn = block_red(spn, 0, sh); lnpn = block_red(lnpn, 0, sh);
     qd = block_red(qd, 0, sh); dinf = block_red(dinf, 1, sh); cmax = block_red(cmax, 1, sh); cmin = block_red(cmin, 2, sh);
     ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh);
+    {
+      double vals[12] = {thr, rinf, spn, lnpn, qd, dinf, cmax, cmin, ln, bad, cinf, th1};
+      const int kind[12] = {0, 1, 0, 0, 0, 1, 1, 2, 0, 1, 1, 0};
+      if (!vec_combine(D, bi, vals, kind)) return;
+      thr = vals[0]; rinf = vals[1]; spn = vals[2]; lnpn = vals[3]; qd = vals[4]; dinf = vals[5]; cmax = vals[6]; cmin = vals[7];
+      ln = vals[8]; bad = vals[9]; cinf = vals[10]; th1 = vals[11];
+    }
     if (t == 0) {
       const double f = D.obj[bi];
       verdict = 0;
@@ -258,7 +299,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   }
   // pass 2: gradient of the Lagrangian, complementarity products
   #pragma unroll 4
-  for (int i = t; i < D.nv; i += blockDim.x) {
+  for (int i = i0; i < D.nv; i += stride) {
     const double acc = glag[i];               // grad f + A^T lambda (ipm_jt_lambda_kernel)
     const double l = vl[i], u = vu[i], vi = v[i], zli = zL[i], zui = zU[i];    // loads ahead of the branch
     if (l != u) {
@@ -276,15 +317,20 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
       }
     }
   }
-  if (D.o.mu_adaptive) {
-    csq = block_red(csq, 0, sh); dsq = block_red(dsq, 0, sh); psum = block_red(psum, 0, sh); psq = block_red(psq, 0, sh);
-    nfree = block_red(nfree, 0, sh);
-  }
+  csq = block_red(csq, 0, sh); dsq = block_red(dsq, 0, sh); psum = block_red(psum, 0, sh); psq = block_red(psq, 0, sh);
+  nfree = block_red(nfree, 0, sh);
   #pragma unroll 4
-  for (int r = t; r < D.m; r += blockDim.x) sl += fabs(lam[r]);
+  for (int r = i0; r < D.m; r += stride) sl += fabs(lam[r]);
   dinf = block_red(dinf, 1, sh);
   cmax = block_red(cmax, 1, sh); cmin = block_red(cmin, 2, sh); sl = block_red(sl, 0, sh); sz = block_red(sz, 0, sh);
   ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh); nzb = block_red(nzb, 0, sh);
+  {
+    double vals[15] = {dinf, cmax, cmin, sl, sz, ln, bad, nzb, cinf, th1, csq, dsq, psum, psq, nfree};
+    const int kind[15] = {1, 1, 2, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
+    if (!vec_combine(D, bi, vals, kind)) return;
+    dinf = vals[0]; cmax = vals[1]; cmin = vals[2]; sl = vals[3]; sz = vals[4]; ln = vals[5]; bad = vals[6]; nzb = vals[7];
+    cinf = vals[8]; th1 = vals[9]; csq = vals[10]; dsq = vals[11]; psum = vals[12]; psq = vals[13]; nfree = vals[14];
+  }
   if (t != 0) return;
   const IpmOpts& o = D.o;
   S.f = D.obj[bi]; S.theta = th1; S.lnsum = ln; S.dinf = dinf; S.cinf = cinf; S.comp_max = cmax; S.comp_min = cmin;
@@ -871,13 +917,13 @@ __global__ void ipm_inertia_kernel(IpmDev D) {
 __device__ inline double ftb(double w, double dw, double tau, double a) { return dw < 0 ? fmin(a, -tau * w / dw) : a; }
 
 // step of the regular iteration from a solution of (13): dz (12), step lengths (15), slope of the barrier objective
-__device__ inline void newton_step(const IpmDev& D, int bi, const double* sol, double* dv, double* dlam, double* dzL, double* dzU,
+__device__ inline bool newton_step(const IpmDev& D, int bi, const double* sol, double* dv, double* dlam, double* dzL, double* dzU,
                                    double mu, double tau, double* sh, double* amax_o, double* az_o, double* dphi_o, double* bad_o) {
   const size_t o = size_t(bi) * D.nv;
-  const int t = threadIdx.x;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;    // this workgroup's slice (vec_combine)
   double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
   #pragma unroll 4
-  for (int i = t; i < D.nv; i += blockDim.x) {
+  for (int i = i0; i < D.nv; i += stride) {
     const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i], dsol = sol[D.pos[i]], zl = D.zL[o + i], zu = D.zU[o + i];
     const double gri = i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0;     // every load ahead of the branches (kept in flight by the unrolling)
     double d = 0.0, dl = 0.0, du = 0.0;
@@ -906,8 +952,12 @@ __device__ inline void newton_step(const IpmDev& D, int bi, const double* sol, d
     dzU[o + i] = du;
   }
   #pragma unroll 4
-  for (int r = t; r < D.m; r += blockDim.x) dlam[size_t(bi) * D.m + r] = sol[D.pos[D.nv + r]];
-  *amax_o = block_red(amax, 2, sh); *az_o = block_red(az, 2, sh); *dphi_o = block_red(dphi, 0, sh); *bad_o = block_red(bad, 1, sh);
+  for (int r = i0; r < D.m; r += stride) dlam[size_t(bi) * D.m + r] = sol[D.pos[D.nv + r]];
+  double vals[4] = {block_red(amax, 2, sh), block_red(az, 2, sh), block_red(dphi, 0, sh), block_red(bad, 1, sh)};
+  const int kind[4] = {2, 2, 0, 1};
+  if (!vec_combine(D, bi, vals, kind)) return false;       // only the last workgroup of the instance goes on
+  *amax_o = vals[0]; *az_o = vals[1]; *dphi_o = vals[2]; *bad_o = vals[3];
+  return true;
 }
 __device__ inline double alpha_min23(const IpmOpts& op, double theta, double theta_min, double dphi) {   // (23)
   double amin = op.gamma_theta;
@@ -920,20 +970,22 @@ __device__ inline double alpha_min23(const IpmOpts& op, double theta, double the
 
 __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
   __shared__ double sh[16];
-  const int bi = blockIdx.x, t = threadIdx.x;
+  const int bi = blockIdx.y, t = threadIdx.x, i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   IpmInst& S = D.inst[bi];
   const int status = S.status, mode = S.mode;
   const double mu = mode == 2 ? S.mu_r : S.mu, tau = S.tau;
-  __syncthreads();              // thread 0 rewrites S.mode below: everybody has read it
+  __syncthreads();              // thread 0 (of the last workgroup, vec_combine) rewrites S.mode below: everybody has read it
   if (status != 0) return;
   const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
   const double* sol = D.rhs + size_t(bi) * D.Nt;
   if (mode == 3) {              // least-squares multipliers on leaving the restoration; lambda = 0 when they are large (section 3.6)
     double mx = 0.0;
     #pragma unroll 4
-    for (int r = t; r < D.m; r += blockDim.x) mx = fmax(mx, fabs(sol[D.pos[D.nv + r]]));
-    mx = block_red(mx, 1, sh);
-    const bool keep = mx <= D.o.mult_reset;       // false for NaN as well
+    for (int r = i0; r < D.m; r += stride) { const double w = fabs(sol[D.pos[D.nv + r]]); mx = (w < 1e300) ? fmax(mx, w) : 1e300; }   // NaN counts as too large
+    double vals[1] = {block_red(mx, 1, sh)};
+    const int kind[1] = {1};
+    if (!vec_combine(D, bi, vals, kind)) return;
+    const bool keep = vals[0] <= D.o.mult_reset;
     #pragma unroll 4
     for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] = keep ? sol[D.pos[D.nv + r]] : 0.0;
     if (t == 0) { S.mode = 0; S.accepted = 1; S.skip_update = S.skip_update == -1 ? 2 : (S.skip_update == -2 ? 3 : 1); S.ls = 0; S.armijo = 0; S.soc_on = 0; S.soc_req = 0; S.use_soc = 0; }
@@ -943,7 +995,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
     const double rho = D.o.resto_rho, zeta = S.zeta;
     double amax = 1.0, az = 1.0, dphi = 0.0, bad = 0.0;
     #pragma unroll 4
-    for (int i = t; i < D.nv; i += blockDim.x) {
+    for (int i = i0; i < D.nv; i += stride) {
       const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i];
       double d = 0.0, dl = 0.0, du = 0.0;
       if (l != u) {
@@ -967,7 +1019,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
       D.dv[o + i] = d; D.dzL[o + i] = dl; D.dzU[o + i] = du;
     }
     #pragma unroll 4
-    for (int r = t; r < D.m; r += blockDim.x) {
+    for (int r = i0; r < D.m; r += stride) {
       const double pp = D.pp[om + r], nn = D.nn[om + r], zp = D.zp[om + r], zn = D.zn[om + r], lam = D.lam[om + r];
       const double sp = zp / pp, sn = zn / nn, dlam = sol[D.pos[D.nv + r]];
       if (!(fabs(dlam) < 1e300)) bad = 1;
@@ -979,7 +1031,12 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
       dphi += (rho - mu / pp) * dp + (rho - mu / nn) * dn;
       D.dlam[om + r] = dlam; D.dpp[om + r] = dp; D.dnn[om + r] = dn; D.dzp[om + r] = dzp; D.dzn[om + r] = dzn;
     }
-    amax = block_red(amax, 2, sh); az = block_red(az, 2, sh); dphi = block_red(dphi, 0, sh); bad = block_red(bad, 1, sh);
+    {
+      double vals[4] = {block_red(amax, 2, sh), block_red(az, 2, sh), block_red(dphi, 0, sh), block_red(bad, 1, sh)};
+      const int kind[4] = {2, 2, 0, 1};
+      if (!vec_combine(D, bi, vals, kind)) return;
+      amax = vals[0]; az = vals[1]; dphi = vals[2]; bad = vals[3];
+    }
     if (t != 0) return;
     if (bad != 0) { S.status = 5; return; }
     S.alpha_max = amax; S.alpha_z = az; S.alpha = amax; S.dphi = dphi;
@@ -989,7 +1046,7 @@ __global__ __launch_bounds__(1024) void ipm_direction_kernel(IpmDev D) {
     return;
   }
   double amax, az, dphi, bad;
-  newton_step(D, bi, sol, D.dv, D.dlam, D.dzL, D.dzU, mu, tau, sh, &amax, &az, &dphi, &bad);
+  if (!newton_step(D, bi, sol, D.dv, D.dlam, D.dzL, D.dzU, mu, tau, sh, &amax, &az, &dphi, &bad)) return;
   if (t != 0) return;
   if (bad != 0) { S.status = 5; return; }
   S.alpha_max = amax; S.alpha_z = az; S.alpha = amax; S.dphi = dphi;
@@ -1026,13 +1083,14 @@ __global__ void ipm_soc_rhs_kernel(IpmDev D) {
 }
 __global__ __launch_bounds__(1024) void ipm_soc_direction_kernel(IpmDev D) {
   __shared__ double sh[16];
-  const int bi = blockIdx.x;
+  const int bi = blockIdx.y;
   IpmInst& S = D.inst[bi];
   const int go = S.status == 0 && S.soc_req;
+  const double mu = S.mu, tau = S.tau;
   __syncthreads();
   if (!go) return;
   double amax, az, dphi, bad;
-  newton_step(D, bi, D.rhs + size_t(bi) * D.Nt, D.dv2, D.dlam2, D.dzL2, D.dzU2, S.mu, S.tau, sh, &amax, &az, &dphi, &bad);
+  if (!newton_step(D, bi, D.rhs + size_t(bi) * D.Nt, D.dv2, D.dlam2, D.dzL2, D.dzU2, mu, tau, sh, &amax, &az, &dphi, &bad)) return;
   if (threadIdx.x != 0) return;
   S.soc_req = 0;
   if (bad != 0) { S.soc_on = 0; S.alpha = 0.5 * S.alpha; S.ls += 1; return; }   // no usable correction: back to the plain backtracking
@@ -1049,9 +1107,11 @@ __global__ void ipm_trial_kernel(IpmDev D) {
   const size_t o = size_t(bi) * D.nv + i;
   D.xt[size_t(bi) * D.n + i] = S.soc_on ? D.v[o] + S.alpha_soc * D.dv2[o] : D.v[o] + S.alpha * D.dv[o];
 }
+// (several workgroups per instance when a few large instances run, vec_combine: the logarithms of 74 k unknowns kept one
+// workgroup's issue slots busy for 100 us on the metric problem)
 __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   __shared__ double sh[16];
-  const int bi = blockIdx.x, t = threadIdx.x;
+  const int bi = blockIdx.y, t = threadIdx.x, i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   IpmInst& S = D.inst[bi];
   const int go = S.status == 0 && !S.accepted, mode = S.mode, soc = S.soc_on;
   const double a = soc ? S.alpha_soc : S.alpha;
@@ -1062,7 +1122,7 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   double th = 0.0, ln = 0.0, bad = 0.0, qd = 0.0, spn = 0.0, lnpn = 0.0;
   const bool resto = mode == 2;
   #pragma unroll 4
-  for (int i = t; i < D.nv; i += blockDim.x) {
+  for (int i = i0; i < D.nv; i += stride) {
     const double l = D.vl[o + i], u = D.vu[o + i], vi = D.v[o + i], di = dvp[o + i];   // loads ahead of the branch: the unrolled
     if (l == u) continue;                                                                 // iterations keep 16 of them in flight
     const double vt = vi + a * di;
@@ -1071,7 +1131,7 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
     if (resto) { const double dd = vt - D.vR[o + i]; qd += D.dr2[o + i] * dd * dd; }
   }
   #pragma unroll 4
-  for (int r = t; r < D.m; r += blockDim.x) {
+  for (int r = i0; r < D.m; r += stride) {
     const int s = D.row_slack[r];
     const double gr = D.gt[size_t(bi) * D.sg + r];
     double cr = s < 0 ? gr - D.gl[r] : gr - (D.v[o + D.n + s] + a * dvp[o + D.n + s]);
@@ -1087,6 +1147,12 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   }
   th = block_red(th, 0, sh); ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh);
   if (resto) { qd = block_red(qd, 0, sh); spn = block_red(spn, 0, sh); lnpn = block_red(lnpn, 0, sh); }
+  {
+    double vals[6] = {th, ln, bad, qd, spn, lnpn};
+    const int kind[6] = {0, 0, 1, 0, 0, 0};
+    if (!vec_combine(D, bi, vals, kind)) return;
+    th = vals[0]; ln = vals[1]; bad = vals[2]; qd = vals[3]; spn = vals[4]; lnpn = vals[5];
+  }
   const IpmOpts& op = D.o;
   // is the trial point dominated by a filter entry?  (every thread holds the reduced sums; the entries — hundreds on a long
   // Delta-III solve — are dealt to the threads instead of being walked by thread 0)
@@ -1171,10 +1237,13 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
 
 // ------------------------------------------------------------------------------------------------ step
 __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
-  const int bi = blockIdx.x, t = threadIdx.x;
+  const int bi = blockIdx.y, t = threadIdx.x, i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   IpmInst& S = D.inst[bi];
-  // every thread reads the instance's verdicts BEFORE thread 0 changes any of them (a late wave must not see
-  // enter_resto already cleared, or mode already switched, and skip its slice)
+  // every thread reads the instance's verdicts BEFORE anybody changes any of them (a late wave must not see enter_resto already
+  // cleared, or mode already switched, and skip its slice): the record is only written by thread 0 of the LAST workgroup of the
+  // instance to get here (vec_combine with nothing to combine: the arrival ticket alone)
+  double none[1] = {0.0};
+  const int none_kind[1] = {0};
   const int s_status = S.status, s_enter = S.enter_resto, s_accepted = S.accepted, s_mode = S.mode, s_skip = S.skip_update, s_soc = S.use_soc;
   const double s_alpha = s_soc ? S.alpha_soc : S.alpha, s_alpha_z = s_soc ? S.az_soc : S.alpha_z, s_mu = S.mu, s_mu_r = S.mu_r, s_cinf = S.cinf;
   __syncthreads();
@@ -1182,17 +1251,19 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   const size_t o = size_t(bi) * D.nv, om = size_t(bi) * D.m;
   const double ks = D.o.kappa_sigma;
   if (s_skip) {           // this pass only replaced lambda (least-squares multipliers after the restoration, or recalc_y)
+    if (!vec_combine(D, bi, none, none_kind)) return;
     if (t == 0) { if (s_skip == 1) S.n_resto += 1; else if (s_skip == 2) S.n_recalc += 1; S.skip_update = 0; }
     return;
   }
   if (s_enter == 2) {     // recalc_y: the next pass computes least-squares multipliers at this point, nothing else
+    if (!vec_combine(D, bi, none, none_kind)) return;
     if (t == 0) { S.mode = 3; S.enter_resto = 0; S.skip_update = -1; }
     return;
   }
   if (s_enter) {          // the line search gave up at an infeasible point: start the restoration phase from it
     const double rho = D.o.resto_rho, mu_r = fmax(s_mu, s_cinf);
     #pragma unroll 4
-    for (int i = t; i < D.nv; i += blockDim.x) {
+    for (int i = i0; i < D.nv; i += stride) {
       const double vi = D.v[o + i], sc = fmax(1.0, fabs(vi));
       D.vR[o + i] = vi;
       D.dr2[o + i] = 1.0 / (sc * sc);
@@ -1200,13 +1271,14 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
       D.zU[o + i] = fmin(rho, D.zU[o + i]);
     }
     #pragma unroll 4
-    for (int r = t; r < D.m; r += blockDim.x) {     // (33), (34): the p, n that minimise the restoration's barrier objective at v_R
+    for (int r = i0; r < D.m; r += stride) {        // (33), (34): the p, n that minimise the restoration's barrier objective at v_R
       const double c = D.c[om + r], h2 = (mu_r - rho * c) / (2.0 * rho);
       const double nn = h2 + sqrt(h2 * h2 + mu_r * c / (2.0 * rho)), pp = c + nn;
       D.nn[om + r] = nn; D.pp[om + r] = pp;
       D.zp[om + r] = mu_r / pp; D.zn[om + r] = mu_r / nn;
       D.lam[om + r] = 0.0;
     }
+    if (!vec_combine(D, bi, none, none_kind)) return;
     if (t == 0) {
       if (S.nfilt < IPM_FMAX) {
         double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
@@ -1222,7 +1294,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   if (s_mode == 2) {
     const double a = s_alpha, az = s_alpha_z, mu = s_mu_r;
     #pragma unroll 4
-    for (int i = t; i < D.nv; i += blockDim.x) {
+    for (int i = i0; i < D.nv; i += stride) {
       const double l = D.vl[o + i], u = D.vu[o + i];
       if (l == u) continue;
       const double vi = D.v[o + i] + a * D.dv[o + i];
@@ -1231,13 +1303,14 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
       if (u < IPM_INF) D.zU[o + i] = reset16(D.zU[o + i] + az * D.dzU[o + i], u - vi, mu, ks);
     }
     #pragma unroll 4
-    for (int r = t; r < D.m; r += blockDim.x) {
+    for (int r = i0; r < D.m; r += stride) {
       const double pp = D.pp[om + r] + a * D.dpp[om + r], nn = D.nn[om + r] + a * D.dnn[om + r];
       D.pp[om + r] = pp; D.nn[om + r] = nn;
       D.zp[om + r] = reset16(D.zp[om + r] + az * D.dzp[om + r], pp, mu, ks);
       D.zn[om + r] = reset16(D.zn[om + r] + az * D.dzn[om + r], nn, mu, ks);
       D.lam[om + r] += a * D.dlam[om + r];
     }
+    if (!vec_combine(D, bi, none, none_kind)) return;
     if (t == 0) {
       if (!S.armijo && S.nrfilt < IPM_FMAX) {
         double* F = D.rfilt + size_t(bi) * 2 * IPM_FMAX;
@@ -1257,7 +1330,7 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
   const double a = s_alpha, az = s_alpha_z, mu = s_mu;
   const double *dv = s_soc ? D.dv2 : D.dv, *dlam = s_soc ? D.dlam2 : D.dlam, *dzL = s_soc ? D.dzL2 : D.dzL, *dzU = s_soc ? D.dzU2 : D.dzU;
   #pragma unroll 4
-  for (int i = t; i < D.nv; i += blockDim.x) {
+  for (int i = i0; i < D.nv; i += stride) {
     const double l = D.vl[o + i], u = D.vu[o + i], v0 = D.v[o + i], di = dv[o + i];
     const double zl = D.zL[o + i], zu = D.zU[o + i], dl = dzL[o + i], du = dzU[o + i];        // loads ahead of the branch
     if (l == u) continue;
@@ -1267,7 +1340,8 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
     if (u < IPM_INF) D.zU[o + i] = reset16(zu + az * du, u - vi, mu, ks);
   }
   #pragma unroll 4
-  for (int r = t; r < D.m; r += blockDim.x) D.lam[om + r] += a * dlam[om + r];
+  for (int r = i0; r < D.m; r += stride) D.lam[om + r] += a * dlam[om + r];
+  if (!vec_combine(D, bi, none, none_kind)) return;
   if (t == 0) {
     if (!S.armijo && S.nfilt < IPM_FMAX) {       // (22)
       double* F = D.filt + size_t(bi) * 2 * IPM_FMAX;
@@ -1288,6 +1362,10 @@ __global__ __launch_bounds__(1024) void ipm_update_kernel(IpmDev D) {
 // threads per instance of the one-workgroup-per-instance vector kernels: a few large instances (the metric problem: n = 41 k)
 // get 16 waves each, a sweep of many small ones 4
 static unsigned vec_threads(const IpmDev& D) { return D.B <= 32 && D.nv >= 4096 ? 1024u : 256u; }
+// workgroups per instance of the vector kernels that can split an instance (ipm_accept_kernel)
+static unsigned vec_blocks(const IpmDev& D) {
+  return D.B <= 32 && D.nv >= 4096 ? unsigned(std::min(IPM_VEC_BLOCKS, (std::max(D.nv, D.m) + 1023) / 1024)) : 1u;
+}
 void ipm_launch_init(const IpmDev& D, const double* d_x0, hipStream_t st) {
   hipLaunchKernelGGL(ipm_init_kernel, dim3(unsigned(D.B)), dim3(256), 0, st, D, d_x0);
 }
@@ -1300,7 +1378,7 @@ void ipm_launch_pack_x(const IpmDev& D, hipStream_t st) {
 void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
   const int tb = (D.nv + 255) / 256;
   hipLaunchKernelGGL(ipm_jt_lambda_kernel, dim3(unsigned(tb + D.n_long), unsigned(D.B)), dim3(256), 0, st, D, tb);
-  hipLaunchKernelGGL(ipm_residual_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
+  hipLaunchKernelGGL(ipm_residual_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
   const int assemble_blocks = std::max(1, std::min(D.B <= 32 ? 2048 : 64, (nnz_max + 255) / 256));   // a few large instances: the whole chip
@@ -1312,23 +1390,23 @@ void ipm_launch_inertia(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_inertia_kernel, dim3(unsigned((D.B + 255) / 256)), dim3(256), 0, st, D);
 }
 void ipm_launch_direction(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_direction_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
+  hipLaunchKernelGGL(ipm_direction_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_trial(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_trial_kernel, dim3(unsigned((D.n + 255) / 256), unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_accept(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_accept_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
+  hipLaunchKernelGGL(ipm_accept_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_update(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_update_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
+  hipLaunchKernelGGL(ipm_update_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st) {
   const int blocks = std::max(1, std::min(64, (std::max(D.nv, D.m) + 255) / 256));
   hipLaunchKernelGGL(ipm_soc_rhs_kernel, dim3(unsigned(blocks), unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_soc_direction_kernel, dim3(unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
+  hipLaunchKernelGGL(ipm_soc_direction_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
   if (p.nd) return p.max_factor_lds;
