@@ -745,6 +745,31 @@ def test_delta_iii_mesh_ladder_with_the_recorded_retry(built):
 
 
 @pytest.mark.gpu
+def test_large_instances_in_a_batch_use_several_workgroups_each(built):
+    """A few large instances (n >= 4096, at most 32 of them): the vector kernels run several workgroups per instance and the last
+    one to arrive combines their partial sums in a fixed order (vec_combine).  Three instances from the same start, one of them
+    perturbed: the unperturbed two must agree bit for bit with each other and with a one-instance solve."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = problems.launch(16, 8)
+    one = NLPEngine(prob, _exact(), device=0)
+    x0 = one.get_starting_point()
+    assert one.n >= 4096
+    ipm1 = BatchedIPM(one, max_iter=60)
+    r1 = ipm1.solve(x0[None, :])
+    ipm1.close()
+    one.close()
+    eng = NLPEngine(prob, _exact(), n_instances=3, device=0)
+    ipm = BatchedIPM(eng, max_iter=60)
+    xs = np.stack([x0, x0 * (1 + 1e-3 * np.random.RandomState(0).uniform(-1, 1, x0.size)), x0])
+    r = ipm.solve(xs)
+    assert np.array_equal(r["x"][0], r["x"][2]) and np.array_equal(r["x"][0], r1["x"][0])
+    assert r["iterations"][0] == r["iterations"][2] == r1["iterations"][0] == 60 and r["obj"][0] == r1["obj"][0]
+    assert not np.array_equal(r["x"][0], r["x"][1])
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_device_solves_the_metric_problem(built):
     """BASELINE's metric problem at full size — Delta-III, 4 phases x 64 intervals x 16 LGR points, n = 40 996, KKT order
     73 801 — from lpopc's default guess (example/launch/Launch.cpp:200-457), on the device: nested dissection over the 256 mesh
