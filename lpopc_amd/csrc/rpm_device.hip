@@ -247,7 +247,7 @@ int device_init(Engine& e, int device_id) {
   HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_obj), B * sizeof(double)));
   HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_partial), B * e.P * sizeof(double)));
   HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d->d_lambda), B * e.m * sizeof(double)));
-  HIP_TRY(e, hipMemset(d->d_grad, 0, B * e.n * sizeof(double)));
+  HIP_TRY(e, hipMemsetAsync(d->d_grad, 0, B * e.n * sizeof(double), d->stream));   // ordered with the kernels that follow on this stream
   KParams& k = d->kp;
   k.phases = d->d_phases;
   k.tiles = d->d_tiles;

@@ -120,7 +120,9 @@ static int delta_setup(Engine& e) {
   // the counter lives in HBM: an atomic per stored run into HOST memory is a PCIe round trip each (337 of them made a
   // delivery take 340 us instead of 40)
   HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&h.d_sent), sizeof(unsigned)));
-  HIP_TRY(e, hipMemset(h.d_sent, 0, sizeof(unsigned)));
+  // on the engine's stream: a null-stream hipMemset is not ordered against a non-blocking stream, and returned before
+  // the fill ran -- it then zeroed the counter in the middle of the first delivery (seen once: 1618 of 1665 runs)
+  HIP_TRY(e, hipMemsetAsync(h.d_sent, 0, sizeof(unsigned), e.dev->stream));
   // 64 sample positions spread over the owned runs (first and last element included)
   const int NS = 64;
   h.sample_idx.clear();

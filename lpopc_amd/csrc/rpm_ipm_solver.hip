@@ -162,7 +162,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     A_(ipm_alloc(h, &D.dv2, B * p.nv)); A_(ipm_alloc(h, &D.dzL2, B * p.nv)); A_(ipm_alloc(h, &D.dzU2, B * p.nv));
     A_(ipm_alloc(h, &D.rfilt, B * 2 * IPM_FMAX));
     A_(ipm_alloc(h, &D.part, B * IPM_VEC_BLOCKS * IPM_VEC_PART)); A_(ipm_alloc(h, &D.tick, B));
-    if (hipMemset(D.tick, 0, B * sizeof(int)) != hipSuccess) { h->err = "hipMemset"; return fail(RPM_E_DEVICE); }
+    // on the engine's (non-blocking) stream, where the kernels that take tickets run: a null-stream fill is not ordered against it
+    if (hipMemsetAsync(D.tick, 0, B * sizeof(int), static_cast<hipStream_t>(dev_stream(h->eng->e))) != hipSuccess) { h->err = "hipMemset"; return fail(RPM_E_DEVICE); }
   }
   {   // factorisation sub-problems: the whole band + border matrix, or the interval blocks followed by the separator system
     std::vector<KktSub> subs;
