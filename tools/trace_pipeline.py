@@ -1,5 +1,5 @@
 """Timeline of rpm_tile_pl_kernel's first two tiles per workgroup (diagnostic build, perf exploration only).
-Run on the GPU box:  python tools/trace_pipeline.py [instances]"""
+Run on the GPU box:  python tools/trace_pipeline.py [instances [launch|quadrotor]]"""
 import os
 import sys
 
@@ -15,7 +15,7 @@ from lpopc_amd import problems
 from lpopc_amd.engine import NLPEngine
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-prob = problems.config("launch")
+prob = problems.quadrotor(8, 8) if len(sys.argv) > 2 and sys.argv[2] == "quadrotor" else problems.config("launch")
 eng = NLPEngine(prob, n_instances=B, device=0)
 eng.set_option("pipeline", 1)
 xl, xu, _, _ = eng.get_bounds_info()
@@ -31,7 +31,8 @@ torch.cuda.synchronize()
 assert eng.get_option("pipeline_active") == 1
 eng.close()
 t = np.fromfile(out, dtype=np.uint64)
-G = 512
+G = min(512, t.size // 64)
+G = int(os.environ.get("TRACE_HALVES", G))
 t = t[:G * 64].reshape(G, 2, 32).astype(np.float64) * 0.01
 t00 = t[:, 0, 31].min()
 
