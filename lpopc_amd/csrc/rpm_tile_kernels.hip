@@ -751,6 +751,9 @@ struct PlShape { int NH, RG, NDMA, NST; };
 #ifndef RPM_PL_BIG_NST
 #define RPM_PL_BIG_NST 0   // shape for more than 12 roles: 0 barrier per tile, -1 counters in LDS, n > 0 counters and n store waves (see the kernel)
 #endif
+#ifndef RPM_PL_ALL_STAGE_FIRST
+#define RPM_PL_ALL_STAGE_FIRST 0   // experiment: every wave of a half issues a share of its first tile's loads
+#endif
 #ifndef RPM_PL_BIG_NDMA
 #define RPM_PL_BIG_NDMA 2
 #endif
@@ -846,6 +849,53 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
 #endif
   if (tid == 0) { RPM_PTRC(0, 31); }
 
+  // A tile's inputs go from global memory straight into an LDS staging buffer (global_load_lds_dwordx4, 16 B per lane, no
+  // VGPR round trip): a wave only issues them.  Every run is dealt chunk-wise to the NP waves that stage the tile (this
+  // one is `part`), the first chunk of successive runs to successive waves.
+  // The addresses of a tile's runs come from its record.  In steady state that record is already in LDS (each
+  // staging buffer also carries the record of the tile AFTER its own), so issuing the next tile's loads never waits
+  // for global memory; only the first tile of a workgroup reads its record from HBM.
+  struct TileRuns { int k0, cnt, span0, span_len, drow0, drow_len, N, x_state0, x_control0, x_t0, node0, c_src0, c_cnt; };
+  auto runs_of = [&](auto p) {   // p: the record as ints, in LDS or (first tile) in the constant address space
+    TileRuns r;
+#define RPM_RF(f) r.f = __builtin_amdgcn_readfirstlane(p[offsetof(TileDev, f) / 4])
+    RPM_RF(k0); RPM_RF(cnt); RPM_RF(span0); RPM_RF(span_len); RPM_RF(drow0); RPM_RF(drow_len); RPM_RF(N);
+    RPM_RF(x_state0); RPM_RF(x_control0); RPM_RF(x_t0); RPM_RF(node0); RPM_RF(c_src0); RPM_RF(c_cnt);
+#undef RPM_RF
+    return r;
+  };
+  auto stage = [&](auto np_c, int part, int lane, int item, double* buf, const TileRuns tl) {
+    constexpr int NP = decltype(np_c)::value;
+    const int inst = item / nt, tidx = item - inst * nt;
+    const double* __restrict__ x = xall + size_t(inst) * K.n;
+    static_assert(NREC % 2 == 0 && sizeof(TileDev) % 8 == 0, "the tile record is copied as doubles");
+    int rot = 0;
+    auto run = [&](const double* gsrc, double* ldst, int len) {
+      pl_dma_run<NP>(gsrc, ldst, len, lane, (part + NP - (rot++ % NP)) % NP);
+    };
+    if (part == 0 && lane == 0) reinterpret_cast<int*>(buf)[NREC] = inst;   // before the direct loads: an LDS write after them waits for them
+    run(reinterpret_cast<const double*>(K.tiles + tidx), buf, NREC / 2);
+    if (item + G < W) {   // the record of this workgroup's tile after this one
+      const int item2 = item + G, inst2 = item2 / nt;
+      run(reinterpret_cast<const double*>(K.tiles + (item2 - inst2 * nt)), buf + PL_REC / 2, NREC / 2);
+    }
+    run(x + tl.x_t0, buf + S_TT, 2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) run(x + tl.x_state0 + i * (tl.N + 1) + tl.span0, buf + S_X + i * K.max_span, tl.span_len);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) run(x + tl.x_control0 + j * tl.N + tl.k0, buf + S_U + j * T, tl.cnt);
+    run(K.points + tl.node0 + tl.k0, buf + S_TAU, tl.cnt);
+    if (WJ) run(K.diag + tl.node0 + tl.k0, buf + S_DG, tl.cnt);
+    run(reinterpret_cast<const double*>(K.nodes + tl.node0 + tl.k0), buf + S_ND, 2 * tl.cnt);
+    if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
+    if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
+  };
+  // Experiment RPM_PL_ALL_STAGE_FIRST: the FIRST tile of a half staged by all its waves — the compute waves have nothing else
+  // to do until it is there, and two DMA waves take 2.5-2.8 us to issue a tile's loads (of 4 us from the first wave's start
+  // to the first barrier, tools/trace_pipeline.py).  Bit-identical; measured 50.4 / 104.0 / 28.7 us against 50.7 / 104.4 /
+  // 27.6 (1024 quadrotor instances, 64 and 16 iterates of the metric problem): nothing, so it is off.  Barrier scheme only.
+  constexpr int NP0 = (FS || !RPM_PL_ALL_STAGE_FIRST) ? NDMA : RG + NDMA;
+  const auto first_runs = [&]() { return runs_of((const __attribute__((address_space(4))) int*)(K.tiles + (w - (w / nt) * nt))); };
   if (NSW > 0 && tid >= NTHR + 64 * NDMA) {
     // ---------------- store waves: take finished Jacobian columns out of the compute waves' slots (round robin) ----------------
     const int lane = tid & 63;
@@ -930,50 +980,14 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
     // The DMA waves' instruction stream is long and scalar; sharing a SIMD with three busy compute waves it would get
     // a quarter of the issue slots (4 us to issue one tile's loads).  They run at raised priority instead.
     __builtin_amdgcn_s_setprio(3);
-    // The next tile's inputs go from global memory straight into the other LDS staging buffer
-    // (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip): the DMA wave only issues them.
-    // every run is dealt chunk-wise to the NDMA waves, the first chunk of successive runs to successive waves
-    int rot = 0;
-    auto run = [&](const double* gsrc, double* ldst, int len) {
-      pl_dma_run<NDMA>(gsrc, ldst, len, lane, (dw + NDMA - (rot++ & (NDMA - 1))) & (NDMA - 1));
-    };
-    // The addresses of a tile's runs come from its record.  In steady state that record is already in LDS (each
-    // staging buffer also carries the record of the tile AFTER its own), so issuing the next tile's loads never waits
-    // for global memory; only the first tile of a workgroup reads its record from HBM.
-    struct TileRuns { int k0, cnt, span0, span_len, drow0, drow_len, N, x_state0, x_control0, x_t0, node0, c_src0, c_cnt; };
-    auto runs_of = [&](auto p) {   // p: the record as ints, in LDS or (first tile) in the constant address space
-      TileRuns r;
-#define RPM_RF(f) r.f = __builtin_amdgcn_readfirstlane(p[offsetof(TileDev, f) / 4])
-      RPM_RF(k0); RPM_RF(cnt); RPM_RF(span0); RPM_RF(span_len); RPM_RF(drow0); RPM_RF(drow_len); RPM_RF(N);
-      RPM_RF(x_state0); RPM_RF(x_control0); RPM_RF(x_t0); RPM_RF(node0); RPM_RF(c_src0); RPM_RF(c_cnt);
-#undef RPM_RF
-      return r;
-    };
-    auto stage = [&](int item, double* buf, const TileRuns tl) {
-      const int inst = item / nt, tidx = item - inst * nt;
-      const double* __restrict__ x = xall + size_t(inst) * K.n;
-      static_assert(NREC % 2 == 0 && sizeof(TileDev) % 8 == 0, "the tile record is copied as doubles");
-      rot = 0;
-      if (dw == 0 && lane == 0) reinterpret_cast<int*>(buf)[NREC] = inst;   // before the direct loads: an LDS write after them waits for them
-      run(reinterpret_cast<const double*>(K.tiles + tidx), buf, NREC / 2);
-      if (item + G < W) {   // the record of this workgroup's tile after this one
-        const int item2 = item + G, inst2 = item2 / nt;
-        run(reinterpret_cast<const double*>(K.tiles + (item2 - inst2 * nt)), buf + PL_REC / 2, NREC / 2);
-      }
-      run(x + tl.x_t0, buf + S_TT, 2);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) run(x + tl.x_state0 + i * (tl.N + 1) + tl.span0, buf + S_X + i * K.max_span, tl.span_len);
-#pragma unroll
-      for (int j = 0; j < NU; ++j) run(x + tl.x_control0 + j * tl.N + tl.k0, buf + S_U + j * T, tl.cnt);
-      run(K.points + tl.node0 + tl.k0, buf + S_TAU, tl.cnt);
-      if (WJ) run(K.diag + tl.node0 + tl.k0, buf + S_DG, tl.cnt);
-      run(reinterpret_cast<const double*>(K.nodes + tl.node0 + tl.k0), buf + S_ND, 2 * tl.cnt);
-      if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
-      if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
-    };
     if (!FS && dw == 0 && lane == 0) { *fb_ready = 0; *dx_ready = 0; }
-    if (n_iter > 0)   // the tile table never changes: constant address space, i.e. scalar loads for the first record
-      stage(w, lds, runs_of((const __attribute__((address_space(4))) int*)(K.tiles + (w - (w / nt) * nt))));
+    // the tile table never changes: constant address space, i.e. scalar loads for the first record
+    {
+      const auto r0 = first_runs();
+      RPM_PTRC(0, 19);
+      if (n_iter > 0) stage(std::integral_constant<int, NP0>{}, NP0 == NDMA ? dw : RG + dw, lane, w, lds, r0);
+      RPM_PTRC(0, 20);
+    }
     for (int j = 0; j < (FS ? n_iter : n_iter_wg); ++j) {
       const double* cur = lds + (j & 1) * S_SIZE;
       double* nxt = lds + ((j + 1) & 1) * S_SIZE;
@@ -1043,7 +1057,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
         // are done with tile j-1 may already have finished tile j, and a single running count would take their second
         // arrival for a slower wave's first; tile j+1 is not staged yet, so the counter of j-1's parity is exact here
         if constexpr (FS) { if (j >= 1) PL_SPIN(PL_LD(SY + 1 + ((j - 1) & 1)) >= (RG + NCW) * ((j - 1) / 2 + 1)); }
-        stage(w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
+        stage(std::integral_constant<int, NDMA>{}, dw, lane, w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
       }
       RPM_PTRC(j, 18);
     }
@@ -1064,6 +1078,9 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
 #endif
   // ---------------- compute waves: the role loop of rpm_tile_rl_kernel out of the staged buffer ----------------
   const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
+  if constexpr (NP0 != NDMA) {
+    if (n_iter > 0) stage(std::integral_constant<int, NP0>{}, grp, kk, w, lds, first_runs());
+  }
   int n_emit = 0;   // Jacobian columns this wave has handed to the store wave
   int* const my_full = SY + 4 + grp;
   int* const my_done = SY + 4 + RG + grp;
@@ -1077,6 +1094,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
     if constexpr (FS) {
       PL_SPIN(PL_LD(SY) >= NDMA * (jt + 1));
     } else {
+      if (NP0 != NDMA && jt == 0) __builtin_amdgcn_s_waitcnt(0);   // this wave's share of the first tile's loads has landed
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (jt >= n_iter) continue;   // the other half still has a tile: keep the barrier count

@@ -42,6 +42,9 @@ def stat(name, a):
 
 
 stat("kernel start (rel. first)", t[:, 0, 31] - t00)
+stat("prologue: first record read (start -> runs known)", t[:, 0, 19] - t[:, 0, 31])
+stat("prologue: first tile's loads issued", t[:, 0, 20] - t[:, 0, 19])
+stat("prologue: loads issued -> A passed", t[:, 0, 0] - t[:, 0, 20])
 for j in (0, 1):
     print("tile", j, " A passed at %.2f" % (t[:, j, 0] - t00).mean())
     for wv in range(4):
