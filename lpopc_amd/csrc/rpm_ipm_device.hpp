@@ -71,6 +71,11 @@ struct IpmDev {
   const int *pos, *row_slack, *slack_row, *jac_dst, *hes_dst, *diag_dst, *slk_dst, *jt_ptr, *jt_ent, *jt_row;
   const int *hg_ptr, *hg_src, *hg_dst;   // Hessian entries grouped by storage slot
   int n_hg;
+  // every structural slot of the KKT storage in ascending order (ipm_fill_kernel): as_ki = kind << 28 | index (kind 0 Hessian
+  // slot hg i, 1 Jacobian entry k, 2 slack s, 3 diagonal of variable i — as_hg: the Hessian slot that shares it or -1 —,
+  // 4 diagonal of constraint r); as_ptr[c] = first entry at or beyond chunk c (IPM_FILL_CHUNK doubles); as_nchunk 0 = not built
+  const int *as_dst, *as_ki, *as_hg, *as_ptr;
+  int as_nchunk;
   const int* long_cols;                  // Jacobian columns of more than 256 entries (a workgroup each in ipm_jt_lambda_kernel)
   int n_long;
   const double *gl, *gu;
@@ -105,6 +110,7 @@ struct IpmDev {
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
 };
 
+constexpr int IPM_FILL_CHUNK = 2048;   // doubles of KKT storage one workgroup of ipm_fill_kernel zeroes and fills at a time
 constexpr int IPM_VEC_BLOCKS = 64;   // most workgroups per instance of a vector kernel
 constexpr int IPM_VEC_PART = 24;     // doubles of partial results per workgroup
 constexpr int IPM_MT = 8;   // most 16-row tiles per wave of the factorisation: block columns of up to 4 x 8 x 16 = 512 rows

@@ -460,6 +460,98 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   }
 }
 
+// ipm_zero_kernel + ipm_assemble_kernel in one pass over the storage, by destination: a workgroup builds a chunk of the
+// storage in LDS (zeros, then the chunk's structural slots, as_* tables in ascending order) and writes it out in full lines,
+// so every line of the storage leaves the chip once per refactorisation instead of being zeroed, fetched again for a
+// scattered read-modify-write and written a second time (1024-instance quadrotor sweep: 0.59 + 0.72 ms per iteration for the
+// two kernels).  Same values, bit for bit: a slot that took two atomic adds onto zero (Hessian sum, diagonal term) gets their sum.
+__global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
+  __shared__ double buf[IPM_FILL_CHUNK];
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || !S.refactor) return;
+  double* K = D.K + size_t(bi) * D.kstride;
+  const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
+  const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv;
+  double* rhs = D.rhs + size_t(bi) * D.Nt;
+  const int mode = S.mode;
+  const double mu = mode == 2 ? S.mu_r : S.mu;
+  const double delta_w = S.delta_w, zeta = S.zeta;
+  const int tid = threadIdx.x;
+  // the value of structural slot e (and, for a diagonal slot, the right-hand side entry that goes with it)
+  auto value_of = [&](int e) -> double {
+    const int ki = D.as_ki[e], kind = ki >> 28, idx = ki & 0x0fffffff;
+    if (kind == 1) return D.jac[size_t(bi) * D.sv + idx];
+    if (kind == 2) return -1.0;
+    if (kind == 4) {   // diagonal of constraint row idx
+      double k22 = -D.o.delta_c, rr = 0.0;
+      if (mode == 0) rr = -D.c[size_t(bi) * D.m + idx];
+      else if (mode == 2) {
+        const size_t q = size_t(bi) * D.m + idx;
+        const double pp = D.pp[q], nn = D.nn[q], sp = D.zp[q] / pp, sn = D.zn[q] / nn, lam = D.lam[q];
+        const double rp = D.o.resto_rho - lam - mu / pp, rn = D.o.resto_rho + lam - mu / nn;
+        k22 = -(1.0 / sp + 1.0 / sn);
+        rr = -(D.c[q] - pp + nn) - rp / sp + rn / sn;
+      }
+      rhs[D.pos[D.nv + idx]] = rr;
+      return k22;
+    }
+    // 0: a Hessian slot; 3: the diagonal of variable idx (with the Hessian slot that shares it)
+    const int hgi = kind == 0 ? idx : D.as_hg[e];
+    double acc = 0.0;
+    if (mode == 0 && hgi >= 0)
+      for (int j = D.hg_ptr[hgi]; j < D.hg_ptr[hgi + 1]; ++j) acc += D.hess[size_t(bi) * D.nnz_h + D.hg_src[j]];
+    if (kind == 0) return 0.0 + acc;   // as the add onto the zeroed slot gave it (a sum of -0.0 becomes +0.0)
+    const int i = idx;
+    const double l = vl[i], u = vu[i];
+    double diag = 1.0, r = 0.0;
+    if (l != u) {
+      if (mode == 3) {
+        diag = 1.0 + delta_w;
+        r = (i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0) - zL[i] + zU[i];
+      } else {
+        diag = delta_w;
+        r = D.glag[size_t(bi) * D.nv + i];
+        if (mode == 2) {
+          const double w2 = zeta * D.dr2[size_t(bi) * D.nv + i];
+          diag += w2;
+          r += w2 * (v[i] - D.vR[size_t(bi) * D.nv + i]);
+        }
+        const double cap = D.o.sigma_cap > 0 ? D.o.sigma_cap : 1e300;
+        if (l > -IPM_INF) { const double d = v[i] - l; diag += fmin(zL[i] / d, cap); r -= mu / d; }
+        if (u < IPM_INF) { const double d = u - v[i]; diag += fmin(zU[i] / d, cap); r += mu / d; }
+      }
+    }
+    rhs[D.pos[i]] = -r;
+    // the two-kernel path adds the two terms onto zero, in either order: acc + diag, exactly
+    return (mode == 0 && hgi >= 0) ? acc + diag : diag;
+  };
+  for (int c = blockIdx.x; c < D.as_nchunk; c += gridDim.x) {
+    const long long lo = (long long)c * IPM_FILL_CHUNK, hi = min(lo + IPM_FILL_CHUNK, D.kstride);
+    const int e0 = D.as_ptr[c], e1 = D.as_ptr[c + 1];
+    // this thread's first slot: its loads are under way while the chunk is zeroed
+    const int ef = e0 + tid;
+    double val_f = 0.0;
+    int off_f = -1;
+    if (ef < e1) { off_f = int(D.as_dst[ef] - lo); val_f = value_of(ef); }
+    double2* b2 = reinterpret_cast<double2*>(buf);
+    for (int i = tid; i < IPM_FILL_CHUNK / 2; i += 256) b2[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    if (off_f >= 0) buf[off_f] = val_f;
+    for (int e = ef + 256; e < e1; e += 256) buf[D.as_dst[e] - lo] = value_of(e);
+    __syncthreads();
+    const int len = int(hi - lo);
+    if ((reinterpret_cast<size_t>(K + lo) & 15) == 0) {
+      double2* K2 = reinterpret_cast<double2*>(K + lo);
+      for (int i = tid; i < (len >> 1); i += 256) K2[i] = b2[i];
+      if ((len & 1) && tid == 0) K[hi - 1] = buf[len - 1];
+    } else {
+      for (int i = tid; i < len; i += 256) K[lo + i] = buf[i];
+    }
+    __syncthreads();   // buf is free for the next chunk
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ band + border LDL^T
 // Storage of one instance: column j holds rows j .. j+b of the band (slot i-j) and the nb border rows (slot b+1+i-Nb).
 // IPM_W columns at a time: the diagonal block is factored in LDS, each panel row is solved by the thread that owns it.
@@ -1381,6 +1473,10 @@ void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_residual_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
+  if (D.as_nchunk > 0) {
+    hipLaunchKernelGGL(ipm_fill_kernel, dim3(unsigned(std::min(D.as_nchunk, 65535)), unsigned(D.B)), dim3(256), 0, st, D);
+    return;
+  }
   const int assemble_blocks = std::max(1, std::min(D.B <= 32 ? 2048 : 64, (nnz_max + 255) / 256));   // a few large instances: the whole chip
   const int zero_blocks = int(std::max<long long>(1, std::min<long long>(256, D.kstride / 2 / 256 + 1)));
   hipLaunchKernelGGL(ipm_zero_kernel, dim3(unsigned(zero_blocks), unsigned(D.B)), dim3(256), 0, st, D);

@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unordered_map>
+#include <vector>
 
 #include "rpm_device_internal.hpp"
 #include "rpm_ipm_device.hpp"
@@ -135,6 +137,43 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc_c(h, &D.jt_ent, p.jt_ent)); A_(ipm_alloc_c(h, &D.jt_row, p.jt_row));
   A_(ipm_alloc_c(h, &D.hg_ptr, p.hg_ptr)); A_(ipm_alloc_c(h, &D.hg_src, p.hg_src)); A_(ipm_alloc_c(h, &D.hg_dst, p.hg_dst));
   D.n_hg = int(p.hg_dst.size());
+  {   // the structural slots in ascending order, for the one-pass fill (ipm_fill_kernel)
+    struct Ent { int dst, ki, hg; };
+    std::vector<Ent> ents;
+    ents.reserve(p.hg_dst.size() + p.jac_dst.size() + p.slk_dst.size() + p.diag_dst.size());
+    std::unordered_map<int, int> var_of_slot;
+    for (int i = 0; i < p.nv; ++i) var_of_slot.emplace(p.diag_dst[size_t(i)], i);
+    std::vector<int> hg_of_var(size_t(p.nv), -1);
+    bool ok = p.hg_dst.size() < (1u << 28) && p.jac_dst.size() < (1u << 28) && p.diag_dst.size() < (1u << 28) && p.storage() < (1ll << 31);
+    for (size_t i = 0; i < p.hg_dst.size(); ++i) {
+      auto it = var_of_slot.find(p.hg_dst[i]);
+      if (it != var_of_slot.end()) hg_of_var[size_t(it->second)] = int(i);
+      else ents.push_back(Ent{p.hg_dst[i], (0 << 28) | int(i), -1});
+    }
+    for (size_t k = 0; k < p.jac_dst.size(); ++k)
+      if (p.jac_dst[k] >= 0) ents.push_back(Ent{p.jac_dst[k], (1 << 28) | int(k), -1});
+    for (size_t s2 = 0; s2 < p.slk_dst.size(); ++s2) ents.push_back(Ent{p.slk_dst[s2], (2 << 28) | int(s2), -1});
+    for (int i = 0; i < p.nv; ++i) ents.push_back(Ent{p.diag_dst[size_t(i)], (3 << 28) | i, hg_of_var[size_t(i)]});
+    for (int r = 0; r < p.m; ++r) ents.push_back(Ent{p.diag_dst[size_t(p.nv + r)], (4 << 28) | r, -1});
+    std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.dst < b.dst; });
+    for (size_t i = 1; i < ents.size() && ok; ++i) ok = ents[i].dst != ents[i - 1].dst;   // two writers of one slot: keep the two-kernel path
+    for (const Ent& en : ents) ok = ok && en.dst >= 0 && en.dst < p.storage();
+    D.as_nchunk = 0;
+    D.as_dst = D.as_ki = D.as_hg = D.as_ptr = nullptr;
+    if (ok && !getenv("RPM_IPM_TWO_PASS_FILL")) {
+      const int nchunk = int((p.storage() + IPM_FILL_CHUNK - 1) / IPM_FILL_CHUNK);
+      std::vector<int> a_dst(ents.size()), a_ki(ents.size()), a_hg(ents.size()), a_ptr(size_t(nchunk) + 1, 0);
+      size_t e2 = 0;
+      for (int c = 0; c <= nchunk; ++c) {
+        while (e2 < ents.size() && ents[e2].dst < (long long)c * IPM_FILL_CHUNK) ++e2;
+        a_ptr[size_t(c)] = int(e2);
+      }
+      a_ptr[size_t(nchunk)] = int(ents.size());
+      for (size_t i = 0; i < ents.size(); ++i) { a_dst[i] = ents[i].dst; a_ki[i] = ents[i].ki; a_hg[i] = ents[i].hg; }
+      A_(ipm_alloc_c(h, &D.as_dst, a_dst)); A_(ipm_alloc_c(h, &D.as_ki, a_ki)); A_(ipm_alloc_c(h, &D.as_hg, a_hg)); A_(ipm_alloc_c(h, &D.as_ptr, a_ptr));
+      D.as_nchunk = nchunk;
+    }
+  }
   {
     std::vector<int> long_cols;
     for (int i = 0; i < p.n; ++i)
