@@ -893,7 +893,9 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
   // Experiment RPM_PL_ALL_STAGE_FIRST: the FIRST tile of a half staged by all its waves — the compute waves have nothing else
   // to do until it is there, and two DMA waves take 2.5-2.8 us to issue a tile's loads (of 4 us from the first wave's start
   // to the first barrier, tools/trace_pipeline.py).  Bit-identical; measured 50.4 / 104.0 / 28.7 us against 50.7 / 104.4 /
-  // 27.6 (1024 quadrotor instances, 64 and 16 iterates of the metric problem): nothing, so it is off.  Barrier scheme only.
+  // 27.6 (1024 quadrotor instances, 64 and 16 iterates of the metric problem): nothing, so it is off — the trace shows why: six waves
+  // issue the same ~30 direct-to-LDS loads in 1.8 us instead of 2.5, and the last of them lands 2.0 us later instead of 0.5; the
+  // CU takes these loads at a fixed rate whoever issues them.  Barrier scheme only.
   constexpr int NP0 = (FS || !RPM_PL_ALL_STAGE_FIRST) ? NDMA : RG + NDMA;
   const auto first_runs = [&]() { return runs_of((const __attribute__((address_space(4))) int*)(K.tiles + (w - (w / nt) * nt))); };
   if (NSW > 0 && tid >= NTHR + 64 * NDMA) {
