@@ -108,6 +108,7 @@ struct IpmDev {
   int n_cg2, n_rg2, n_rs2;
   int n_cg_long, n_cg2_long;             // leading corner-gather destinations with >= 32 sources (a wave each)
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
+  size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
 };
 
 constexpr int IPM_FILL_CHUNK = 2048;   // doubles of KKT storage one workgroup of ipm_fill_kernel zeroes and fills at a time
@@ -131,6 +132,9 @@ void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st);    // its step a
 // factorisation / substitution of every running instance; tiles_per_wave 4 or IPM_MT
 size_t kkt_factor_lds_bytes(const IpmPlan& p);
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes);
+size_t kkt_factor_dense_lds_bytes(int block_rows);
+int kkt_factor_dense_max_block_rows();
+hipError_t kkt_factor_dense_prepare(size_t lds_bytes);
 // factor every running instance that asks for it / solve in place in D.rhs: the band + border matrix, or level 1 ->
 // corner gather -> level 2 and forward -> gather -> level 2 -> scatter -> backward with nested dissection
 void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hipStream_t st);

@@ -864,6 +864,233 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 #endif
 }
 
+// Level 1 of the nested dissection when an interval block is small and (nearly) dense — the quadrotor sweep's are of order 252
+// with a half bandwidth of 200: the whole lower triangle lives in the REGISTERS of one workgroup as 16 x 16 accumulator tiles
+// (tile (I, K), K <= I, transposed like kkt_factor_kernel's: lane l holds columns (l >> 4) + 4 reg of block K for row l & 15 of
+// block I), dealt round robin to 7 waves (at most IPM_DENSE_SLOTS = 22 tiles each: 17 block rows), and the elimination runs
+// right-looking: block column J's diagonal tile is factored by the eighth wave, which holds no tiles (the same register LDL^T
+// with the inverse alongside; its 100-odd registers would not fit beside 22 accumulator tiles),
+// the tiles below it are solved against it (4 matrix products each) and leave L and L D in LDS, every tile to the right takes
+// its rank-16 update from there (4 products).  Nothing is read twice: the left-looking kernel streams the 488 KB of such a
+// block ~12 times from the L2 / Infinity Cache, a 16-column step every 25 us.  Same products in the same order, so the factors
+// are the left-looking kernel's bit for bit.  Partial elimination only (the band part; the border x border corner is handed
+// on as the Schur complement).
+constexpr int IPM_DENSE_SLOTS = 22, IPM_DENSE_TILE_WAVES = 7, IPM_DENSE_LDS_ROW = 18;
+__global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
+                                                                  int n_sub, IpmInst* inst, int* piv) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int W = IPM_W, NWV = IPM_DENSE_TILE_WAVES, MAXS = IPM_DENSE_SLOTS;
+  const int bi = blockIdx.x / n_here, sidx = sub0 + int(blockIdx.x) % n_here, t = threadIdx.x;
+  const IpmInst& S = inst[bi];
+  if (S.status != 0 || !S.refactor) return;
+  const KktSub sub = subs[sidx];
+  const KktGeom G = sub.g;
+  double* K = Kall + size_t(bi) * kstride + sub.koff;
+  const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr, ntl = NTB * (NTB + 1) / 2;
+  extern __shared__ double lds[];
+  double* Dg = lds;                       // W x (W + 1)
+  double* Mi = Dg + W * (W + 1);          // W x W: L11^-1, row-major
+  double* invd = Mi + W * W;              // W
+  // rows of 18 doubles: the 16 lanes that read one column of 16 successive rows then hit 16 different pairs of banks (at 16
+  // doubles per row they share two, and the matrix products starve: 18 us per block column instead of 3)
+  constexpr int BS = IPM_DENSE_LDS_ROW;
+  double* BL = invd + W;                   // NTB x 16 x BS: L of the current block column, by block row
+  double* BY = BL + size_t(NTB) * W * BS;  // the same for L D
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = t & 15, lq = (t & 63) >> 4;
+  auto row0 = [&](int I) { return I < nbb ? W * I : G.Nb + W * (I - nbb); };
+  auto rend = [&](int I) { return I < nbb ? G.Nb : G.Nt; };
+  if (wv == NWV) {
+    // ---------------- the eighth wave holds no tiles: it factors the diagonal blocks (its registers are free for that) ----------------
+    __builtin_amdgcn_s_setprio(3);   // the chain of diagonal blocks is the critical path: this wave goes first on its SIMD
+    int npos = 0, nneg = 0, nbad = 0;
+#ifdef IPM_TIMING
+    long long tq[4] = {0, 0, 0, 0}, tp = wall_clock64();
+#define IPM_DTICK(i) do { const long long n_ = wall_clock64(); tq[i] += n_ - tp; tp = n_; } while (0)
+#else
+#define IPM_DTICK(i)
+#endif
+    for (int J = 0; J < nbb; ++J) {
+      const int J0 = W * J, w = min(W, G.Nb - J0);
+      __syncthreads();          // B1: the owner of tile (J, J) has put it into Dg
+      IPM_DTICK(0);
+      double row[W], inv[W];    // lane (l & 15) = row of the block and of L11^-1 (kkt_factor_kernel's elimination, word for word)
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        row[c] = (lr < w && c <= lr) ? Dg[lr * (W + 1) + c] : (c == lr ? 1.0 : 0.0);
+        inv[c] = c == lr ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const double dk = readlane_d(row[k], k);
+        double ajk[W], mkj[W];
+#pragma unroll
+        for (int j = k + 1; j < W; ++j) ajk[j] = readlane_d(row[k], j);
+#pragma unroll
+        for (int j = 0; j <= k; ++j) mkj[j] = readlane_d(inv[j], k);
+        const double lik = lr > k ? row[k] / dk : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < W; ++j)
+          if (lr >= j) row[j] = __builtin_fma(-lik, ajk[j], row[j]);
+#pragma unroll
+        for (int j = 0; j <= k; ++j) inv[j] = __builtin_fma(-lik, mkj[j], inv[j]);
+        if (lr > k) row[k] = lik;
+      }
+      if (lq == 0) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          if (lr < w && c <= lr) Dg[lr * (W + 1) + c] = row[c];
+          Mi[lr * W + c] = inv[c];
+        }
+        invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
+      }
+      IPM_DTICK(1);
+      __syncthreads();          // B2: Dg, Mi, invd are there
+      // the diagonal block is stored as d on the diagonal and L11^-1 below it (what the solves use)
+      for (int idx = lane; idx < W * W; idx += 64) {
+        const int di = idx / W, dj = idx % W;
+        if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = di == dj ? Dg[di * (W + 1) + dj] : Mi[di * W + dj];
+      }
+      if (lane < w) {
+        const double dk = Dg[lane * (W + 1) + lane];
+        if (dk > 0) ++npos; else if (dk < 0) ++nneg; else ++nbad;
+        if (!(fabs(dk) < 1e300)) ++nbad;
+      }
+      __syncthreads();          // B3: (the panel is in LDS)
+      IPM_DTICK(2);
+    }
+#ifdef IPM_TIMING
+    if (lane == 0 && sidx == 0) { inst[bi].dbg[6] = tq[0] + tq[2]; inst[bi].dbg[7] = tq[1]; }   // waiting for the tile waves | factoring
+#endif
+    for (int o = 32; o; o >>= 1) { npos += __shfl_xor(npos, o); nneg += __shfl_xor(nneg, o); nbad += __shfl_xor(nbad, o); }
+    if (lane == 0) {
+      int* pv = piv + (size_t(bi) * n_sub + sidx) * 3;
+      pv[0] = npos; pv[1] = nneg; pv[2] = nbad;
+    }
+    return;
+  }
+  // ---------------- tile waves ----------------
+  // Tiles are numbered column by column (tile (I, K): K NTB - K (K - 1) / 2 + I - K) and dealt round robin, slot s of wave wv
+  // holds tile wv + 7 s: the tiles a step touches are then a RANGE of slots — those of block column J for the panel solve,
+  // everything from the first tile of column J + 1 on for the update — entered through a switch and walked without a branch
+  // per tile, so that the LDS reads and matrix products of successive tiles overlap.
+#define IPM_REP22(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21)
+  static_assert(MAXS == 22, "IPM_REP22");
+  auto colstart = [&](int Kb) { return Kb * NTB - Kb * (Kb - 1) / 2; };
+  int sIK[MAXS];                // block row << 8 | block column of the slot's tile (wave-uniform); unused slots: tile (0, 0), never stored
+  d4 acc[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const int tl = wv + NWV * s;
+    int Kb = 0;
+    while (Kb + 1 < NTB && colstart(Kb + 1) <= tl) ++Kb;
+    const bool have = tl < ntl;
+    const int I = have ? Kb + (tl - colstart(Kb)) : 0;
+    Kb = have ? Kb : 0;
+    sIK[s] = __builtin_amdgcn_readfirstlane(I << 8 | Kb);
+    const int r = row0(I) + lr;
+    const bool rv = have && r < rend(I), border = r >= G.Nb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cc = row0(Kb) + lq + 4 * g;
+      const bool ok = rv && cc < rend(Kb) && cc <= r && (border || r - cc <= G.b);
+      acc[s][g] = ok ? K[G.at(r, cc)] : 0.0;
+    }
+  }
+  auto first_slot_at = [&](int tl) { return tl <= wv ? 0 : (tl - wv + NWV - 1) / NWV; };   // first slot of this wave with tile number >= tl
+  // slot s takes its rank-16 update from the panel in LDS: A(I, K) -= L(I, J) D L(K, J)^T
+#define IPM_UPD_BODY(s) {                                                                                                    \
+    int ik = sIK[s];                                                                                                         \
+    asm volatile("" : "+s"(ik));   /* keeps the 44 LDS addresses from being hoisted out of the J loop into registers */      \
+    const double* bl = BL + (size_t(ik >> 8) * W + lr) * BS + lq;                                                            \
+    const double* by = BY + (size_t(ik & 255) * W + lr) * BS + lq;                                                           \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-by[4 * g], bl[4 * g], acc[s], 0, 0, 0); \
+  }
+  // slot s is a diagonal tile of width wd: its lower triangle goes to Dg for the eighth wave
+#define IPM_PUT_BODY(s, wd) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int c = lq + 4 * g; if (lr < (wd) && c <= lr) Dg[lr * (W + 1) + c] = acc[s][g]; } }
+  if (wv == 0) IPM_PUT_BODY(0, min(W, G.Nb))    // tile (0, 0) is tile number 0: slot 0 of wave 0
+  __syncthreads();              // B1 of block column 0
+  __syncthreads();              // B2: its diagonal block is factored
+  for (int J = 0; J < nbb; ++J) {
+    const int J0 = W * J, w = min(W, G.Nb - J0);
+    const int cs = colstart(J), cs1 = colstart(J + 1);
+    // the tiles below the diagonal one: Y^T = L11^-1 A^T, L^T = D^-1 Y^T; both go to LDS for the updates, L to the storage
+    {
+      const int sa = first_slot_at(cs + 1), sb = min(MAXS, first_slot_at(cs1));   // slots [sa, sb)
+      switch (sa) {
+#define IPM_PANEL(s) case s: if (s < sb) {                                                                                   \
+          d4 y = {0.0, 0.0, 0.0, 0.0};                                                                                       \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * W + 4 * g + lq], acc[s][g], y, 0, 0, 0); \
+          int ik = sIK[s];                                                                                                   \
+          asm volatile("" : "+s"(ik));                                                                                       \
+          const int I = ik >> 8, r = row0(I) + lr;                                                                           \
+          const bool rv = r < rend(I), border = r >= G.Nb;                                                                   \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
+            const int c = lq + 4 * g;                                                                                        \
+            const double l = y[g] * invd[c];                                                                                 \
+            const bool ok = rv && c < w;                                                                                     \
+            if (ok && (border || r - (J0 + c) <= G.b)) K[G.at(r, J0 + c)] = l;                                               \
+            BL[(size_t(I) * W + lr) * BS + c] = ok ? l : 0.0;                                                                \
+            BY[(size_t(I) * W + lr) * BS + c] = ok ? y[g] : 0.0;                                                             \
+          }                                                                                                                  \
+        }
+        IPM_REP22(IPM_PANEL)
+#undef IPM_PANEL
+        default: break;
+      }
+    }
+    __syncthreads();            // B3: the panel is in LDS
+    // every tile to the right takes its update; the next diagonal tile first, so that the eighth wave factors it meanwhile
+    int s0 = first_slot_at(cs1);
+    if (J + 1 < nbb) {
+      if (cs1 % NWV == wv) {
+        const int w1 = min(W, G.Nb - (J0 + W));
+        switch (s0) {
+#define IPM_NEXT(s) case s: IPM_UPD_BODY(s) IPM_PUT_BODY(s, w1) break;
+          IPM_REP22(IPM_NEXT)
+#undef IPM_NEXT
+          default: break;
+        }
+        ++s0;
+      }
+      __syncthreads();          // B1 of block column J + 1
+    }
+    switch (s0) {
+#define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);   /* two tiles' loads and products may interleave, not all 22 (registers) */
+      IPM_REP22(IPM_UPD)
+#undef IPM_UPD
+      default: break;
+    }
+    if (J + 1 < nbb) __syncthreads();   // B2 of block column J + 1
+  }
+#undef IPM_UPD_BODY
+#undef IPM_PUT_BODY
+  // the Schur complement of the corner, unfactored, back into the corner's storage
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    if ((sIK[s] & 255) >= nbb && wv + NWV * s < ntl) {
+      const int r = row0(sIK[s] >> 8) + lr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cc = row0(sIK[s] & 255) + lq + 4 * g;
+        if (r < G.Nt && cc < G.Nt && cc <= r) K[G.at(r, cc)] = acc[s][g];
+      }
+    }
+  }
+#undef IPM_REP22
+}
+size_t kkt_factor_dense_lds_bytes(int block_rows) {
+  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
+}
+int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of this many block rows
+  int n = 1;
+  while ((n + 1) * (n + 2) / 2 <= IPM_DENSE_TILE_WAVES * IPM_DENSE_SLOTS) ++n;
+  return n;
+}
+hipError_t kkt_factor_dense_prepare(size_t lds_bytes) {
+  if (lds_bytes <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+}
+
 // L y = r, then x = L^-T D^-1 y, in place in rhs: one workgroup per instance, IPM_W columns per step.  The diagonal
 // blocks hold L11^-1, so a step's own 16 unknowns are 16 parallel dot products.  The right-hand side lives in LDS when it
 // fits (RL); the diagonal block and each thread's panel row of the NEXT step are fetched while the current one is worked.
@@ -1583,7 +1810,11 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
     const unsigned blocks = unsigned(std::max(1, std::min(1024, (n + 255) / 256)));
     hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1, n_long);
   };
-  launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);                 // every interval up to its corner
+  if (D.l1_dense_lds)                                                                  // every interval up to its corner
+    hipLaunchKernelGGL(kkt_factor_dense_kernel, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
+                       D.n_l1, D.n_sub, D.inst, D.piv);
+  else
+    launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);
   corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg, D.n_cg_long);
   if (D.n_l2) {
     launch_factor_subs(D, D.n_l1, D.n_l2, 1, tiles_per_wave, lds_bytes, st);          // every group of separators up to its corner

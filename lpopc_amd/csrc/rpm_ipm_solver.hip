@@ -216,6 +216,15 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     D.n_l1 = p.nd ? D.n_sub - 1 - D.n_l2 : 0;
     D.max_sub_nt = 0;
     for (const KktSub& q : subs) D.max_sub_nt = std::max(D.max_sub_nt, q.g.Nt);
+    D.l1_dense_lds = 0;
+    if (D.n_l1 > 0 && !(std::getenv("RPM_IPM_DENSE") && std::atoi(std::getenv("RPM_IPM_DENSE")) == 0)) {
+      int rows = 0;   // most 16-row blocks (band + border) of a level-1 sub-problem
+      for (int i = 0; i < D.n_l1; ++i) rows = std::max(rows, (subs[size_t(i)].g.Nb + IPM_W - 1) / IPM_W + (subs[size_t(i)].g.nb + IPM_W - 1) / IPM_W);
+      if (rows <= kkt_factor_dense_max_block_rows()) {
+        D.l1_dense_lds = kkt_factor_dense_lds_bytes(rows);
+        if (kkt_factor_dense_prepare(D.l1_dense_lds) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
+      }
+    }
     A_(ipm_alloc_c(h, &D.subs, subs));
     A_(ipm_alloc(h, &D.piv, B * subs.size() * 3));
     A_(ipm_alloc_c(h, &D.cg_ptr, p.cg_ptr)); A_(ipm_alloc_c(h, &D.cg_src, p.cg_src)); A_(ipm_alloc_c(h, &D.cg_dst, p.cg_dst));
@@ -571,8 +580,8 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   IPM_TRY(h, hipMemcpyAsync(h->h_inst.data(), D.inst, size_t(B) * sizeof(IpmInst), hipMemcpyDeviceToHost, st));
   IPM_TRY(h, hipStreamSynchronize(st));
 #ifdef IPM_TIMING
-  fprintf(stderr, "last factorisation of instance 0, phase clocks [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld\n",
-          h->h_inst[0].dbg[0], h->h_inst[0].dbg[1], h->h_inst[0].dbg[2], h->h_inst[0].dbg[3], h->h_inst[0].dbg[4], h->h_inst[0].dbg[5]);
+  fprintf(stderr, "last factorisation of instance 0, phase clocks [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld | dense level 1, diagonal wave: waiting %lld  factoring %lld\n",
+          h->h_inst[0].dbg[0], h->h_inst[0].dbg[1], h->h_inst[0].dbg[2], h->h_inst[0].dbg[3], h->h_inst[0].dbg[4], h->h_inst[0].dbg[5], h->h_inst[0].dbg[6], h->h_inst[0].dbg[7]);
 #endif
   for (unsigned bi = 0; bi < B; ++bi) {
     const IpmInst& S = h->h_inst[bi];
