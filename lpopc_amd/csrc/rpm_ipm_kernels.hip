@@ -927,6 +927,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         for (int j = k + 1; j < W; ++j) ajk[j] = readlane_d(row[k], j);
 #pragma unroll
         for (int j = 0; j <= k; ++j) mkj[j] = readlane_d(inv[j], k);
+        // (a reciprocal estimate with two Newton steps instead of the division: 90.5 -> 86.6 us of diagonal-block time per
+        // interval block, not worth leaving the left-looking kernel's arithmetic)
         const double lik = lr > k ? row[k] / dk : 0.0;
 #pragma unroll
         for (int j = k + 1; j < W; ++j)
