@@ -720,9 +720,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 #pragma unroll
         for (int j = 0; j <= k; ++j) mkj[j] = readlane_d(inv[j], k);        // row k of the inverse so far
         const double lik = lr > k ? row[k] / dk : 0.0;
+        // (no `lr >= j` guard: entries right of a lane's diagonal are never read, lanes at or above row k have lik = 0, and the
+        // compare and two selects per entry were a quarter of this loop's instructions — the loop is issue-bound)
 #pragma unroll
-        for (int j = k + 1; j < W; ++j)
-          if (lr >= j) row[j] = __builtin_fma(-lik, ajk[j], row[j]);
+        for (int j = k + 1; j < W; ++j) row[j] = __builtin_fma(-lik, ajk[j], row[j]);
 #pragma unroll
         for (int j = 0; j <= k; ++j) inv[j] = __builtin_fma(-lik, mkj[j], inv[j]);
         if (lr > k) row[k] = lik;
@@ -889,8 +890,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr, ntl = NTB * (NTB + 1) / 2;
   extern __shared__ double lds[];
   double* Dg = lds;                       // W x (W + 1)
-  double* Mi = Dg + W * (W + 1);          // W x W: L11^-1, row-major
-  double* invd = Mi + W * W;              // W
+  double* Mi = Dg + W * (W + 1);          // W x 18: L11^-1, row-major (rows padded like the panel's, see below)
+  double* invd = Mi + W * IPM_DENSE_LDS_ROW;   // W
   // rows of 18 doubles: the 16 lanes that read one column of 16 successive rows then hit 16 different pairs of banks (at 16
   // doubles per row they share two, and the matrix products starve: 18 us per block column instead of 3)
   constexpr int BS = IPM_DENSE_LDS_ROW;
@@ -930,9 +931,10 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         // (a reciprocal estimate with two Newton steps instead of the division: 90.5 -> 86.6 us of diagonal-block time per
         // interval block, not worth leaving the left-looking kernel's arithmetic)
         const double lik = lr > k ? row[k] / dk : 0.0;
+        // (no `lr >= j` guard as in kkt_factor_kernel: entries right of a lane's diagonal are never read, and the compare and
+        // the two selects per entry are a quarter of this loop's instructions — it is issue-bound, 800 cycles per step)
 #pragma unroll
-        for (int j = k + 1; j < W; ++j)
-          if (lr >= j) row[j] = __builtin_fma(-lik, ajk[j], row[j]);
+        for (int j = k + 1; j < W; ++j) row[j] = __builtin_fma(-lik, ajk[j], row[j]);
 #pragma unroll
         for (int j = 0; j <= k; ++j) inv[j] = __builtin_fma(-lik, mkj[j], inv[j]);
         if (lr > k) row[k] = lik;
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #pragma unroll
         for (int c = 0; c < W; ++c) {
           if (lr < w && c <= lr) Dg[lr * (W + 1) + c] = row[c];
-          Mi[lr * W + c] = inv[c];
+          Mi[lr * IPM_DENSE_LDS_ROW + c] = inv[c];
         }
         invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
       }
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       // the diagonal block is stored as d on the diagonal and L11^-1 below it (what the solves use)
       for (int idx = lane; idx < W * W; idx += 64) {
         const int di = idx / W, dj = idx % W;
-        if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = di == dj ? Dg[di * (W + 1) + dj] : Mi[di * W + dj];
+        if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = di == dj ? Dg[di * (W + 1) + dj] : Mi[di * IPM_DENSE_LDS_ROW + dj];
       }
       if (lane < w) {
         const double dk = Dg[lane * (W + 1) + lane];
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       switch (sa) {
 #define IPM_PANEL(s) case s: if (s < sb) {                                                                                   \
           d4 y = {0.0, 0.0, 0.0, 0.0};                                                                                       \
-          _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * W + 4 * g + lq], acc[s][g], y, 0, 0, 0); \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], acc[s][g], y, 0, 0, 0); \
           int ik = sIK[s];                                                                                                   \
           asm volatile("" : "+s"(ik));                                                                                       \
           const int I = ik >> 8, r = row0(I) + lr;                                                                           \
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_REP22
 }
 size_t kkt_factor_dense_lds_bytes(int block_rows) {
-  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
+  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
 }
 int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of this many block rows
   int n = 1;
