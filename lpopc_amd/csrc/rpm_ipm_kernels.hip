@@ -881,6 +881,9 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
                                                                   int n_sub, IpmInst* inst, int* piv) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W, NWV = IPM_DENSE_TILE_WAVES, MAXS = IPM_DENSE_SLOTS;
+  // the barriers of this kernel order LDS traffic only: __syncthreads() would also wait for the stores of L into the storage
+  // (s_waitcnt vmcnt(0)), a trip to the L2 on the critical path of every block column
+#define IPM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   const int bi = blockIdx.x / n_here, sidx = sub0 + int(blockIdx.x) % n_here, t = threadIdx.x;
   const IpmInst& S = inst[bi];
   if (S.status != 0 || !S.refactor) return;
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #endif
     for (int J = 0; J < nbb; ++J) {
       const int J0 = W * J, w = min(W, G.Nb - J0);
-      __syncthreads();          // B1: the owner of tile (J, J) has put it into Dg
+      IPM_LDS_BARRIER();          // B1: the owner of tile (J, J) has put it into Dg
       IPM_DTICK(0);
       double row[W], inv[W];    // lane (l & 15) = row of the block and of L11^-1 (kkt_factor_kernel's elimination, word for word)
 #pragma unroll
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
       }
       IPM_DTICK(1);
-      __syncthreads();          // B2: Dg, Mi, invd are there
+      IPM_LDS_BARRIER();          // B2: Dg, Mi, invd are there
       // the diagonal block is stored as d on the diagonal and L11^-1 below it (what the solves use)
       for (int idx = lane; idx < W * W; idx += 64) {
         const int di = idx / W, dj = idx % W;
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         if (dk > 0) ++npos; else if (dk < 0) ++nneg; else ++nbad;
         if (!(fabs(dk) < 1e300)) ++nbad;
       }
-      __syncthreads();          // B3: (the panel is in LDS)
+      IPM_LDS_BARRIER();          // B3: (the panel is in LDS)
       IPM_DTICK(2);
     }
 #ifdef IPM_TIMING
@@ -1012,8 +1015,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   // slot s is a diagonal tile of width wd: its lower triangle goes to Dg for the eighth wave
 #define IPM_PUT_BODY(s, wd) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int c = lq + 4 * g; if (lr < (wd) && c <= lr) Dg[lr * (W + 1) + c] = acc[s][g]; } }
   if (wv == 0) IPM_PUT_BODY(0, min(W, G.Nb))    // tile (0, 0) is tile number 0: slot 0 of wave 0
-  __syncthreads();              // B1 of block column 0
-  __syncthreads();              // B2: its diagonal block is factored
+  IPM_LDS_BARRIER();              // B1 of block column 0
+  IPM_LDS_BARRIER();              // B2: its diagonal block is factored
   for (int J = 0; J < nbb; ++J) {
     const int J0 = W * J, w = min(W, G.Nb - J0);
     const int cs = colstart(J), cs1 = colstart(J + 1);
@@ -1042,7 +1045,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         default: break;
       }
     }
-    __syncthreads();            // B3: the panel is in LDS
+    IPM_LDS_BARRIER();            // B3: the panel is in LDS
     // every tile to the right takes its update; the next diagonal tile first, so that the eighth wave factors it meanwhile
     int s0 = first_slot_at(cs1);
     if (J + 1 < nbb) {
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         }
         ++s0;
       }
-      __syncthreads();          // B1 of block column J + 1
+      IPM_LDS_BARRIER();          // B1 of block column J + 1
     }
     switch (s0) {
 #define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);   /* two tiles' loads and products may interleave, not all 22 (registers) */
@@ -1064,7 +1067,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_UPD
       default: break;
     }
-    if (J + 1 < nbb) __syncthreads();   // B2 of block column J + 1
+    if (J + 1 < nbb) IPM_LDS_BARRIER();   // B2 of block column J + 1
   }
 #undef IPM_UPD_BODY
 #undef IPM_PUT_BODY
@@ -1081,6 +1084,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     }
   }
 #undef IPM_REP22
+#undef IPM_LDS_BARRIER
 }
 size_t kkt_factor_dense_lds_bytes(int block_rows) {
   return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
