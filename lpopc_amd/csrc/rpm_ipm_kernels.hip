@@ -1017,9 +1017,16 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   if (wv == 0) IPM_PUT_BODY(0, min(W, G.Nb))    // tile (0, 0) is tile number 0: slot 0 of wave 0
   IPM_LDS_BARRIER();              // B1 of block column 0
   IPM_LDS_BARRIER();              // B2: its diagonal block is factored
+#ifdef IPM_TIMING
+  long long tw[5] = {0, 0, 0, 0, 0}, twp = wall_clock64();
+#define IPM_TTICK(i) do { const long long n_ = wall_clock64(); tw[i] += n_ - twp; twp = n_; } while (0)
+#else
+#define IPM_TTICK(i)
+#endif
   for (int J = 0; J < nbb; ++J) {
     const int J0 = W * J, w = min(W, G.Nb - J0);
     const int cs = colstart(J), cs1 = colstart(J + 1);
+    IPM_TTICK(4);               // waiting at B2
     // the tiles below the diagonal one: Y^T = L11^-1 A^T, L^T = D^-1 Y^T; both go to LDS for the updates, L to the storage
     {
       const int sa = first_slot_at(cs + 1), sb = min(MAXS, first_slot_at(cs1));   // slots [sa, sb)
@@ -1045,7 +1052,9 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         default: break;
       }
     }
+    IPM_TTICK(0);               // panel
     IPM_LDS_BARRIER();            // B3: the panel is in LDS
+    IPM_TTICK(1);               // waiting at B3
     // every tile to the right takes its update; the next diagonal tile first, so that the eighth wave factors it meanwhile
     int s0 = first_slot_at(cs1);
     if (J + 1 < nbb) {
@@ -1060,6 +1069,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         ++s0;
       }
       IPM_LDS_BARRIER();          // B1 of block column J + 1
+      IPM_TTICK(2);             // next diagonal tile + B1
     }
     switch (s0) {
 #define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);   /* two tiles' loads and products may interleave, not all 22 (registers) */
@@ -1067,8 +1077,14 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_UPD
       default: break;
     }
+    IPM_TTICK(3);               // update
     if (J + 1 < nbb) IPM_LDS_BARRIER();   // B2 of block column J + 1
   }
+#ifdef IPM_TIMING
+  // (build with -DIPM_TIMING_SUB=<out of range> so that the left-looking kernel of the last level leaves these alone:
+  //  wave 0's panel | wait at B3 | next diagonal tile + B1 | update | wait at B2, 100 MHz ticks per interval block)
+  if (t == 0 && sidx == 0) { inst[bi].dbg[0] = tw[0]; inst[bi].dbg[1] = tw[1]; inst[bi].dbg[2] = tw[2]; inst[bi].dbg[3] = tw[3]; inst[bi].dbg[4] = tw[4]; }
+#endif
 #undef IPM_UPD_BODY
 #undef IPM_PUT_BODY
   // the Schur complement of the corner, unfactored, back into the corner's storage
