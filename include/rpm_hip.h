@@ -242,7 +242,10 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       LOQO oracle and the kkt-error globalisation; 0: the monotone Fiacco-McCormick rule,
  *                       three batched iterations fewer on the quadrotor sweep),
  *                       "sigma_cap" (0 = off; experimental clamp on z/s in the KKT matrix),
- *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start)
+ *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start),
+ *                       "level1_dense" (1 where it applies: the interval blocks of the nested dissection are factored out of
+ *                       registers, kkt_factor_dense_kernel, when each has at most 17 block rows of 16; 0 = the left-looking
+ *                       kernel for every level; 1 on a layout it does not fit: RPM_E_UNSUPPORTED)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,

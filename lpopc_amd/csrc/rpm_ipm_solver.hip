@@ -23,6 +23,7 @@ struct rpm_ipm {
   std::vector<void*> allocs;
   int* h_cnt = nullptr;           // page-locked mirror of D.cnt
   size_t factor_lds = 0;
+  size_t l1_dense_lds = 0;    // LDS of kkt_factor_dense_kernel when every level-1 sub-problem fits its register tiles, else 0
   int factor_mt = IPM_MT;
   std::string err;
   std::vector<IpmInst> h_inst;
@@ -217,13 +218,14 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     D.max_sub_nt = 0;
     for (const KktSub& q : subs) D.max_sub_nt = std::max(D.max_sub_nt, q.g.Nt);
     D.l1_dense_lds = 0;
-    if (D.n_l1 > 0 && !(std::getenv("RPM_IPM_DENSE") && std::atoi(std::getenv("RPM_IPM_DENSE")) == 0)) {
+    if (D.n_l1 > 0) {
       int rows = 0;   // most 16-row blocks (band + border) of a level-1 sub-problem
       for (int i = 0; i < D.n_l1; ++i) rows = std::max(rows, (subs[size_t(i)].g.Nb + IPM_W - 1) / IPM_W + (subs[size_t(i)].g.nb + IPM_W - 1) / IPM_W);
       if (rows <= kkt_factor_dense_max_block_rows()) {
-        D.l1_dense_lds = kkt_factor_dense_lds_bytes(rows);
-        if (kkt_factor_dense_prepare(D.l1_dense_lds) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
+        h->l1_dense_lds = kkt_factor_dense_lds_bytes(rows);
+        if (kkt_factor_dense_prepare(h->l1_dense_lds) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
       }
+      if (!(std::getenv("RPM_IPM_DENSE") && std::atoi(std::getenv("RPM_IPM_DENSE")) == 0)) D.l1_dense_lds = h->l1_dense_lds;   // option "level1_dense"
     }
     A_(ipm_alloc_c(h, &D.subs, subs));
     A_(ipm_alloc(h, &D.piv, B * subs.size() * 3));
@@ -295,6 +297,10 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
     o.mu_adaptive = int(value);
   }
   else if (k == "restoration_penalty") o.resto_rho = value;
+  else if (k == "level1_dense") {   // level 1 of the nested dissection on kkt_factor_dense_kernel (default where the interval blocks fit it)
+    if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 17 block rows"; return RPM_E_UNSUPPORTED; }
+    h->D.l1_dense_lds = value != 0.0 ? h->l1_dense_lds : 0;
+  }
   else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
     const int cap = int(value);
     if (cap < 0 || cap > 100000) { h->err = "trace: 0 ... 100000 records"; return RPM_E_INVALID; }

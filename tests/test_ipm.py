@@ -196,6 +196,41 @@ def test_kkt_factorisation_layouts_against_numpy(built, name, make, B, nested):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,make,B", [("quadrotor_8x8", lambda: problems.quadrotor(8, 8), 3), ("quadrotor_24x4", lambda: problems.quadrotor(24, 4), 2),
+                                         ("launch_16x4", lambda: problems.launch(16, 4), 1)], ids=["quadrotor_8x8", "quadrotor_24x4", "launch_16x4"])
+def test_register_resident_level_1_equals_the_left_looking_kernel(built, name, make, B):
+    """kkt_factor_dense_kernel (interval blocks of at most 17 block rows factored out of registers, option level1_dense) against
+    kkt_factor_kernel on the same random quasi-definite matrices: both solve to 1e-11 of numpy, report the same inertia, and agree
+    with each other to rounding (the same products in the same order: 1e-13).  A layout without nested dissection refuses the option."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine, RpmError
+    eng = NLPEngine(make(), _exact(), n_instances=B, device=0)
+    eng.set_option("ipm_nested", 1)
+    ipm = BatchedIPM(eng)
+    dense, sign, filled = _random_kkt_dense(ipm, eng.n, B, 23)
+    rhs = np.random.RandomState(9).uniform(-1, 1, size=(B, sign.size))
+    sols = []
+    for on in (1, 0):
+        ipm.set_option("level1_dense", on)          # 1 is the default here; it must be accepted
+        sol, npos, nneg = ipm.debug_solve_dense(dense, rhs)
+        for bi in range(B):
+            ref = np.linalg.solve(dense[bi], rhs[bi])
+            assert np.max(np.abs(sol[bi] - ref)) <= 1e-11 * np.max(np.abs(ref))
+            assert npos[bi] == (sign > 0).sum() and nneg[bi] == (sign < 0).sum()
+        sols.append(sol)
+    assert np.max(np.abs(sols[0] - sols[1])) <= 1e-13 * np.max(np.abs(sols[1]))
+    ipm.close()
+    eng.close()
+    band = NLPEngine(make(), _exact(), n_instances=1, device=0)
+    band.set_option("ipm_nested", 0)
+    ipm = BatchedIPM(band)
+    with pytest.raises(RpmError):
+        ipm.set_option("level1_dense", 1)
+    ipm.set_option("level1_dense", 0)
+    ipm.close()
+    band.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,make,B,pert", [("bryson_denham", lambda: problems.bryson_denham(2, 8), 2, 0.0),
                                              ("hypersensitive", lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), 2, 0.0),
                                              ("quadrotor_3x6", lambda: problems.quadrotor(3, 6, pref=(0.4, 0.8, -0.6)), 3, 2e-2),
