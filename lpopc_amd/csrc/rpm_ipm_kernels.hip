@@ -898,7 +898,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   // rows of 18 doubles: the 16 lanes that read one column of 16 successive rows then hit 16 different pairs of banks (at 16
   // doubles per row they share two, and the matrix products starve: 18 us per block column instead of 3)
   constexpr int BS = IPM_DENSE_LDS_ROW;
-  double* BL = invd + W;                   // NTB x 16 x BS: L of the current block column, by block row
+  double* dv = invd + W;                   // W: the pivots d (what the storage holds on the diagonal)
+  double* BL = dv + W;                     // NTB x 16 x BS: L of the current block column, by block row
   double* BY = BL + size_t(NTB) * W * BS;  // the same for L D
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = t & 15, lq = (t & 63) >> 4;
   auto row0 = [&](int I) { return I < nbb ? W * I : G.Nb + W * (I - nbb); };
@@ -949,6 +950,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
           Mi[lr * IPM_DENSE_LDS_ROW + c] = inv[c];
         }
         invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
+        dv[lr] = lr < w ? row[lr] : 0.0;
       }
       IPM_DTICK(1);
       IPM_LDS_BARRIER();          // B2: Dg, Mi, invd are there
@@ -1044,7 +1046,9 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
             const bool ok = rv && c < w;                                                                                     \
             if (ok && (border || r - (J0 + c) <= G.b)) K[G.at(r, J0 + c)] = l;                                               \
             BL[(size_t(I) * W + lr) * BS + c] = ok ? l : 0.0;                                                                \
-            BY[(size_t(I) * W + lr) * BS + c] = ok ? y[g] : 0.0;                                                             \
+            /* L D as kkt_factor_kernel forms it: the product of the stored l and d for a band row (its T), y itself for a   \
+               border row (its BY) — the two differ in the last bit, and Delta-III's path is sensitive to that */            \
+            BY[(size_t(I) * W + lr) * BS + c] = ok ? (border ? y[g] : l * dv[c]) : 0.0;                                        \
           }                                                                                                                  \
         }
         IPM_REP22(IPM_PANEL)
@@ -1103,7 +1107,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_LDS_BARRIER
 }
 size_t kkt_factor_dense_lds_bytes(int block_rows) {
-  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
+  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + 2 * IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
 }
 int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of this many block rows
   int n = 1;
