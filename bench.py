@@ -31,9 +31,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from lpopc_amd._hostmem import keep_heap_mapped  # noqa: E402
-
-keep_heap_mapped()       # see lpopc_amd/_hostmem.py
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

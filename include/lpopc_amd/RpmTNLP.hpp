@@ -29,9 +29,10 @@ class RpmTNLPT : public Base {
   // ("delta_values": the constant Doffdiag block, the linear entries and every x-independent block cross PCIe once; the
   // engine still checks 64 sampled entries of the array before each delivery and re-sends everything if one differs).
   // Pass false for a caller that allocates fresh arrays per call or edits `values` in place: plain staged copies.
-  explicit RpmTNLPT(rpm_engine* engine, bool ipopt_owned_arrays = true) : e_(engine) {
-    rpm_set_option(e_, "pin_host", ipopt_owned_arrays ? 1 : 0);
-    rpm_set_option(e_, "delta_values", ipopt_owned_arrays ? 1 : 0);
+  // ("pin_host" is off in the C ABI unless asked for: this constructor argument is the asking.)
+  explicit RpmTNLPT(rpm_engine* engine, bool ipopt_owned_arrays = true) : e_(engine), owned_(ipopt_owned_arrays) {
+    rpm_set_option(e_, "pin_host", owned_ ? 1 : 0);
+    rpm_set_option(e_, "delta_values", owned_ ? 1 : 0);
   }
 
   bool get_nlp_info(Index& n, Index& m, Index& nnz_jac_g, Index& nnz_h_lag, IndexStyleEnum& index_style) override {
@@ -72,14 +73,15 @@ class RpmTNLPT : public Base {
     rpm_finalize_solution(e_, int(status), n, x, z_L, z_U, m, g, lambda, obj_value);  // LpopcIpopt.cpp:220-246
     // Ipopt's last call into the TNLP, and its x / g / values arrays (TNLPAdapter's) may be freed before this object is:
     // release their page-locked registrations now (rpm_hip.h "pin_host": a registered array must not be unmapped), and
-    // turn the option back on for a further OptimizeTNLP with the same object.
+    // put the option back to what the constructor was told, for a further OptimizeTNLP with the same object.
     rpm_set_option(e_, "pin_host", 0);
-    rpm_set_option(e_, "pin_host", 1);
+    rpm_set_option(e_, "pin_host", owned_ ? 1 : 0);
   }
   std::string last_error() const { return rpm_last_error(e_); }
 
  private:
   rpm_engine* e_;
+  bool owned_;   // the caller's promise about the arrays (constructor)
 };
 
 }  // namespace lpopc_amd

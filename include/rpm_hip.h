@@ -352,18 +352,27 @@ int rpm_synchronize(rpm_engine* e);
  * "ipm_nested_group" 0 (default: automatic) | positions per group: with nested dissection the separator system (block
  *                    tridiagonal along time) of a long mesh is cut once more into groups of this many of its positions, each
  *                    eliminated by a workgroup of its own (automatic: when that system is >= 512 long, groups of ~sqrt(length * bandwidth))
- * "zero_copy"        1 (default): with page-locked caller arrays the tile kernel reads x straight from the caller's array and
- *                    stores g straight into it (no copy operations: one launch + one synchronisation per rpm_eval_g);
- *                    0: staged through the engine's HBM buffers with copy-engine transfers
+ * "zero_copy"        1 (default): the tile kernel reads x straight from page-locked host memory and stores g straight into it
+ *                    (the caller's arrays with "pin_host", else the engine's staging buffers) — no copy-engine operations,
+ *                    one launch + one synchronisation per rpm_eval_g; 0: through the engine's HBM buffers with copy-engine transfers
  * "check_finite"     1 (default): NaN/Inf in a result -> RPM_E_NONFINITE (checked on the device); 0: lpopc's behaviour
- * "pin_host"         1 (default): the host-pointer entry points page-lock (hipHostRegister) the caller's x / g /
- *                    values arrays the first time they see them — Ipopt reuses the same arrays every iteration —
- *                    so copies run at PCIe rate and the kernels can address them.  At most 8 registrations are kept
- *                    (least recently used is released first; a new range that overlaps an old one replaces it); all are
- *                    released by rpm_destroy, or at once by setting the option to 0 (do that BEFORE unmapping a registered
- *                    array, e.g. a shared segment).  LIFETIME: a registered array must stay mapped until rpm_destroy, its
- *                    eviction or that release; leave the option 0 if the caller frees and re-allocates these buffers between
- *                    calls.  (An unmapped range that is still page-locked can end the process in a later copy: DESIGN.md §6.)
+ * "pin_host"         0 (default) | 1.  0: the host-pointer entry points copy x into, and g / values / grad_f out of,
+ *                    page-locked staging buffers the engine owns (CPU copies); the caller's memory is never handed to
+ *                    the HIP runtime, so arrays of any lifetime may be passed (this replaces LpopcIpopt's own heap copy
+ *                    of x and element-wise copy-out, Core/LpopcIpopt.cpp:135-181).  1 (opt-in; RpmTNLP asks for it on
+ *                    behalf of Ipopt, whose TNLPAdapter hands the same arrays every iteration): arrays of >= 64 KB are
+ *                    page-locked (hipHostRegister) the first time they are seen, the kernels read x from and store g into
+ *                    them, copy engines and the delta delivery write `values` straight into them.  Registrations live in
+ *                    ONE process-wide, page-granular, reference-counted table shared by every engine of the process
+ *                    (librpm_pin.so): page-aligned supersets of the arrays, never overlapping; an engine holds at most 8
+ *                    (least recently used is let go first) and lets go of all of them in rpm_destroy or when the option
+ *                    is set to 0; pages are unregistered when their last holder lets go.  A request the runtime refuses,
+ *                    or that partly overlaps pages another engine holds, is served through the staging buffers instead and
+ *                    is never silent: get-only "pin_register_failures", "pin_unregister_failures", "pin_overlap_refused"
+ *                    (process-wide counts; also "pin_registered", "pin_unregistered", "pin_shared", "pin_merged",
+ *                    "pin_evicted", "pin_live", and "pin_held" = this engine's) and the reason in rpm_last_error.
+ *                    LIFETIME (option 1 only): a registered array must stay allocated until rpm_destroy, its eviction or
+ *                    that release — set the option to 0 BEFORE freeing or unmapping such an array.
  */
 /* Parameter sweeps (n_instances > 1): by default every instance shares the problem functor's constants
  * (rpm_problem_desc.consts — the reference keeps them in file-scope globals, example/launch/Launch.cpp:47-74).  This

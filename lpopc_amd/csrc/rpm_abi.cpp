@@ -9,6 +9,7 @@
 #include <string>
 
 #include "rpm_engine.hpp"
+#include "rpm_pin.h"
 
 struct rpm_engine {
   rpm::Engine e;
@@ -70,7 +71,15 @@ void rpm_destroy(rpm_engine* h) {
   delete h;
 }
 
-const char* rpm_last_error(const rpm_engine* h) { return h ? h->e.err.c_str() : g_create_error.c_str(); }
+// the reason of the last failed call; when no call failed, the reason the page-lock registry last refused this engine
+// (the call itself went through the staging buffers and succeeded)
+const char* rpm_last_error(const rpm_engine* h) {
+  if (!h) return g_create_error.c_str();
+  if (h->e.pin_note.empty()) return h->e.err.c_str();
+  rpm_engine* w = const_cast<rpm_engine*>(h);
+  w->e.err_report = h->e.err + (h->e.err.empty() ? "" : "; ") + "page-lock registry: " + h->e.pin_note;
+  return w->e.err_report.c_str();
+}
 
 int rpm_device_init(rpm_engine* h, int device_id) {
   if (!h) return RPM_E_INVALID;
@@ -128,7 +137,6 @@ static int stage_x(Engine& e, int n, const double* x) {   // x into the engine's
     int rc = rpm::device_init(e, 0);
     if (rc) return rc;
   }
-  (void)rpm::dev_pin_host(e, x, size_t(e.n_instances) * e.n * sizeof(double));
   return rpm::dev_upload_x(e, x);
 }
 
@@ -214,12 +222,11 @@ int rpm_eval_h(rpm_engine* h, int n, const double* x, int new_x, double obj_fact
   if (rc) return rc;
   // the reference copies only m-1 multipliers (LpopcIpopt.cpp:205-208); the last one belongs to a linear row and
   // never enters the Hessian, so all m are uploaded here
-  rc = rpm::dev_upload(e, rpm::dev_buf(e, 5), lambda, size_t(e.n_instances) * e.m);
+  rc = rpm::dev_upload(e, rpm::dev_buf(e, 5), lambda, size_t(e.n_instances) * e.m, rpm::STAGE_LAMBDA);
   if (rc) return rc;
   rc = rpm::dev_eval_h(e, rpm::dev_buf(e, 0), obj_factor, rpm::dev_buf(e, 5), rpm::dev_buf(e, 6), rpm::dev_stream(e));
   if (rc) return rc;
-  rpm::dev_pin_host(e, values, size_t(e.n_instances) * e.nnz_h * sizeof(double));
-  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 6), size_t(e.n_instances) * e.nnz_h);
+  rc = rpm::dev_download(e, values, rpm::dev_buf(e, 6), size_t(e.n_instances) * e.nnz_h, rpm::STAGE_HESS);
   if (rc) return rc;
   if (e.opt_check_finite && rpm::dev_nonfinite(e, rpm::dev_buf(e, 6), size_t(e.n_instances) * e.nnz_h) != 0) return fail(e, RPM_E_NONFINITE, "eval_h: non-finite Hessian value");
   return RPM_OK;
@@ -519,7 +526,10 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   else if (k == "check_finite") e.opt_check_finite = value ? 1 : 0;
   else if (k == "pin_host") {
     e.opt_pin_host = value ? 1 : 0;
-    if (!value) rpm::dev_pin_release_all(e);   // a caller that is about to unmap its arrays turns the option off first
+    if (!value) {   // a caller that is about to free or unmap its arrays turns the option off first
+      if (e.dev) { int rc = rpm::dev_sync(e); if (rc) return rc; }
+      rpm::dev_pin_release_all(e);
+    }
   }
   else if (k == "dx_mode") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "dx_mode must be 0 (scalar, reference order) or 1 (MFMA)");
@@ -573,6 +583,7 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
     }
   } else
     return fail(e, RPM_E_INVALID, "unknown option");
+  rpm::host_new_x(e);   // nothing cached under the old options is handed out under the new ones
   return RPM_OK;
 }
 int rpm_get_option(rpm_engine* h, const char* key, int* value) {
@@ -593,9 +604,17 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "ipm_nested_group") *value = e.opt_ipm_nested_group;
   else if (k == "zero_copy") *value = e.opt_zero_copy;
   else if (k == "pin_host") *value = e.opt_pin_host;
-  else if (k == "pin_registered") *value = rpm::dev_pin_counter(0);
-  else if (k == "pin_register_failures") *value = rpm::dev_pin_counter(1);
-  else if (k == "pin_unregister_failures") *value = rpm::dev_pin_counter(2);
+  // page-lock registry of the process (librpm_pin.so; counters since the process started) and this engine's share of it
+  else if (k == "pin_registered") *value = int(rpm::dev_pin_counter(RPM_PIN_REGISTERED));
+  else if (k == "pin_register_failures") *value = int(rpm::dev_pin_counter(RPM_PIN_REGISTER_FAILURES));
+  else if (k == "pin_unregistered") *value = int(rpm::dev_pin_counter(RPM_PIN_UNREGISTERED));
+  else if (k == "pin_unregister_failures") *value = int(rpm::dev_pin_counter(RPM_PIN_UNREGISTER_FAILURES));
+  else if (k == "pin_overlap_refused") *value = int(rpm::dev_pin_counter(RPM_PIN_OVERLAP_REFUSED));
+  else if (k == "pin_shared") *value = int(rpm::dev_pin_counter(RPM_PIN_SHARED));
+  else if (k == "pin_merged") *value = int(rpm::dev_pin_counter(RPM_PIN_MERGED));
+  else if (k == "pin_evicted") *value = int(rpm::dev_pin_counter(RPM_PIN_EVICTED));
+  else if (k == "pin_live") *value = int(rpm::dev_pin_counter(RPM_PIN_LIVE));
+  else if (k == "pin_held") *value = rpm::dev_pin_held(e);
   else if (k == "delta_sent_runs") return rpm::host_delta_sent_runs(e, value);
   else if (k == "delta_total_runs") *value = e.last_delta_total;
   else if (k == "stride_g") *value = int(e.stride_g());

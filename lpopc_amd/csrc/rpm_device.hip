@@ -4,10 +4,9 @@
 // rpm_tile_kernels.hip, the exact Hessian (K6) in rpm_hess_kernels.hip, the post-solve kernels in rpm_post_kernels.hip.
 // No CPU fallback lives here or anywhere else in the product.
 #include "rpm_device_internal.hpp"
+#include "rpm_pin.h"
 
 namespace rpm {
-
-static void pin_release(const void* ptr);   // hipHostUnregister with failure accounting (defined with dev_pin_host)
 
 // ------------------------------------------------------------------------------------------
 // Objective and gradient.  One workgroup per phase; thread = node (strided).  Sums use a fixed
@@ -187,8 +186,8 @@ void device_destroy(Engine& e) {
   if (d->h_flags2) (void)hipHostFree(d->h_flags2);   // d_flags2 is its device alias
   host_path_destroy(d);
   exchange_destroy(d);
-  for (auto& p : d->pinned) pin_release(p.ptr);
-  (void)hipGetLastError();   // a buffer the caller already freed makes the unregister fail: not an error of ours
+  rpm_pin_release_owner(&e);   // this engine's holds; pages another engine still addresses stay registered
+  dev_stage_destroy(d);
   for (auto& row : d->segtab)
     for (auto& t : row)
       if (t.ptr) (void)hipFree(t.ptr);
@@ -402,73 +401,103 @@ int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b
   hipLaunchKernelGGL(rpm_finite2_kernel, dim3(blocks), dim3(256), 0, d.stream, a, na, b, nb, d.d_flags2);
   return RPM_OK;
 }
-int dev_flags_fetch(Engine& e) {   // nothing to queue: the kernel ORs straight into host memory (rarely: only on NaN/Inf)
-  (void)e;
-  return RPM_OK;
-}
 int dev_flag_value(Engine& e, int slot) { return e.dev->h_flags2 ? e.dev->h_flags2[slot] : 0; }
-int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count) {
-  HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e.dev->stream));
-  return RPM_OK;
-}
 
-// Page-lock the caller's buffer once (Ipopt hands the same x / g / values arrays every iteration) so that
-// the copies are direct DMA at PCIe rate instead of staged pageable copies.  Best effort: failures are ignored.
-// At most PIN_MAX registrations are kept (least recently used goes first), so a caller that passes many distinct
-// buffers cannot accumulate page-locked memory; a range that overlaps a new one is dropped first (the caller freed
-// and re-allocated there).  The caller must keep a registered buffer mapped until rpm_destroy or until it has been
-// evicted (rpm_hip.h, option "pin_host").  Returns the device-visible alias of `ptr`, or nullptr when it is not pinned.
-static int g_pin_unreg_fail = 0, g_pin_reg_fail = 0, g_pin_reg_ok = 0;   // process-wide diagnostics (rpm_get_option "pin_*")
-int dev_pin_counter(int which) { return which == 0 ? g_pin_reg_ok : (which == 1 ? g_pin_reg_fail : g_pin_unreg_fail); }
-static void pin_release(const void* ptr) {
-  if (hipHostUnregister(const_cast<void*>(ptr)) != hipSuccess) { ++g_pin_unreg_fail; (void)hipGetLastError(); }
-}
-// rpm_set_option "pin_host" 0: every registration goes (a caller about to unmap its arrays — e.g. a shared segment — turns the
-// option off first)
-void dev_pin_release_all(Engine& e) {
-  if (!e.dev) return;
-  for (auto& p : e.dev->pinned) pin_release(p.ptr);
-  e.dev->pinned.clear();
-  (void)hipGetLastError();
+// Page-locked caller arrays (option "pin_host", off unless the caller asks: RpmTNLP does for Ipopt's arrays).  The table
+// of registrations is NOT the engine's: hipHostRegister is process-wide and page-granular, so all engines of all libraries
+// of the process share the one registry of librpm_pin.so (rpm_pin.cpp: page-aligned, disjoint, reference-counted, every
+// refusal counted and kept for rpm_last_error).  An engine holds at most PIN_MAX registrations (least recently used goes
+// first) and lets go of all of them in rpm_destroy or when the option is set to 0.  Returns the device-visible alias of
+// `ptr`, or nullptr when the array is not page-locked (option off, below RPM_PIN_MIN_BYTES, refused) — the caller of this
+// function then goes through the engine's own staging buffers, never through the runtime's pageable-copy path.
+constexpr int PIN_MAX = 8;
+long dev_pin_counter(int which) { return rpm_pin_counter(which); }
+int dev_pin_held(const Engine& e) { return rpm_pin_held(&e); }
+void dev_pin_release_all(Engine& e) { rpm_pin_release_owner(&e); }
+std::string dev_pin_last_error() {
+  char buf[320];
+  buf[0] = 0;
+  rpm_pin_last_error(buf, sizeof buf);
+  return buf;
 }
 void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
-  constexpr size_t PIN_MAX = 8;
-  if (!e.opt_pin_host || !ptr || bytes == 0) return nullptr;   // small arrays too: a pageable copy costs ~20 us each way
+  if (!e.opt_pin_host || !ptr || bytes < RPM_PIN_MIN_BYTES) return nullptr;
+  const long refused = rpm_pin_counter(RPM_PIN_REGISTER_FAILURES) + rpm_pin_counter(RPM_PIN_OVERLAP_REFUSED);
+  void* alias = rpm_pin_acquire(&e, ptr, bytes, PIN_MAX);
+  if (!alias && rpm_pin_counter(RPM_PIN_REGISTER_FAILURES) + rpm_pin_counter(RPM_PIN_OVERLAP_REFUSED) != refused)
+    e.pin_note = dev_pin_last_error();   // the call goes on through the staging buffers; the reason stays readable
+  return alias;
+}
+
+// ---- the engine's own page-locked staging buffers (hipHostMalloc, mapped) -----------------------------------------------
+// Caller arrays that are not registered never reach the HIP runtime: inputs are copied by the CPU into a staging buffer
+// the engine owns (the kernels read it in place or a copy engine moves it on), results land in one and are copied out by
+// the CPU after the call's synchronisation.  The runtime's pageable-copy path would lock the caller's pages itself and
+// keep that lock cached past the call.
+int dev_stage_reserve(Engine& e, int slot, size_t count, double** host, double** alias) {
   Device& d = *e.dev;
-  const char* lo = static_cast<const char*>(ptr);
-  for (size_t i = 0; i < d.pinned.size(); ++i)
-    if (d.pinned[i].ptr == ptr && d.pinned[i].bytes >= bytes) {
-      Device::Pinned hit = d.pinned[i];
-      d.pinned.erase(d.pinned.begin() + i);
-      d.pinned.push_back(hit);            // most recently used last
-      return hit.dptr;
-    }
-  for (size_t i = 0; i < d.pinned.size();) {   // overlapping older registration: the range was re-allocated
-    const char* plo = static_cast<const char*>(d.pinned[i].ptr);
-    if (lo < plo + d.pinned[i].bytes && plo < lo + bytes) {
-      pin_release(d.pinned[i].ptr);
-      d.pinned.erase(d.pinned.begin() + i);
-    } else {
-      ++i;
-    }
+  Device::Stage& s = d.stage[slot];
+  if (s.busy || s.cap < count) {   // a queued copy still reads the slot, or it has to grow
+    HIP_TRY(e, hipStreamSynchronize(d.stream));
+    dev_stage_synced(e);
   }
-  while (d.pinned.size() >= PIN_MAX) {
-    pin_release(d.pinned.front().ptr);
-    d.pinned.erase(d.pinned.begin());
+  if (s.cap < count) {
+    if (s.h) HIP_TRY(e, hipHostFree(s.h));
+    s.h = s.d = nullptr;
+    s.cap = 0;
+    const size_t cap = count + count / 4 + 64;
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&s.h), cap * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&s.d), s.h, 0));
+    s.cap = cap;
   }
-  if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
-    (void)hipGetLastError();
-    ++g_pin_reg_fail;
-    return nullptr;
+  *host = s.h;
+  if (alias) *alias = s.d;
+  return RPM_OK;
+}
+void dev_stage_synced(Engine& e) {
+  if (!e.dev) return;
+  for (Device::Stage& s : e.dev->stage) s.busy = false;
+}
+void dev_stage_destroy(Device* d) {
+  for (Device::Stage& s : d->stage) {
+    if (s.h) (void)hipHostFree(s.h);
+    s = Device::Stage{};
   }
-  ++g_pin_reg_ok;
-  void* dptr = nullptr;
-  if (hipHostGetDevicePointer(&dptr, const_cast<void*>(ptr), 0) != hipSuccess) {
-    (void)hipGetLastError();
-    dptr = nullptr;
+}
+// host -> HBM through the staging slot (synchronous with respect to the caller's array: it may be reused on return)
+int dev_stage_upload(Engine& e, int slot, double* dev, const double* host, size_t count) {
+  if (count == 0) return RPM_OK;
+  if (dev_pin_host(e, host, count * sizeof(double))) {   // registered: the copy engine reads the caller's pages
+    HIP_TRY(e, hipMemcpyAsync(dev, host, count * sizeof(double), hipMemcpyHostToDevice, e.dev->stream));
+    HIP_TRY(e, hipStreamSynchronize(e.dev->stream));     // the caller may reuse its array on return
+    dev_stage_synced(e);
+    return RPM_OK;
   }
-  d.pinned.push_back(Device::Pinned{ptr, bytes, dptr});
-  return dptr;
+  double* h = nullptr;
+  int rc = dev_stage_reserve(e, slot, count, &h, nullptr);
+  if (rc) return rc;
+  std::memcpy(h, host, count * sizeof(double));
+  HIP_TRY(e, hipMemcpyAsync(dev, h, count * sizeof(double), hipMemcpyHostToDevice, e.dev->stream));
+  e.dev->stage[slot].busy = true;
+  return RPM_OK;
+}
+// HBM -> host through the staging slot; returns after the data is in the caller's array
+int dev_stage_download(Engine& e, int slot, double* host, const double* dev, size_t count) {
+  if (count == 0) return RPM_OK;
+  if (dev_pin_host(e, host, count * sizeof(double))) {
+    HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e.dev->stream));
+    HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+    dev_stage_synced(e);
+    return RPM_OK;
+  }
+  double* h = nullptr;
+  int rc = dev_stage_reserve(e, slot, count, &h, nullptr);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(h, dev, count * sizeof(double), hipMemcpyDeviceToHost, e.dev->stream));
+  HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+  dev_stage_synced(e);
+  std::memcpy(host, h, count * sizeof(double));
+  return RPM_OK;
 }
 
 // ---- small helpers used by the C ABI (rpm_abi.cpp) ---------------------------------------------
@@ -478,18 +507,14 @@ int dev_upload_x(Engine& e, const double* x) {
     if (rc) return rc;
   }
   HIP_TRY(e, hipSetDevice(e.dev->device_id));
-  HIP_TRY(e, hipMemcpyAsync(e.dev->d_x, x, size_t(e.n_instances) * e.n * sizeof(double), hipMemcpyHostToDevice,
-                            e.dev->stream));
-  return RPM_OK;
+  return dev_stage_upload(e, STAGE_X, e.dev->d_x, x, size_t(e.n_instances) * e.n);
 }
-int dev_download(Engine& e, double* host, const double* dev, size_t count) {
-  HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e.dev->stream));
-  HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
-  return RPM_OK;
+// `host` is a caller's array: through the page-lock registry or the staging slot, never the runtime's pageable path
+int dev_download(Engine& e, double* host, const double* dev, size_t count, int slot) {
+  return dev_stage_download(e, slot, host, dev, count);
 }
-int dev_upload(Engine& e, double* dev, const double* host, size_t count) {
-  HIP_TRY(e, hipMemcpyAsync(dev, host, count * sizeof(double), hipMemcpyHostToDevice, e.dev->stream));
-  return RPM_OK;
+int dev_upload(Engine& e, double* dev, const double* host, size_t count, int slot) {
+  return dev_stage_upload(e, slot, dev, host, count);
 }
 int dev_update_instance_constants(Engine& e) {
   if (!e.dev || e.inst_consts.empty()) return RPM_OK;
@@ -500,13 +525,14 @@ int dev_update_instance_constants(Engine& e) {
   HIP_TRY(e, hipMemcpy(d.d_inst_consts, e.inst_consts.data(), count * sizeof(double), hipMemcpyHostToDevice));
   d.kp.consts = d.d_inst_consts;
   d.kp.consts_stride = int(e.consts.size());
-  d.cache_valid = false;
+  host_new_x(e);   // constraint pair, objective and gradient cached under the old constants are gone
   return RPM_OK;
 }
 
 int dev_sync(Engine& e) {
   if (!e.dev) return RPM_OK;
   HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+  dev_stage_synced(e);
   return RPM_OK;
 }
 double* dev_buf(Engine& e, int which) {

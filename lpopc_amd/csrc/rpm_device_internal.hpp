@@ -77,8 +77,10 @@ struct Device {
          *d_lambda = nullptr, *d_hess = nullptr;
   double* d_partial = nullptr;  // objective partial sums
   int* d_flag = nullptr;        // non-finite flag of the host-pointer path
-  struct Pinned { const void* ptr; size_t bytes; void* dptr; };
-  std::vector<Pinned> pinned;   // caller buffers registered with hipHostRegister (LRU order, capped), with their device aliases
+  // page-locked staging buffers the engine owns (hipHostMalloc, mapped): caller arrays that are not registered
+  // ("pin_host" off, small, refused) are copied through these by the CPU and never reach the HIP runtime
+  struct Stage { double* h = nullptr; double* d = nullptr; size_t cap = 0; bool busy = false; };   // busy: a queued H2D copy still reads it
+  Stage stage[STAGE_SLOTS];
   bool cache_valid = false;     // d_g / d_values hold the pair of the x last uploaded
   size_t lds_bytes = 0;
   int pl_slots = 0;             // resident workgroups the pipelined kernel is launched with (2 per CU)
@@ -151,6 +153,14 @@ inline hipError_t upload(T** dst, const std::vector<T>& src) {
 
 
 void host_path_destroy(Device* d);   // rpm_host_path.hip
+// rpm_device.hip: staging slots (see Device::Stage)
+int dev_stage_reserve(Engine& e, int slot, size_t count, double** host, double** alias);
+int dev_stage_upload(Engine& e, int slot, double* dev, const double* host, size_t count);
+int dev_stage_download(Engine& e, int slot, double* host, const double* dev, size_t count);
+void dev_stage_destroy(Device* d);
+void host_new_x(Engine& e);
+void dev_stage_synced(Engine& e);    // the engine's stream was synchronised: every staging slot may be overwritten
+std::string dev_pin_last_error();
 void exchange_destroy(Device* d);    // rpm_peer.hip
 
 // rpm_tile_kernels.hip: occupancy, LDS size and eligibility of the pipelined kernel for this engine (device_init)

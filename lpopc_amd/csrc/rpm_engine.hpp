@@ -117,6 +117,9 @@ struct PhaseHost {
   int var0 = 0, con0 = 0, nvar = 0, ncon = 0;
 };
 
+// page-locked staging slots of an engine (Device::Stage): caller arrays that are not registered go through these
+enum { STAGE_X = 0, STAGE_G, STAGE_V, STAGE_GRAD, STAGE_LAMBDA, STAGE_HESS, STAGE_SLOTS };
+
 struct Device;  // HIP-side state, defined in rpm_device.hip
 
 struct Engine {
@@ -165,7 +168,8 @@ struct Engine {
   int opt_pipeline = -1;         // rpm_tile_pl_kernel: -1 automatic (>= 2 tiles per resident workgroup), 0 never, 1 whenever the mesh fits
   int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
   const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)
-  int opt_pin_host = 1;          // hipHostRegister the caller's x / g / values buffers on first use
+  int opt_pin_host = 0;          // 1: page-lock the caller's x / g / values arrays through the process-wide registry (librpm_pin.so); opt-in
+  std::string pin_note;          // why the last registration this engine asked for was refused (shown by rpm_last_error after the reason of a failed call)
   int opt_zero_copy = 1;         // host-pointer path: the kernel reads x from / stores g into the caller's page-locked arrays
   int opt_delta_values = 0;      // host-pointer path: deliver only the runs of `values` that changed since the last delivery into the same array
   int last_delta_total = 0;      // runs of `values` this engine owns (rpm_get_option "delta_total_runs")
@@ -179,6 +183,7 @@ struct Engine {
   std::vector<MeshErrTables> mesh_err;            // built on first use, per phase
   // state
   std::string err;
+  std::string err_report;   // what rpm_last_error hands out when the registry has something to add
   Device* dev = nullptr;
 };
 
@@ -250,8 +255,8 @@ int host_eval_pair(Engine& e, const double* x, double* g, double* values);
 int host_delta_sent_runs(Engine& e, int* sent);   // runs delivered since the previous query
 int dev_pipeline_active(const Engine& e);   // 1 when the next constraint launch uses rpm_tile_pl_kernel
 int dev_upload_x(Engine& e, const double* x);
-int dev_upload(Engine& e, double* dev, const double* host, size_t count);
-int dev_download(Engine& e, double* host, const double* dev, size_t count);
+int dev_upload(Engine& e, double* dev, const double* host, size_t count, int slot);    // slot: STAGE_* (rpm_device_internal.hpp)
+int dev_download(Engine& e, double* host, const double* dev, size_t count, int slot);
 int dev_sync(Engine& e);
 int dev_update_instance_constants(Engine& e);   // (re)uploads e.inst_consts and points the kernels at it
 double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 lambda, 6 hess
@@ -259,11 +264,10 @@ bool& dev_cache_valid(Engine& e);
 void* dev_stream(Engine& e);
 int dev_nonfinite(Engine& e, const double* dev, size_t count);   // 1 if a NaN/Inf is present, checked on the device
 int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b, size_t nb);   // asynchronous form, flag words 0 / 1
-int dev_flags_fetch(Engine& e);
 int dev_flag_value(Engine& e, int slot);
-int dev_download_enqueue(Engine& e, double* host, const double* dev, size_t count);
-int dev_pin_counter(int which);   // process-wide: 0 registrations made, 1 registrations refused, 2 unregistrations refused
-void* dev_pin_host(Engine& e, const void* ptr, size_t bytes);      // page-lock a caller buffer once (best effort); its device alias or nullptr
-void dev_pin_release_all(Engine& e);   // drop every page-locked registration (rpm_set_option "pin_host" 0)
+long dev_pin_counter(int which);  // process-wide counters of librpm_pin.so (RPM_PIN_*, rpm_pin.h)
+int dev_pin_held(const Engine& e);                                 // registrations this engine holds
+void* dev_pin_host(Engine& e, const void* ptr, size_t bytes);      // "pin_host": the array's device alias once its pages are registered, else nullptr
+void dev_pin_release_all(Engine& e);   // let go of every registration this engine holds (rpm_set_option "pin_host" 0, rpm_destroy)
 
 }  // namespace rpm

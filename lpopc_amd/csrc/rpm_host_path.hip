@@ -5,8 +5,12 @@
 // one queue operation + hipStreamSynchronize 10.2 us, PCIe 57 GB/s marginal for a copy-engine D2H (47.9 GB/s at the
 // NL prefix's 3.1 MB), 46 GB/s for stores a kernel makes straight into page-locked host memory.
 //
-//   * x is read by the tile kernel straight from the caller's page-locked array, g is stored straight into the
-//     caller's page-locked array (no copy operations, ONE launch + ONE synchronisation per rpm_eval_g);
+//   * transport of the caller's arrays: with option "pin_host" (RpmTNLP turns it on for Ipopt's arrays) their pages are
+//     registered once in the process-wide table of librpm_pin.so and the device addresses them; otherwise — the default —
+//     the CPU copies x into, and g / values out of, page-locked staging buffers this engine owns.  Caller memory that is
+//     not registered never reaches the HIP runtime (its pageable-copy path would lock the pages itself and cache the lock);
+//   * x is read by the tile kernel straight from the page-locked array (the caller's or the staging copy), g is stored
+//     straight into it (no copy-engine operations, ONE launch + ONE synchronisation per rpm_eval_g);
 //   * NaN/Inf detection is fused into the kernel that produces the values (K.chk; two host-visible words);
 //   * the Jacobian of the same x is produced by the same launch into HBM (fused pair) and delivered by
 //     rpm_eval_jac_g(new_x = 0) either by one copy-engine transfer (default; option "const_once": NL prefix only) or,
@@ -66,6 +70,11 @@ struct HostPath {
   double* h_obj = nullptr;
   double* d_obj_alias = nullptr;
   bool obj_valid = false;                  // h_obj and the engine's gradient buffer hold f and grad f of the current x
+  // "const_once": 16 sampled entries of the linear / constant tail as this engine left them in the caller's array
+  std::vector<unsigned long long> tail_val;
+  // results waiting in staging slots for the call's synchronisation: then copied into the caller's arrays by the CPU
+  struct CopyOut { double* dst; const double* src; size_t count; };
+  std::vector<CopyOut> pending;
 };
 
 static HostPath& host_path(Engine& e) {
@@ -82,6 +91,55 @@ void host_path_destroy(Device* d) {
   if (h->h_obj) (void)hipHostFree(h->h_obj);
   delete h;
   d->host_path = nullptr;
+}
+
+// the call's one synchronisation, then the CPU half of the staged deliveries
+static int sync_and_deliver(Engine& e) {
+  HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+  dev_stage_synced(e);
+  HostPath& h = host_path(e);
+  for (const HostPath::CopyOut& c : h.pending) std::memcpy(c.dst, c.src, c.count * sizeof(double));
+  h.pending.clear();
+  return RPM_OK;
+}
+
+// x for a kernel: the caller's registered array, or the staging copy (read in place with "zero_copy", else moved to HBM)
+static int stage_x_in(Engine& e, const double* x, const double** xa) {
+  Device& d = *e.dev;
+  const size_t count = size_t(e.n_instances) * e.n;
+  void* alias = dev_pin_host(e, x, count * sizeof(double));
+  if (alias && e.opt_zero_copy) { *xa = static_cast<const double*>(alias); return RPM_OK; }
+  if (alias) {
+    HIP_TRY(e, hipMemcpyAsync(d.d_x, x, count * sizeof(double), hipMemcpyHostToDevice, d.stream));
+    *xa = d.d_x;
+    return RPM_OK;
+  }
+  double *hx = nullptr, *ax = nullptr;
+  int rc = dev_stage_reserve(e, STAGE_X, count, &hx, &ax);
+  if (rc) return rc;
+  std::memcpy(hx, x, count * sizeof(double));
+  d.stage[STAGE_X].busy = true;
+  if (e.opt_zero_copy) { *xa = ax; return RPM_OK; }
+  HIP_TRY(e, hipMemcpyAsync(d.d_x, hx, count * sizeof(double), hipMemcpyHostToDevice, d.stream));
+  *xa = d.d_x;
+  return RPM_OK;
+}
+
+// queue the delivery of `count` doubles at dev into the caller's array `host`: straight by the copy engine when the
+// array is registered, else into the staging slot (+ a CPU copy after the synchronisation)
+static int stage_out(Engine& e, int slot, double* host, const double* dev, size_t count) {
+  Device& d = *e.dev;
+  if (count == 0) return RPM_OK;
+  if (dev_pin_host(e, host, count * sizeof(double))) {
+    HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+    return RPM_OK;
+  }
+  double* h = nullptr;
+  int rc = dev_stage_reserve(e, slot, count, &h, nullptr);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(h, dev, count * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  host_path(e).pending.push_back(HostPath::CopyOut{host, h, count});
+  return RPM_OK;
 }
 
 static int ensure_flags(Engine& e) {
@@ -186,28 +244,40 @@ static int enqueue_cons(Engine& e, const double* x, double* g, bool with_g, bool
   Device& d = *e.dev;
   const size_t B = size_t(e.n_instances);
   HIP_TRY(e, hipSetDevice(d.device_id));
+  host_path(e).pending.clear();   // a call that failed half-way leaves nothing behind
   const bool zc = e.opt_zero_copy != 0;
-  const double* xa = zc ? static_cast<const double*>(dev_pin_host(e, x, B * e.n * sizeof(double))) : nullptr;
-  if (!xa) {
-    if (!zc) (void)dev_pin_host(e, x, B * e.n * sizeof(double));
-    HIP_TRY(e, hipMemcpyAsync(d.d_x, x, B * e.n * sizeof(double), hipMemcpyHostToDevice, d.stream));
-    xa = d.d_x;
+  const bool sharded = e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1;
+  if (with_g && sharded && !dev_pin_host(e, g, B * e.m * sizeof(double))) {
+    e.err = "host-pointer delivery of an interval-sharded engine needs option pin_host = 1 and a registrable g array (each rank stores only its own rows)";
+    if (!e.pin_note.empty()) e.err += "; " + e.pin_note;
+    return RPM_E_UNSUPPORTED;
   }
+  const double* xa = nullptr;
+  int rc = stage_x_in(e, x, &xa);
+  if (rc) return rc;
   const bool fused_chk = e.opt_check_finite && dev_cons_is_one_role(e);
-  double* ga = nullptr;
-  if (with_g) {
-    void* alias = dev_pin_host(e, g, B * e.m * sizeof(double));
-    if (zc && alias && (fused_chk || !e.opt_check_finite)) ga = static_cast<double*>(alias);
+  double* ga = nullptr;            // where the kernel stores g when it can store it in page-locked host memory
+  if (with_g && zc && (fused_chk || !e.opt_check_finite)) {
+    ga = static_cast<double*>(dev_pin_host(e, g, B * e.m * sizeof(double)));
+    if (!ga) {                     // not registered: the kernel stores into the staging slot, the CPU copies it out
+      double* hg = nullptr;
+      rc = dev_stage_reserve(e, STAGE_G, B * e.m, &hg, &ga);
+      if (rc) return rc;
+      host_path(e).pending.push_back(HostPath::CopyOut{g, hg, B * e.m});
+    }
   }
   if (e.opt_check_finite) {
-    int rc = ensure_flags(e);
+    rc = ensure_flags(e);
     if (rc) return rc;
     d.h_flags2[0] = d.h_flags2[1] = 0;   // the previous verdicts were read after their synchronisation
   }
   const int flags = (with_g ? 1 : 0) | (with_jac ? 2 : 0) | (fused_chk ? 8 : 0);
-  int rc = dev_eval_cons(e, xa, ga ? ga : d.d_g, d.d_values, flags, d.stream);
+  rc = dev_eval_cons(e, xa, ga ? ga : d.d_g, d.d_values, flags, d.stream);
   if (rc) return rc;
-  if (with_g && !ga) HIP_TRY(e, hipMemcpyAsync(g, d.d_g, B * e.m * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  if (with_g && !ga) {
+    rc = stage_out(e, STAGE_G, g, d.d_g, B * e.m);
+    if (rc) return rc;
+  }
   if (e.opt_check_finite && !fused_chk) {
     rc = dev_nonfinite_enqueue(e, d.d_g, with_g ? B * e.m : 0, d.d_values, with_jac ? B * size_t(e.nnz_jac) : 0);
     if (rc) return rc;
@@ -220,16 +290,31 @@ static int ensure_device(Engine& e) {
   return device_init(e, 0);
 }
 
+// Every registration a call needs is made BEFORE its first launch: making one may replace or let go of another of this
+// engine's registrations (arrays sharing a page are merged, the least recently used goes at the cap), which must not
+// happen under a kernel that is storing through it.  Every entry point ends with a synchronisation, so nothing of this
+// engine is in flight here; the later dev_pin_host calls of the same call only look the aliases up.
+static void acquire_registrations(Engine& e, const double* x, const double* g, const double* values, const double* grad) {
+  if (!e.opt_pin_host) return;
+  const size_t B = size_t(e.n_instances);
+  if (x) (void)dev_pin_host(e, x, B * e.n * sizeof(double));
+  if (g) (void)dev_pin_host(e, g, B * e.m * sizeof(double));
+  if (values) (void)dev_pin_host(e, values, B * e.nnz_jac * sizeof(double));
+  if (grad) (void)dev_pin_host(e, grad, B * e.n * sizeof(double));
+}
+
 int host_eval_g(Engine& e, const double* x, int new_x, double* g) {
   int rc = ensure_device(e);
   if (rc) return rc;
   Device& d = *e.dev;
   if (new_x) host_new_x(e);
   d.cache_valid = false;
+  acquire_registrations(e, x, g, nullptr, nullptr);
   const bool pair = e.opt_fuse_pair != 0;   // the Jacobian of the same x comes out of the same launch
   rc = enqueue_cons(e, x, g, true, pair);
   if (rc) return rc;
-  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  rc = sync_and_deliver(e);
+  if (rc) return rc;
   d.cache_valid = pair;
   e.jac_nonfinite = -1;
   if (e.opt_check_finite) {
@@ -240,6 +325,28 @@ int host_eval_g(Engine& e, const double* x, int new_x, double* g) {
     }
   }
   return RPM_OK;
+}
+
+// "const_once" trusts the tail of an array only if it is the array this engine filled last AND 16 sampled tail entries
+// still hold what it stored there (an array freed and re-allocated at the same address does not pass)
+static size_t tail_pos(const Engine& e, int k) {
+  const size_t tail = size_t(e.nnz_jac) - size_t(e.nnz_nl);
+  return size_t(e.nnz_nl) + (tail > 1 ? size_t(k) * (tail - 1) / 15 : 0);
+}
+static bool tail_untouched(Engine& e, const double* values) {
+  HostPath& h = host_path(e);
+  if (e.nnz_jac <= e.nnz_nl || h.tail_val.size() != 16) return false;
+  const unsigned long long* hv = reinterpret_cast<const unsigned long long*>(values);
+  for (int k = 0; k < 16; ++k)
+    if (hv[tail_pos(e, k)] != h.tail_val[k]) return false;
+  return true;
+}
+static void tail_remember(Engine& e, const double* values) {
+  HostPath& h = host_path(e);
+  h.tail_val.clear();
+  if (!e.opt_const_once || e.n_instances != 1 || e.nnz_jac <= e.nnz_nl) return;
+  const unsigned long long* hv = reinterpret_cast<const unsigned long long*>(values);
+  for (int k = 0; k < 16; ++k) h.tail_val.push_back(hv[tail_pos(e, k)]);
 }
 
 // queue the delivery of the staged Jacobian values into `values`; *delta = the delivery needs delta_commit afterwards
@@ -259,9 +366,8 @@ static int enqueue_values(Engine& e, double* values, bool* delta) {
   // values = [NL | LIN | CONST]: with "const_once" the constant tail (54 % of the entries at the metric problem) crosses
   // PCIe only when the caller hands a buffer this engine did not fill last time
   size_t count = B * e.nnz_jac;
-  if (e.opt_const_once && e.n_instances == 1 && values == e.const_filled) count = size_t(e.nnz_nl);
-  HIP_TRY(e, hipMemcpyAsync(values, d.d_values, count * sizeof(double), hipMemcpyDeviceToHost, d.stream));
-  return RPM_OK;
+  if (e.opt_const_once && e.n_instances == 1 && values == e.const_filled && tail_untouched(e, values)) count = size_t(e.nnz_nl);
+  return stage_out(e, STAGE_V, values, d.d_values, count);
 }
 
 int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values) {
@@ -270,6 +376,8 @@ int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values) 
   Device& d = *e.dev;
   if (new_x) host_new_x(e);
   const bool cached = !new_x && d.cache_valid;
+  host_path(e).pending.clear();
+  acquire_registrations(e, cached ? nullptr : x, nullptr, values, nullptr);
   if (!cached) {
     d.cache_valid = false;
     rc = enqueue_cons(e, x, nullptr, false, true);
@@ -279,10 +387,16 @@ int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values) 
   bool delta = false;
   rc = enqueue_values(e, values, &delta);
   if (rc) return rc;
-  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  rc = sync_and_deliver(e);
+  if (rc) return rc;
   if (delta) delta_commit(e, values);
   e.const_filled = values;
+  tail_remember(e, values);
   if (e.opt_check_finite) {
+    if (cached && e.jac_nonfinite < 0) {   // the cached pair was produced with "check_finite" off: scan it now
+      e.jac_nonfinite = dev_nonfinite(e, d.d_values, size_t(e.n_instances) * e.nnz_jac);
+      if (e.jac_nonfinite < 0) { e.err = "eval_jac_g: the NaN/Inf scan failed"; return RPM_E_DEVICE; }
+    }
     const int bad = cached ? e.jac_nonfinite : d.h_flags2[1];
     if (bad != 0) {
       e.err = "eval_jac_g: non-finite Jacobian value";
@@ -311,13 +425,11 @@ static int enqueue_obj(Engine& e, const double* x) {
     HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&h.h_obj), B * sizeof(double), hipHostMallocMapped));
     HIP_TRY(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&h.d_obj_alias), h.h_obj, 0));
   }
-  const double* xa = e.opt_zero_copy ? static_cast<const double*>(dev_pin_host(e, x, B * e.n * sizeof(double))) : nullptr;
-  if (!xa) {
-    if (!e.opt_zero_copy) (void)dev_pin_host(e, x, B * e.n * sizeof(double));
-    HIP_TRY(e, hipMemcpyAsync(d.d_x, x, B * e.n * sizeof(double), hipMemcpyHostToDevice, d.stream));
-    xa = d.d_x;
-  }
-  int rc = ensure_flags(e);
+  host_path(e).pending.clear();
+  const double* xa = nullptr;
+  int rc = stage_x_in(e, x, &xa);
+  if (rc) return rc;
+  rc = ensure_flags(e);
   if (rc) return rc;
   d.h_flags2[3] = 0;
   return dev_eval_obj(e, xa, h.d_obj_alias, d.d_grad, d.stream, e.opt_check_finite != 0);
@@ -329,9 +441,11 @@ int host_eval_f(Engine& e, const double* x, int new_x, double* obj) {
   if (new_x) host_new_x(e);
   HostPath& h = host_path(e);
   if (!h.obj_valid) {
+    acquire_registrations(e, x, nullptr, nullptr, nullptr);
     rc = enqueue_obj(e, x);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e.dev->stream));
+    rc = sync_and_deliver(e);
+    if (rc) return rc;
     h.obj_valid = true;
   }
   for (int b = 0; b < e.n_instances; ++b) obj[b] = h.h_obj[b];
@@ -347,14 +461,16 @@ int host_eval_grad_f(Engine& e, const double* x, int new_x, double* grad) {
   if (new_x) host_new_x(e);
   HostPath& h = host_path(e);
   Device& d = *e.dev;
+  acquire_registrations(e, h.obj_valid ? nullptr : x, nullptr, nullptr, grad);
   if (!h.obj_valid) {
     rc = enqueue_obj(e, x);
     if (rc) return rc;
   }
   const size_t count = size_t(e.n_instances) * e.n;
-  (void)dev_pin_host(e, grad, count * sizeof(double));
-  HIP_TRY(e, hipMemcpyAsync(grad, d.d_grad, count * sizeof(double), hipMemcpyDeviceToHost, d.stream));
-  HIP_TRY(e, hipStreamSynchronize(d.stream));
+  rc = stage_out(e, STAGE_GRAD, grad, d.d_grad, count);
+  if (rc) return rc;
+  rc = sync_and_deliver(e);
+  if (rc) return rc;
   h.obj_valid = true;
   if (e.opt_check_finite && d.h_flags2[3] != 0) { e.err = "eval_grad_f: non-finite gradient"; return RPM_E_NONFINITE; }
   return RPM_OK;
@@ -365,14 +481,17 @@ int host_eval_pair(Engine& e, const double* x, double* g, double* values) {
   if (rc) return rc;
   Device& d = *e.dev;
   host_new_x(e);
+  acquire_registrations(e, x, g, values, nullptr);
   rc = enqueue_cons(e, x, g, true, true);
   if (rc) return rc;
   bool delta = false;
   rc = enqueue_values(e, values, &delta);
   if (rc) return rc;
-  HIP_TRY(e, hipStreamSynchronize(d.stream));   // the one synchronisation of the pair
+  rc = sync_and_deliver(e);                     // the one synchronisation of the pair
+  if (rc) return rc;
   if (delta) delta_commit(e, values);
   e.const_filled = values;
+  tail_remember(e, values);
   d.cache_valid = true;
   e.jac_nonfinite = -1;
   if (e.opt_check_finite) {

@@ -384,9 +384,13 @@ int rpm_ipm_set_bounds(rpm_ipm* h, int instance, const double* x_l, const double
       h->err = "rpm_ipm_set_bounds: variable " + std::to_string(i) + " changes between fixed and free (the KKT layout is shared by all instances)";
       return RPM_E_INVALID;
     }
-  IPM_TRY(h, hipMemcpy(h->D.vl0 + size_t(instance) * p.nv, x_l, p.n * sizeof(double), hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy(h->D.vu0 + size_t(instance) * p.nv, x_u, p.n * sizeof(double), hipMemcpyHostToDevice));
-  return RPM_OK;
+  // caller arrays go through the engine's staging slots (rpm_device.hip), not the runtime's pageable-copy path
+  Engine& e = h->eng->e;
+  int rc = dev_upload(e, h->D.vl0 + size_t(instance) * p.nv, x_l, size_t(p.n), STAGE_X);
+  if (!rc) rc = dev_upload(e, h->D.vu0 + size_t(instance) * p.nv, x_u, size_t(p.n), STAGE_G);
+  if (!rc) rc = dev_sync(e);
+  if (rc) h->err = e.err;
+  return rc;
 }
 
 /* variable bounds of all instances at once: x_l, x_u are n_instances x n (host), e.g. the measured initial states of a
@@ -402,10 +406,19 @@ int rpm_ipm_set_all_bounds(rpm_ipm* h, const double* x_l, const double* x_u) {
                  " changes between fixed and free (the KKT layout is shared by all instances)";
         return RPM_E_INVALID;
       }
-  IPM_TRY(h, hipMemcpy2D(h->D.vl0, size_t(p.nv) * sizeof(double), x_l, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
-                         hipMemcpyHostToDevice));
-  IPM_TRY(h, hipMemcpy2D(h->D.vu0, size_t(p.nv) * sizeof(double), x_u, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
-                         hipMemcpyHostToDevice));
+  Engine& e = h->eng->e;
+  hipStream_t st = static_cast<hipStream_t>(dev_stream(e));
+  double *sl = nullptr, *su = nullptr;
+  int rc = dev_stage_reserve(e, STAGE_X, B * p.n, &sl, nullptr);
+  if (!rc) rc = dev_stage_reserve(e, STAGE_G, B * p.n, &su, nullptr);
+  if (rc) { h->err = e.err; return rc; }
+  std::memcpy(sl, x_l, B * p.n * sizeof(double));
+  std::memcpy(su, x_u, B * p.n * sizeof(double));
+  IPM_TRY(h, hipMemcpy2DAsync(h->D.vl0, size_t(p.nv) * sizeof(double), sl, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
+                              hipMemcpyHostToDevice, st));
+  IPM_TRY(h, hipMemcpy2DAsync(h->D.vu0, size_t(p.nv) * sizeof(double), su, size_t(p.n) * sizeof(double), size_t(p.n) * sizeof(double), B,
+                              hipMemcpyHostToDevice, st));
+  IPM_TRY(h, hipStreamSynchronize(st));
   return RPM_OK;
 }
 
@@ -610,14 +623,19 @@ int rpm_ipm_solve(rpm_ipm* h, double* x, double* lambda, double* obj, int* statu
     h->err = "hipMalloc";
     return RPM_E_DEVICE;
   }
-  int rc = RPM_OK;
-  if (hipMemcpy(d_x, x, size_t(D.B) * p.n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = RPM_E_DEVICE;
-  if (!rc) rc = rpm_ipm_solve_dev(h, d_x, d_l, obj, status, iterations, kkt_error, nullptr);   // blocking copies above: nothing in flight
-  if (!rc && hipMemcpy(x, d_x, size_t(D.B) * p.n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RPM_E_DEVICE;
-  if (!rc && lambda && hipMemcpy(lambda, d_l, size_t(D.B) * p.m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RPM_E_DEVICE;
+  // x / lambda are the caller's arrays: through the engine's staging slots (or its page-lock registrations)
+  Engine& e = h->eng->e;
+  int rc = dev_upload(e, d_x, x, size_t(D.B) * p.n, STAGE_X);
+  if (!rc) rc = dev_sync(e);                                                                   // nothing in flight when the solve starts
+  if (rc) h->err = e.err;
+  if (!rc) rc = rpm_ipm_solve_dev(h, d_x, d_l, obj, status, iterations, kkt_error, nullptr);
+  if (!rc) {
+    rc = dev_download(e, x, d_x, size_t(D.B) * p.n, STAGE_X);
+    if (!rc && lambda) rc = dev_download(e, lambda, d_l, size_t(D.B) * p.m, STAGE_LAMBDA);
+    if (rc) h->err = e.err;
+  }
   (void)hipFree(d_x);
   (void)hipFree(d_l);
-  if (rc == RPM_E_DEVICE && h->err.empty()) h->err = "hip copy failed";
   return rc;
 }
 

@@ -242,8 +242,8 @@ int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, doub
   double* o_scal = o_lag + M;          // [0] mayer, [1] lagrange cost
   double* u_end = o_scal + 8;
   double* pm_end = u_end + nu;
-  int rc = dev_upload(e, d.d_x, x, size_t(e.n));
-  if (rc == RPM_OK) rc = dev_upload(e, d.d_lambda, lambda, size_t(e.m));
+  int rc = dev_upload(e, d.d_x, x, size_t(e.n), STAGE_X);
+  if (rc == RPM_OK) rc = dev_upload(e, d.d_lambda, lambda, size_t(e.m), STAGE_LAMBDA);
   hipError_t s = hipSuccess;
   if (rc == RPM_OK) {
     hipStream_t st = d.stream;
@@ -263,8 +263,8 @@ int dev_nlp2op(Engine& e, int phase, const double* x, const double* lambda, doub
     hipLaunchKernelGGL(rpm_post_cost_kernel, dim3(1), dim3(256), 0, st, d.kp, phase, d.d_x, o_lag, o_scal + 1);
     s = hipGetLastError();
     if (s == hipSuccess) s = hipStreamSynchronize(st);
-    auto get = [&](double* host, const double* dev, size_t cnt) {
-      if (host && cnt && s == hipSuccess) s = hipMemcpy(host, dev, cnt * sizeof(double), hipMemcpyDeviceToHost);
+    auto get = [&](double* host, const double* dev, size_t cnt) {   // caller arrays: through the staging slot
+      if (host && cnt && s == hipSuccess && rc == RPM_OK) rc = dev_download(e, host, dev, cnt, STAGE_HESS);
     };
     get(time, o_time, M);
     get(state, o_state, size_t(M) * nx);
@@ -336,7 +336,7 @@ int dev_solution_error(Engine& e, int phase, const double* x, double* rel_err) {
   put(d_hit_s, t.hit_s.data(), t.hit_s.size() * sizeof(int));
   put(d_hit_c, t.hit_c.data(), t.hit_c.size() * sizeof(int));
   put(d_iv, t.iv.data(), K * sizeof(MeshIvDev));
-  int rc = (s == hipSuccess) ? dev_upload(e, d.d_x, x, size_t(e.n)) : RPM_OK;
+  int rc = (s == hipSuccess) ? dev_upload(e, d.d_x, x, size_t(e.n), STAGE_X) : RPM_OK;
   if (rc == RPM_OK && s == hipSuccess) {
     hipStream_t st = d.stream;
     with_problem(e.problem_id, [&](auto prob) {
@@ -347,7 +347,7 @@ int dev_solution_error(Engine& e, int phase, const double* x, double* rel_err) {
     hipLaunchKernelGGL(rpm_mesh_rel_kernel, dim3(unsigned(nx)), dim3(256), 0, st, rows, d_fine, d_integ, d_rel);
     s = hipGetLastError();
     if (s == hipSuccess) s = hipStreamSynchronize(st);
-    if (s == hipSuccess) s = hipMemcpy(rel_err, d_rel, size_t(rows) * nx * sizeof(double), hipMemcpyDeviceToHost);
+    if (s == hipSuccess) rc = dev_download(e, rel_err, d_rel, size_t(rows) * nx, STAGE_HESS);
   }
   (void)hipFree(buf);
   if (rc) return rc;

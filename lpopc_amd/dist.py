@@ -124,8 +124,9 @@ class HostConsumerGroup:
 
     The segment is POSIX shared memory (multiprocessing.shared_memory); `dist` is only used to hand its name round."""
 
-    def __init__(self, eng, dist, n, m, nnz, n_instances=1, n_x_slots=4):
+    def __init__(self, eng, dist, n, m, nnz, n_instances=1, n_x_slots=4, timeout_s=60.0):
         from multiprocessing import shared_memory
+        self.timeout_s = float(timeout_s)
         self.eng, self.dist = eng, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         B = n_instances
@@ -164,21 +165,53 @@ class HostConsumerGroup:
         eng.set_option("delta_values", 1)
         self.seq = 0
 
+    def _wait(self, word, deadline, what):
+        """Poll a control word until it reaches +seq (ok) or -seq (the peer failed), with a deadline: an error on one rank — e.g.
+        RPM_E_NONFINITE on the rank whose intervals hold the NaN — must surface on every rank, not hang the others at 100 % CPU."""
+        import time
+        spins = 0
+        while True:
+            v = int(self.ctrl[word])
+            if v >= self.seq:
+                return
+            if v == -self.seq:
+                raise RuntimeError("HostConsumerGroup: %s reported a failed evaluation in step %d" % (what, self.seq))
+            spins += 1
+            if spins > 2000:                                   # ~ the first 100 us spin, then yield the core
+                if time.monotonic() > deadline:
+                    raise TimeoutError("HostConsumerGroup: no answer from %s in step %d within %.0f s" % (what, self.seq, self.timeout_s))
+                time.sleep(50e-6)
+
     def step(self, x_slot):
         """One (eval_g, eval_jac_g) pair of the iterate in x slot `x_slot`, all ranks together; returns when the whole g and
-        values arrays are complete (on rank 0: for the consumer; the other ranks return after their own share)."""
+        values arrays are complete (on rank 0: for the consumer; the other ranks return after their own share).  A rank whose
+        evaluation fails publishes -seq; every rank then raises (rank 0 after it has heard from all ranks, so the group stays
+        in step and the next step() can proceed)."""
+        import time
         self.seq += 1
+        deadline = time.monotonic() + self.timeout_s
         if self.rank == 0:
             self.ctrl[0] = self.seq                          # go
         else:
-            while self.ctrl[0] < self.seq:
-                pass
-        self.eng.eval_pair(self.x[x_slot], self.g, self.values)   # own rows / runs only (interval-sharded engine)
-        self.ctrl[64 * (self.rank + 1)] = self.seq            # done
+            self._wait(0, deadline, "rank 0 (go)")
+        err = None
+        try:
+            self.eng.eval_pair(self.x[x_slot], self.g, self.values)   # own rows / runs only (interval-sharded engine)
+            self.ctrl[64 * (self.rank + 1)] = self.seq        # done
+        except Exception as ex:                               # expected error returns included (RPM_E_NONFINITE ...)
+            err = ex
+            self.ctrl[64 * (self.rank + 1)] = -self.seq       # failed
         if self.rank == 0:
+            failed = []
             for r in range(1, self.world):
-                while self.ctrl[64 * (r + 1)] < self.seq:
-                    pass
+                try:
+                    self._wait(64 * (r + 1), deadline, "rank %d" % r)
+                except RuntimeError:
+                    failed.append(r)
+            if err is None and failed:
+                err = RuntimeError("HostConsumerGroup: evaluation failed on rank(s) %s in step %d" % (failed, self.seq))
+        if err is not None:
+            raise err
 
     def close(self):
         try:

@@ -169,9 +169,9 @@ class NLPEngine:
             self.set_option("tile_nodes", tile_nodes)
         if role_loop is not None:
             self.set_option("role_loop", role_loop)
-        # this wrapper returns freshly allocated numpy arrays, so page-locking the caller's buffers (the C ABI's
-        # default, meant for Ipopt's long-lived arrays) would register a new buffer per call: off unless `out=` reuse
-        self.set_option("pin_host", 0)
+        # "pin_host" stays at the C ABI's default 0: this wrapper hands numpy arrays of any lifetime to the library, which
+        # copies them through its own page-locked staging buffers.  A caller that reuses long-lived `out=` arrays (as
+        # Ipopt does) may set_option("pin_host", 1) — then rpm_hip.h's lifetime contract for those arrays applies.
         n, m, nj, nh, st = (C.c_int() for _ in range(5))
         self._check(self._L.rpm_get_nlp_info(h, C.byref(n), C.byref(m), C.byref(nj), C.byref(nh), C.byref(st)))
         self.n, self.m, self.nnz_jac, self.nnz_h, self.index_style = n.value, m.value, nj.value, nh.value, st.value
@@ -190,10 +190,9 @@ class NLPEngine:
         self.close()
 
     def _own(self, name, size):
-        """A result array owned by this object for calls without `out=`.  With pin_host = 1 the library page-locks every
-        host array it is handed and keeps the registration (rpm_hip.h: such arrays must outlive the engine or their
-        eviction); a temporary numpy array would be freed while still registered, and an unmapped range inside the HIP
-        runtime's table of locked memory ends in an abort of the process some copy later.  So temporaries never reach the
+        """A result array owned by this object for calls without `out=`.  With pin_host = 1 the library page-locks the
+        host arrays it is handed and holds the registration until eviction or close() (rpm_hip.h: such arrays must stay
+        mapped that long); a temporary numpy array would be freed while still registered.  So temporaries never reach the
         library: results are written into these buffers, which live until close(), and handed out as copies."""
         bufs = self.__dict__.setdefault("_bufs", {})
         b = bufs.get(name)
@@ -206,6 +205,10 @@ class NLPEngine:
     def _check(self, rc):
         if rc != RPM_OK:
             raise RpmError(rc, self._L.rpm_last_error(self._h).decode())
+
+    def last_error(self):
+        """rpm_last_error: the reason of the last failed call, plus what the page-lock registry last refused this engine."""
+        return self._L.rpm_last_error(self._h).decode()
 
     def device_init(self, device_id=0):
         self._check(self._L.rpm_device_init(self._h, int(device_id)))

@@ -37,10 +37,18 @@ def _sources():
 
 def build(header, cache_dir=None, only_user=True, jobs=8, verbose=False):
     """Compile the engine around the functor `rpm::UserProblem` defined in `header` -> path of the shared library.
-    only_user: leave the built-in problems out of that library (a 6x shorter build; they stay available in librpm_hip.so)."""
+    only_user: leave the built-in problems out of that library (a 6x shorter build; they stay available in librpm_hip.so).
+
+    The cache key is the hash of the header's text and of the engine's sources; files the header #includes are NOT tracked
+    (keep a functor in one header, or pass a fresh cache_dir after editing an include).  Concurrent callers (two ranks under
+    torchrun) are serialised by a lock on the cache directory; the library is linked under a temporary name and renamed into
+    place, so nobody ever loads a half-written file."""
+    import fcntl
     header = os.path.abspath(header)
     if not os.path.exists(header):
         raise FileNotFoundError(header)
+    if any(c in header for c in " \t\n'\"\\$`"):
+        raise ValueError("the header path is spliced into a make command line: no whitespace, quotes, backslashes or $ (%r)" % header)
     h = hashlib.sha256()
     h.update(open(header, "rb").read())
     h.update(b"only_user" if only_user else b"all")
@@ -52,12 +60,21 @@ def build(header, cache_dir=None, only_user=True, jobs=8, verbose=False):
     so = os.path.join(cache_dir, "librpm_hip_user_%s.so" % tag)
     if os.path.exists(so):
         return so
-    objdir = os.path.join(cache_dir, "build_%s" % tag)
-    extra = '-DRPM_USER_PROBLEM_HEADER=\\"%s\\"' % header + (" -DRPM_ONLY_USER_PROBLEM" if only_user else "")
-    cmd = ["make", "-C", _CSRC, "-j%d" % jobs, "LIB=%s" % so, "OBJDIR=%s" % objdir, "EXTRA=%s" % extra, so]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0 or not os.path.exists(so):
-        raise RuntimeError("building the library for %s failed:\n%s\n%s" % (header, r.stdout[-2000:], r.stderr[-6000:]))
-    if verbose:
-        print(r.stdout[-1000:])
+    with open(os.path.join(cache_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(so):                       # another process built it while this one waited
+                return so
+            tmp = os.path.join(cache_dir, "librpm_hip_user_%s.%d.tmp.so" % (tag, os.getpid()))
+            objdir = os.path.join(cache_dir, "build_%s" % tag)
+            extra = '-DRPM_USER_PROBLEM_HEADER=\\"%s\\"' % header + (" -DRPM_ONLY_USER_PROBLEM" if only_user else "")
+            cmd = ["make", "-C", _CSRC, "-j%d" % jobs, "LIB=%s" % tmp, "OBJDIR=%s" % objdir, "EXTRA=%s" % extra, tmp]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(tmp):
+                raise RuntimeError("building the library for %s failed:\n%s\n%s" % (header, r.stdout[-2000:], r.stderr[-6000:]))
+            os.replace(tmp, so)
+            if verbose:
+                print(r.stdout[-1000:])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return so

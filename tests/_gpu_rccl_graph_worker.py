@@ -8,9 +8,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from lpopc_amd._hostmem import keep_heap_mapped  # noqa: E402
-
-keep_heap_mapped()       # see lpopc_amd/_hostmem.py
 
 from lpopc_amd import problems  # noqa: E402
 from lpopc_amd.dist import IntervalExchange, pack_all_host, slot_layout  # noqa: E402

@@ -14,9 +14,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from lpopc_amd._hostmem import keep_heap_mapped  # noqa: E402
-
-keep_heap_mapped()       # see lpopc_amd/_hostmem.py
 
 from lpopc_amd import problems  # noqa: E402
 from lpopc_amd.dist import HostConsumerGroup, SweepShard  # noqa: E402
@@ -49,10 +46,30 @@ def main():
                 assert np.array_equal(np.array(grp.values), v_ref), "values assembled by the ranks differ"
         sent, total = eng.get_option("delta_sent_runs"), eng.get_option("delta_total_runs")
         assert 0 < total and 0 < sent < 7 * total, (sent, total)     # seven deliveries, the later ones partial
+        # an error on ONE rank (a NaN among the nodes only the last rank evaluates -> RPM_E_NONFINITE there) reaches rank 0 as
+        # an exception instead of a hang, and the group stays in step: the next step() is complete and correct again
+        if rank == 0:
+            grp.x[0][eng.n - 3] = np.nan                             # last control value of the last phase
+        dist.barrier()
+        try:
+            grp.step(0)
+            raised = False
+        except Exception:
+            raised = True
+        flags = [None] * world
+        dist.all_gather_object(flags, raised)
+        assert flags[0] and flags[world - 1], flags
+        if rank == 0:
+            grp.x[0][:] = xs[0]
+        dist.barrier()
+        grp.step(0)
+        if rank == 0:
+            g_ref, v_ref = ref.eval_pair(xs[0])
+            assert np.array_equal(np.array(grp.g), g_ref) and np.array_equal(np.array(grp.values), v_ref), "after a failed step"
         if ref is not None:
             ref.close()
-        eng.close()      # releases its page-locked registrations of the segment before the segment is unmapped
-        grp.close()
+        grp.close()      # sets pin_host = 0: the engine lets go of its registrations of the segment BEFORE it is unmapped
+        eng.close()
     # ---- SweepShard around the real device solver ----
     opts = Options()
     opts.SetStringValue("hessian-approximation", "exact")

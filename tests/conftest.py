@@ -7,9 +7,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from lpopc_amd._hostmem import keep_heap_mapped  # noqa: E402
-
-keep_heap_mapped()       # before the first large allocation of the session (see lpopc_amd/_hostmem.py)
 
 
 def pytest_configure(config):

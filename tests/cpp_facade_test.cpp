@@ -60,7 +60,19 @@ int main() {
     std::printf("create failed: %s\n", rpm_last_error(nullptr));
     return 1;
   }
+  // page-locking of caller arrays is opt-in at the C ABI; the adaptor's constructor argument is the opt-in, and
+  // finalize_solution puts the option back to what the constructor was told (not unconditionally on)
+  int pin = -1;
+  if (rpm_get_option(eng, "pin_host", &pin) != RPM_OK || pin != 0) return 10;
+  {
+    RpmTNLPT<FakeTNLP> fresh_arrays(eng, /*ipopt_owned_arrays=*/false);
+    if (rpm_get_option(eng, "pin_host", &pin) != RPM_OK || pin != 0) return 11;
+    std::vector<double> z(85), l(66);
+    fresh_arrays.finalize_solution(0, 85, z.data(), nullptr, nullptr, 66, l.data(), l.data(), 0.0, nullptr, nullptr);
+    if (rpm_get_option(eng, "pin_host", &pin) != RPM_OK || pin != 0) return 12;
+  }
   RpmTNLPT<FakeTNLP> nlp(eng);
+  if (rpm_get_option(eng, "pin_host", &pin) != RPM_OK || pin != 1) return 13;
   int n, m, nj, nh;
   FakeTNLP::IndexStyleEnum st;
   if (!nlp.get_nlp_info(n, m, nj, nh, st) || st != FakeTNLP::C_STYLE) return 2;
@@ -74,6 +86,9 @@ int main() {
   const bool ok = nlp.eval_g(n, x.data(), true, m, g.data());
   std::printf("eval_g -> %s%s%s\n", ok ? "true" : "false", ok ? "" : ": ", ok ? "" : nlp.last_error().c_str());
   nlp.finalize_solution(0, n, x.data(), nullptr, nullptr, m, g.data(), g.data(), 1.5, nullptr, nullptr);
+  if (rpm_get_option(eng, "pin_host", &pin) != RPM_OK || pin != 1) return 14;
+  int held = -1;
+  if (rpm_get_option(eng, "pin_held", &held) != RPM_OK || held != 0) return 15;   // finalize released Ipopt's arrays
   rpm_destroy(eng);
   return 0;
 }

@@ -26,17 +26,20 @@ def _iterates(eng, count, mode="perturb"):
 
 @pytest.fixture(autouse=True)
 def _registrations_are_released(built):
-    """Every page-lock registration an engine makes is released by rpm_destroy / eviction: a refused hipHostUnregister
-    would leave a stale pinned range behind for whatever the process allocates at that address next."""
-    yield
+    """Every page-lock registration is gone once its last holder is: after each test the process-wide table (librpm_pin.so)
+    is empty and no hipHostRegister / hipHostUnregister was refused behind the caller's back."""
     probe = NLPEngine(problems.brachistochrone(1, 10))
-    failures, made = probe.get_option("pin_unregister_failures"), probe.get_option("pin_registered")
+    before = {k: probe.get_option(k) for k in ("pin_unregister_failures", "pin_register_failures")}
+    yield
+    after = {k: probe.get_option(k) for k in before}
+    live, made, gone = (probe.get_option(k) for k in ("pin_live", "pin_registered", "pin_unregistered"))
     probe.close()
-    assert failures == 0, (failures, made)
+    assert after == before, (before, after, probe.last_error() if probe._h else "")
+    assert live == 0 and made == gone, (live, made, gone)
 
 
 CASES = [
-    ("launch_3x6", lambda: problems.launch(3, 6), "perturb"),                 # arrays below the 64 KB pinning threshold
+    ("launch_3x6", lambda: problems.launch(3, 6), "perturb"),                 # g below the 64 KB registration threshold: staged
     ("launch_metric", lambda: problems.launch(64, 16), "perturb"),
     ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), "perturb"),
     ("hypersensitive_hp", lambda: problems.config("hypersensitive"), "uniform"),
@@ -163,7 +166,8 @@ def test_nonfinite_is_reported_by_every_entry_point(built):
 
 
 def test_many_caller_arrays_do_not_accumulate_registrations(built):
-    """pin_host keeps at most 8 page-locked registrations (LRU): 20 distinct arrays in a row still evaluate correctly."""
+    """An engine holds at most 8 page-locked registrations (least recently used is let go first): 20 distinct arrays in a
+    row still evaluate correctly, and what it let go of was unregistered."""
     prob = problems.launch(64, 16)
     e = NLPEngine(prob, device=0)
     e.set_option("pin_host", 1)
@@ -175,7 +179,120 @@ def test_many_caller_arrays_do_not_accumulate_registrations(built):
         keep.append((g, v))
         e.eval_pair(x, g, v)
         assert np.array_equal(g, ref_g) and np.array_equal(v, ref_v)
+        assert e.get_option("pin_held") <= 8
+    assert e.get_option("pin_evicted") > 0 and e.get_option("pin_live") <= 8
     e.close()
+
+
+def test_pin_host_is_opt_in_and_the_default_path_never_registers_caller_memory(built):
+    """C ABI default: "pin_host" = 0 — x / g / values / grad_f go through the engine's own page-locked staging buffers, the
+    caller's arrays are never registered (they may have any lifetime), results are bit-identical to the registered path."""
+    prob = problems.launch(64, 16)
+    e, p = NLPEngine(prob, device=0), NLPEngine(prob, device=0)
+    assert e.get_option("pin_host") == 0
+    p.set_option("pin_host", 1)
+    made = e.get_option("pin_registered")
+    xs = _iterates(e, 3)
+    xbuf, g, v, gr = np.zeros(e.n), np.zeros(e.m), np.zeros(e.nnz_jac), np.zeros(e.n)
+    for zc in (1, 0):
+        e.set_option("zero_copy", zc)
+        for x in xs:
+            got = (e.eval_g(x + 0.0, True), e.eval_jac_g(x + 0.0, False), e.eval_f(x + 0.0, True), e.eval_grad_f(x + 0.0, False))   # temporaries
+            assert e.get_option("pin_registered") == made and e.get_option("pin_held") == 0
+            xbuf[:] = x
+            p.eval_g(xbuf, True, out=g)
+            p.eval_jac_g(xbuf, False, out=v)
+            f = p.eval_f(xbuf, True)
+            p.eval_grad_f(xbuf, False, out=gr)
+            assert np.array_equal(got[0], g) and np.array_equal(got[1], v) and got[2] == f and np.array_equal(got[3], gr)
+            g2, v2 = e.eval_pair(x + 0.0)
+            assert np.array_equal(g2, g) and np.array_equal(v2, v)
+    assert p.get_option("pin_held") == 4 and p.get_option("pin_registered") == made + 4
+    e.close()
+    p.close()
+
+
+def test_page_lock_registry_is_process_wide_page_granular_and_reference_counted(built):
+    prob = problems.launch(64, 16)
+    ref = NLPEngine(prob, device=0)
+    x = _iterates(ref, 1)[0]
+    ref_g, ref_v = ref.eval_pair(x)
+    a, b = NLPEngine(prob, device=0), NLPEngine(prob, device=0)
+    for e in (a, b):
+        e.set_option("pin_host", 1)
+    xbuf, g, v = x.copy(), np.zeros(a.m), np.zeros(a.nnz_jac)
+    made, shared = a.get_option("pin_registered"), a.get_option("pin_shared")
+    a.eval_pair(xbuf, g, v)
+    assert a.get_option("pin_registered") == made + 3 and a.get_option("pin_live") == 3
+    # a second engine asks for the same arrays: no second hipHostRegister, it shares the three registrations
+    g[:] = 0
+    v[:] = 0
+    b.eval_pair(xbuf, g, v)
+    assert np.array_equal(g, ref_g) and np.array_equal(v, ref_v)
+    assert b.get_option("pin_registered") == made + 3 and b.get_option("pin_shared") == shared + 3 and b.get_option("pin_live") == 3
+    # rpm_destroy of one holder does not unpin pages the other still addresses
+    a.close()
+    assert b.get_option("pin_live") == 3 and b.get_option("pin_held") == 3
+    g[:] = 0
+    v[:] = 0
+    b.eval_pair(xbuf, g, v)
+    assert np.array_equal(g, ref_g) and np.array_equal(v, ref_v)
+    # "pin_host" = 0 lets go of everything at once (what a caller does before freeing its arrays)
+    b.set_option("pin_host", 0)
+    assert b.get_option("pin_live") == 0 and b.get_option("pin_held") == 0
+    b.set_option("pin_host", 1)
+    # two arrays that share a page (one allocation, the boundary in the middle of a page): ONE registration covers both
+    back = np.zeros(a.m + a.nnz_jac + 8)
+    assert (back.ctypes.data + 8 * a.m) % 4096 != 0
+    g2, v2 = back[:a.m], back[a.m:a.m + a.nnz_jac]
+    merged = b.get_option("pin_merged")
+    for _ in range(2):
+        b.eval_pair(xbuf, g2, v2)
+        assert np.array_equal(g2, ref_g) and np.array_equal(v2, ref_v)
+    assert b.get_option("pin_merged") == merged + 1 and b.get_option("pin_held") == 2      # x, and g+values as one
+    # a request that partly overlaps pages ANOTHER engine holds is refused, counted and reported - and served correctly
+    # through the staging buffers
+    c = NLPEngine(prob, device=0)
+    c.set_option("pin_host", 1)
+    refused = c.get_option("pin_overlap_refused")
+    big = np.zeros(2 * a.nnz_jac)
+    v3 = big[:a.nnz_jac]
+    b.eval_pair(xbuf, g2, v3)                                   # b registers the first half of `big`
+    v4 = big[a.nnz_jac // 2: a.nnz_jac // 2 + a.nnz_jac]       # c asks for a range that starts inside it and ends beyond
+    g4 = np.zeros(a.m)
+    c.eval_pair(xbuf.copy(), g4, v4)
+    assert np.array_equal(g4, ref_g) and np.array_equal(v4, ref_v)
+    assert c.get_option("pin_overlap_refused") == refused + 1 and "page-lock registry" in c.last_error()
+    # arrays below 64 KB are never registered
+    small = NLPEngine(problems.launch(3, 6), device=0)
+    small.set_option("pin_host", 1)
+    assert 8 * small.nnz_jac < 65536
+    xs_, gs_, vs_ = small.get_starting_point(), np.zeros(small.m), np.zeros(small.nnz_jac)
+    small.eval_pair(xs_, gs_, vs_)
+    assert small.get_option("pin_held") == 0
+    for e in (small, c, b, ref):
+        e.close()
+
+
+def test_const_once_does_not_trust_a_reallocated_array(built):
+    """"const_once" skips the constant tail only if the array is the one it filled last AND sampled tail entries still
+    hold what it stored: an array freed and re-allocated at the same address (different contents) gets everything."""
+    prob = problems.launch(64, 16)
+    ref = NLPEngine(prob, device=0)
+    for pin in (0, 1):
+        e = NLPEngine(prob, device=0)
+        e.set_option("pin_host", pin)
+        e.set_option("const_once", 1)
+        xs = _iterates(e, 2)
+        xbuf, v = np.zeros(e.n), np.zeros(e.nnz_jac)
+        xbuf[:] = xs[0]
+        e.eval_jac_g(xbuf, True, out=v)
+        v[:] = 7.0                                 # same address, the contents of a fresh allocation
+        xbuf[:] = xs[1]
+        e.eval_jac_g(xbuf, True, out=v)
+        assert np.array_equal(v, ref.eval_jac_g(xs[1]))
+        e.close()
+    ref.close()
 
 
 def test_objective_and_gradient_cache_follows_new_x(built):
