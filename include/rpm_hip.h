@@ -363,11 +363,11 @@ int rpm_synchronize(rpm_engine* e);
  *                    behalf of Ipopt, whose TNLPAdapter hands the same arrays every iteration): arrays of >= 64 KB are
  *                    page-locked (hipHostRegister) the first time they are seen, the kernels read x from and store g into
  *                    them, copy engines and the delta delivery write `values` straight into them.  Registrations live in
- *                    ONE process-wide, page-granular, reference-counted table shared by every engine of the process
- *                    (librpm_pin.so): page-aligned supersets of the arrays, never overlapping; an engine holds at most 8
+ *                    ONE process-wide table shared by every engine of the process (librpm_pin.so): exactly the arrays'
+ *                    bytes, never a byte twice, overlapping arrays as one range; an engine holds at most 8 arrays
  *                    (least recently used is let go first) and lets go of all of them in rpm_destroy or when the option
- *                    is set to 0; pages are unregistered when their last holder lets go.  A request the runtime refuses,
- *                    or that partly overlaps pages another engine holds, is served through the staging buffers instead and
+ *                    is set to 0; a range is unregistered when its last holder lets go.  A request the runtime refuses,
+ *                    or that partly overlaps memory another engine holds, is served through the staging buffers instead and
  *                    is never silent: get-only "pin_register_failures", "pin_unregister_failures", "pin_overlap_refused"
  *                    (process-wide counts; also "pin_registered", "pin_unregistered", "pin_shared", "pin_merged",
  *                    "pin_evicted", "pin_live", and "pin_held" = this engine's) and the reason in rpm_last_error.

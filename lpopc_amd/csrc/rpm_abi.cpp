@@ -526,6 +526,7 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   else if (k == "check_finite") e.opt_check_finite = value ? 1 : 0;
   else if (k == "pin_host") {
     e.opt_pin_host = value ? 1 : 0;
+    e.pin_refused.clear();
     if (!value) {   // a caller that is about to free or unmap its arrays turns the option off first
       if (e.dev) { int rc = rpm::dev_sync(e); if (rc) return rc; }
       rpm::dev_pin_release_all(e);
@@ -614,6 +615,7 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "pin_merged") *value = int(rpm::dev_pin_counter(RPM_PIN_MERGED));
   else if (k == "pin_evicted") *value = int(rpm::dev_pin_counter(RPM_PIN_EVICTED));
   else if (k == "pin_live") *value = int(rpm::dev_pin_counter(RPM_PIN_LIVE));
+  else if (k == "pin_live_kb") *value = int(rpm::dev_pin_counter(RPM_PIN_LIVE_BYTES) / 1024);
   else if (k == "pin_held") *value = rpm::dev_pin_held(e);
   else if (k == "delta_sent_runs") return rpm::host_delta_sent_runs(e, value);
   else if (k == "delta_total_runs") *value = e.last_delta_total;

@@ -404,16 +404,19 @@ int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b
 int dev_flag_value(Engine& e, int slot) { return e.dev->h_flags2 ? e.dev->h_flags2[slot] : 0; }
 
 // Page-locked caller arrays (option "pin_host", off unless the caller asks: RpmTNLP does for Ipopt's arrays).  The table
-// of registrations is NOT the engine's: hipHostRegister is process-wide and page-granular, so all engines of all libraries
-// of the process share the one registry of librpm_pin.so (rpm_pin.cpp: page-aligned, disjoint, reference-counted, every
-// refusal counted and kept for rpm_last_error).  An engine holds at most PIN_MAX registrations (least recently used goes
+// of registrations is NOT the engine's: hipHostRegister is process-wide, so all engines of all libraries of the process
+// share the one registry of librpm_pin.so (rpm_pin.cpp: exactly the arrays' bytes, never a byte twice, reference-counted,
+// every refusal counted and kept for rpm_last_error).  An engine holds at most PIN_MAX registrations (least recently used goes
 // first) and lets go of all of them in rpm_destroy or when the option is set to 0.  Returns the device-visible alias of
 // `ptr`, or nullptr when the array is not page-locked (option off, below RPM_PIN_MIN_BYTES, refused) — the caller of this
 // function then goes through the engine's own staging buffers, never through the runtime's pageable-copy path.
 constexpr int PIN_MAX = 8;
 long dev_pin_counter(int which) { return rpm_pin_counter(which); }
 int dev_pin_held(const Engine& e) { return rpm_pin_held(&e); }
-void dev_pin_release_all(Engine& e) { rpm_pin_release_owner(&e); }
+void dev_pin_release_all(Engine& e) {
+  rpm_pin_release_owner(&e);
+  e.pin_refused.clear();
+}
 std::string dev_pin_last_error() {
   char buf[320];
   buf[0] = 0;
@@ -421,11 +424,20 @@ std::string dev_pin_last_error() {
   return buf;
 }
 void* dev_pin_host(Engine& e, const void* ptr, size_t bytes) {
-  if (!e.opt_pin_host || !ptr || bytes < RPM_PIN_MIN_BYTES) return nullptr;
+  // an interval-sharded engine stores only ITS rows / runs into the caller's g and values: they have to be addressable
+  // whatever their size (a staged copy of the whole array would overwrite the other ranks' shares)
+  const bool sharded = e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1;
+  if (!e.opt_pin_host || !ptr || bytes == 0 || (bytes < RPM_PIN_MIN_BYTES && !sharded)) return nullptr;
+  for (const auto& r : e.pin_refused)   // asked before and refused: staged until the option is set again
+    if (r.first == ptr && r.second == bytes) return nullptr;
   const long refused = rpm_pin_counter(RPM_PIN_REGISTER_FAILURES) + rpm_pin_counter(RPM_PIN_OVERLAP_REFUSED);
-  void* alias = rpm_pin_acquire(&e, ptr, bytes, PIN_MAX);
+  void* alias = rpm_pin_acquire(&e, ptr, bytes, PIN_MAX, sharded ? 1 : 0);
   if (!alias && rpm_pin_counter(RPM_PIN_REGISTER_FAILURES) + rpm_pin_counter(RPM_PIN_OVERLAP_REFUSED) != refused)
     e.pin_note = dev_pin_last_error();   // the call goes on through the staging buffers; the reason stays readable
+  if (!alias) {
+    if (e.pin_refused.size() >= 16) e.pin_refused.erase(e.pin_refused.begin());
+    e.pin_refused.emplace_back(ptr, bytes);
+  }
   return alias;
 }
 

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstddef>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rpm_hip.h"
@@ -169,6 +170,7 @@ struct Engine {
   int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
   const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)
   int opt_pin_host = 0;          // 1: page-lock the caller's x / g / values arrays through the process-wide registry (librpm_pin.so); opt-in
+  std::vector<std::pair<const void*, size_t>> pin_refused;   // arrays the registry refused this engine (not asked for again until "pin_host" is set again)
   std::string pin_note;          // why the last registration this engine asked for was refused (shown by rpm_last_error after the reason of a failed call)
   int opt_zero_copy = 1;         // host-pointer path: the kernel reads x from / stores g into the caller's page-locked arrays
   int opt_delta_values = 0;      // host-pointer path: deliver only the runs of `values` that changed since the last delivery into the same array
