@@ -416,6 +416,44 @@ int rpm_shard_pack_all_dev(rpm_engine* e, const double* d_g, const double* d_val
 int rpm_shard_unpack_all_dev(rpm_engine* e, const double* d_gathered, double* d_g, double* d_values, int skip_own,
                              void* stream);
 
+/* ---- one process, several GPUs: the mesh intervals of ONE NLP sharded over the devices of a node -------------------------
+ * The caller this is for is lpopc's NLPSolver::SolveNlp (Core/LpNLPSolver.cpp:13-53): one process, one TNLP object, Ipopt
+ * calling it from one thread — a second GPU is only reachable from inside the callback.  A group is one interval-sharded
+ * engine per listed device (rank r computes a contiguous run of every phase's tiles, rank 0 also the endpoint rows); the
+ * same device may be listed more than once.  Set-up calls (rpm_get_nlp_info, rpm_get_bounds_info, rpm_get_starting_point,
+ * the structure passes, rpm_finalize_solution, the post-solve entry points) go to rpm_group_engine(g, 0): sizes and
+ * layout are those of the unsharded problem.  Results are bit-identical to a single engine's (no reductions).  Calls on one
+ * group are serial, as for an engine. */
+#define RPM_GROUP_MAX 16
+typedef struct rpm_group rpm_group;
+int rpm_group_create(const rpm_problem_desc* desc, int n_devices, const int* device_ids, rpm_group** out);
+void rpm_group_destroy(rpm_group* g);
+const char* rpm_group_last_error(const rpm_group* g);      /* g == NULL: of the last failed rpm_group_create */
+int rpm_group_size(const rpm_group* g);
+rpm_engine* rpm_group_engine(rpm_group* g, int rank);
+int rpm_group_device_init(rpm_group* g);                   /* optional: binds every engine to its device now */
+int rpm_group_set_option(rpm_group* g, const char* key, int value);   /* rpm_set_option on every engine */
+/* Host consumer — the TNLP callbacks (Core/LpopcIpopt.cpp:106-217) with every device on the data path: x, g, values are
+ * the caller's arrays, page-locked once for all devices ("pin_host" is on in a group: the arrays must stay allocated until
+ * rpm_group_destroy or rpm_group_set_option(g, "pin_host", 0)); every device reads x from them and stores ITS rows of g and,
+ * by difference ("delta_values"), its runs of `values` straight into them over its own PCIe link; all devices are started
+ * before any is waited for.  Objective, gradient and exact Hessian are evaluated by rank 0 (one small kernel each). */
+int rpm_group_eval_f(rpm_group* g, int n, const double* x, int new_x, double* obj_value);
+int rpm_group_eval_grad_f(rpm_group* g, int n, const double* x, int new_x, double* grad_f);
+int rpm_group_eval_g(rpm_group* g, int n, const double* x, int new_x, int m, double* gvec);
+int rpm_group_eval_jac_g(rpm_group* g, int n, const double* x, int new_x, int m, int nele_jac, int* iRow, int* jCol, double* values);
+int rpm_group_eval_pair(rpm_group* g, int n, const double* x, int m, double* gvec, int nele_jac, double* values);
+int rpm_group_eval_h(rpm_group* g, int n, const double* x, int new_x, double obj_factor, int m, const double* lambda, int new_lambda,
+                     int nele_hess, int* iRow, int* jCol, double* values);
+/* Device consumer on ONE device: d_x, d_g, d_values are arrays in the HBM of rank `home`'s device (instance strides as for
+ * rpm_eval_pair_dev); the other ranks' tile kernels read x from and store their rows / runs into them directly over xGMI
+ * (hipDeviceEnablePeerAccess) — no pack, no gather.  Blocking: returns when every rank is done. */
+int rpm_group_eval_pair_dev(rpm_group* g, int home, const double* d_x, double* d_g, double* d_values);
+/* All-gather: d_x[r], d_g[r], d_values[r] are full-size arrays in rank r's HBM; afterwards EVERY rank's g and values are
+ * complete: each rank's tile kernel fills its rows / runs in its own arrays and one push kernel stores them into the same
+ * places of every peer's arrays, one xGMI link per peer (a direct one-shot all-gather, not a ring).  Blocking. */
+int rpm_group_allgather_pair_dev(rpm_group* g, const double* const* d_x, double* const* d_g, double* const* d_values);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,10 +11,6 @@
 #include "rpm_engine.hpp"
 #include "rpm_pin.h"
 
-struct rpm_engine {
-  rpm::Engine e;
-};
-
 static thread_local std::string g_create_error;
 
 using rpm::Engine;

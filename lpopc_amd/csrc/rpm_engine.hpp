@@ -254,6 +254,10 @@ int host_eval_g(Engine& e, const double* x, int new_x, double* g);
 void host_new_x(Engine& e);   // a callback received new_x = true: drop what the other callbacks cached
 int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values);
 int host_eval_pair(Engine& e, const double* x, double* g, double* values);
+// the constraint callbacks in two halves (rpm_host_path.hip): everything queued / synchronised, delivered and judged
+struct ConsCall { bool want_g, want_v, cached, delta, launched_jac; };
+int host_cons_begin(Engine& e, const double* x, int new_x, double* g, double* values, ConsCall* c);
+int host_cons_end(Engine& e, double* g, double* values, const ConsCall& c, const char* who);
 int host_delta_sent_runs(Engine& e, int* sent);   // runs delivered since the previous query
 int dev_pipeline_active(const Engine& e);   // 1 when the next constraint launch uses rpm_tile_pl_kernel
 int dev_upload_x(Engine& e, const double* x);
@@ -273,3 +277,8 @@ void* dev_pin_host(Engine& e, const void* ptr, size_t bytes);      // "pin_host"
 void dev_pin_release_all(Engine& e);   // let go of every registration this engine holds (rpm_set_option "pin_host" 0, rpm_destroy)
 
 }  // namespace rpm
+
+// the opaque handle of include/rpm_hip.h
+struct rpm_engine {
+  rpm::Engine e;
+};

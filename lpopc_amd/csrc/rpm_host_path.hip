@@ -303,30 +303,6 @@ static void acquire_registrations(Engine& e, const double* x, const double* g, c
   if (grad) (void)dev_pin_host(e, grad, B * e.n * sizeof(double));
 }
 
-int host_eval_g(Engine& e, const double* x, int new_x, double* g) {
-  int rc = ensure_device(e);
-  if (rc) return rc;
-  Device& d = *e.dev;
-  if (new_x) host_new_x(e);
-  d.cache_valid = false;
-  acquire_registrations(e, x, g, nullptr, nullptr);
-  const bool pair = e.opt_fuse_pair != 0;   // the Jacobian of the same x comes out of the same launch
-  rc = enqueue_cons(e, x, g, true, pair);
-  if (rc) return rc;
-  rc = sync_and_deliver(e);
-  if (rc) return rc;
-  d.cache_valid = pair;
-  e.jac_nonfinite = -1;
-  if (e.opt_check_finite) {
-    if (pair) e.jac_nonfinite = d.h_flags2[1];
-    if (d.h_flags2[0] != 0) {
-      e.err = "eval_g: non-finite constraint value";
-      return RPM_E_NONFINITE;
-    }
-  }
-  return RPM_OK;
-}
-
 // "const_once" trusts the tail of an array only if it is the array this engine filled last AND 16 sampled tail entries
 // still hold what it stored there (an array freed and re-allocated at the same address does not pass)
 static size_t tail_pos(const Engine& e, int k) {
@@ -370,40 +346,83 @@ static int enqueue_values(Engine& e, double* values, bool* delta) {
   return stage_out(e, STAGE_V, values, d.d_values, count);
 }
 
-int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values) {
+// ---- the constraint callbacks in two halves: everything queued / synchronised, delivered and judged.  One engine calls
+// them back to back (host_eval_g / host_eval_jac_values / host_eval_pair below); a group of interval-sharded engines, one per
+// GPU (rpm_group.hip), begins on every device before it ends on any, so that the devices work at the same time.
+//   g != nullptr: the constraint vector is wanted; values != nullptr: the Jacobian values are wanted.
+int host_cons_begin(Engine& e, const double* x, int new_x, double* g, double* values, ConsCall* c) {
   int rc = ensure_device(e);
   if (rc) return rc;
   Device& d = *e.dev;
+  HIP_TRY(e, hipSetDevice(d.device_id));
   if (new_x) host_new_x(e);
-  const bool cached = !new_x && d.cache_valid;
+  c->want_g = g != nullptr;
+  c->want_v = values != nullptr;
+  c->cached = !c->want_g && !new_x && d.cache_valid;   // eval_jac_g(new_x = false) after an eval_g of the same x
+  c->delta = false;
+  c->launched_jac = false;
   host_path(e).pending.clear();
-  acquire_registrations(e, cached ? nullptr : x, nullptr, values, nullptr);
-  if (!cached) {
+  acquire_registrations(e, c->cached ? nullptr : x, g, values, nullptr);
+  if (!c->cached) {
     d.cache_valid = false;
-    rc = enqueue_cons(e, x, nullptr, false, true);
+    c->launched_jac = c->want_v || e.opt_fuse_pair != 0;   // the Jacobian of the same x comes out of the same launch
+    rc = enqueue_cons(e, x, g, c->want_g, c->launched_jac);
     if (rc) return rc;
     e.jac_nonfinite = -1;
   }
-  bool delta = false;
-  rc = enqueue_values(e, values, &delta);
+  if (c->want_v) {
+    rc = enqueue_values(e, values, &c->delta);
+    if (rc) return rc;
+  }
+  return RPM_OK;
+}
+
+int host_cons_end(Engine& e, double* g, double* values, const ConsCall& c, const char* who) {
+  Device& d = *e.dev;
+  HIP_TRY(e, hipSetDevice(d.device_id));
+  int rc = sync_and_deliver(e);   // the call's one synchronisation
   if (rc) return rc;
-  rc = sync_and_deliver(e);
-  if (rc) return rc;
-  if (delta) delta_commit(e, values);
-  e.const_filled = values;
-  tail_remember(e, values);
-  if (e.opt_check_finite) {
-    if (cached && e.jac_nonfinite < 0) {   // the cached pair was produced with "check_finite" off: scan it now
+  if (c.want_v) {
+    if (c.delta) delta_commit(e, values);
+    e.const_filled = values;
+    tail_remember(e, values);
+  }
+  if (!c.cached) {
+    d.cache_valid = c.launched_jac;
+    if (e.opt_check_finite && c.launched_jac) e.jac_nonfinite = d.h_flags2[1];
+  }
+  if (!e.opt_check_finite) return RPM_OK;
+  if (c.want_g && d.h_flags2[0] != 0) {
+    e.err = std::string(who) + ": non-finite constraint value";
+    return RPM_E_NONFINITE;
+  }
+  if (c.want_v) {
+    if (c.cached && e.jac_nonfinite < 0) {   // the cached pair was produced with "check_finite" off: scan it now
       e.jac_nonfinite = dev_nonfinite(e, d.d_values, size_t(e.n_instances) * e.nnz_jac);
-      if (e.jac_nonfinite < 0) { e.err = "eval_jac_g: the NaN/Inf scan failed"; return RPM_E_DEVICE; }
+      if (e.jac_nonfinite < 0) { e.err = std::string(who) + ": the NaN/Inf scan failed"; return RPM_E_DEVICE; }
     }
-    const int bad = cached ? e.jac_nonfinite : d.h_flags2[1];
-    if (bad != 0) {
-      e.err = "eval_jac_g: non-finite Jacobian value";
+    if ((c.cached ? e.jac_nonfinite : d.h_flags2[1]) != 0) {
+      e.err = std::string(who) + ": non-finite Jacobian value";
       return RPM_E_NONFINITE;
     }
   }
   return RPM_OK;
+}
+
+int host_eval_g(Engine& e, const double* x, int new_x, double* g) {
+  ConsCall c;
+  int rc = host_cons_begin(e, x, new_x, g, nullptr, &c);
+  return rc ? rc : host_cons_end(e, g, nullptr, c, "eval_g");
+}
+int host_eval_jac_values(Engine& e, const double* x, int new_x, double* values) {
+  ConsCall c;
+  int rc = host_cons_begin(e, x, new_x, nullptr, values, &c);
+  return rc ? rc : host_cons_end(e, nullptr, values, c, "eval_jac_g");
+}
+int host_eval_pair(Engine& e, const double* x, double* g, double* values) {
+  ConsCall c;
+  int rc = host_cons_begin(e, x, 1, g, values, &c);
+  return rc ? rc : host_cons_end(e, g, values, c, "eval_pair");
 }
 
 // ---- objective and gradient (LpopcIpopt::eval_f / eval_grad_f, Core/LpopcIpopt.cpp:106-133).  The first of the two calls
@@ -473,32 +492,6 @@ int host_eval_grad_f(Engine& e, const double* x, int new_x, double* grad) {
   if (rc) return rc;
   h.obj_valid = true;
   if (e.opt_check_finite && d.h_flags2[3] != 0) { e.err = "eval_grad_f: non-finite gradient"; return RPM_E_NONFINITE; }
-  return RPM_OK;
-}
-
-int host_eval_pair(Engine& e, const double* x, double* g, double* values) {
-  int rc = ensure_device(e);
-  if (rc) return rc;
-  Device& d = *e.dev;
-  host_new_x(e);
-  acquire_registrations(e, x, g, values, nullptr);
-  rc = enqueue_cons(e, x, g, true, true);
-  if (rc) return rc;
-  bool delta = false;
-  rc = enqueue_values(e, values, &delta);
-  if (rc) return rc;
-  rc = sync_and_deliver(e);                     // the one synchronisation of the pair
-  if (rc) return rc;
-  if (delta) delta_commit(e, values);
-  e.const_filled = values;
-  tail_remember(e, values);
-  d.cache_valid = true;
-  e.jac_nonfinite = -1;
-  if (e.opt_check_finite) {
-    e.jac_nonfinite = d.h_flags2[1];
-    if (d.h_flags2[0] != 0) { e.err = "eval_pair: non-finite constraint value"; return RPM_E_NONFINITE; }
-    if (d.h_flags2[1] != 0) { e.err = "eval_pair: non-finite Jacobian value"; return RPM_E_NONFINITE; }
-  }
   return RPM_OK;
 }
 

@@ -14,7 +14,6 @@
 // =================================================================================================== host side + ABI
 using namespace rpm;
 
-struct rpm_engine { rpm::Engine e; };
 
 struct rpm_ipm {
   rpm_engine* eng = nullptr;

@@ -31,6 +31,9 @@ ABI_SYMBOLS = [
     "rpm_solution_error", "rpm_ph_refine_mesh", "rpm_ph_refine_from_error",
     "rpm_hpliu_create", "rpm_hpliu_destroy", "rpm_hpliu_last_error", "rpm_hpliu_refine",
     "rpm_ipm_create", "rpm_ipm_destroy", "rpm_ipm_last_error", "rpm_ipm_set_option", "rpm_ipm_set_bounds", "rpm_ipm_set_all_bounds", "rpm_ipm_get_info",
+    "rpm_group_create", "rpm_group_destroy", "rpm_group_last_error", "rpm_group_size", "rpm_group_engine", "rpm_group_device_init",
+    "rpm_group_set_option", "rpm_group_eval_f", "rpm_group_eval_grad_f", "rpm_group_eval_g", "rpm_group_eval_jac_g", "rpm_group_eval_pair",
+    "rpm_group_eval_h", "rpm_group_eval_pair_dev", "rpm_group_allgather_pair_dev",
     "rpm_ipm_get_stats", "rpm_ipm_get_subproblems", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_get_kernel_times", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve", "rpm_ipm_debug_solve_dense", "rpm_ipm_debug_slot",
 ]
 
@@ -131,6 +134,24 @@ def lib(path=None):
     L.rpm_shard_slot_len.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.rpm_shard_pack_all_dev.argtypes = [vp, vp, vp, vp, vp]
     L.rpm_shard_unpack_all_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp]
+    L.rpm_group_create.argtypes = [C.POINTER(_abi.rpm_problem_desc), C.c_int, ip, C.POINTER(vp)]
+    L.rpm_group_destroy.argtypes = [vp]
+    L.rpm_group_destroy.restype = None
+    L.rpm_group_last_error.argtypes = [vp]
+    L.rpm_group_last_error.restype = C.c_char_p
+    L.rpm_group_size.argtypes = [vp]
+    L.rpm_group_engine.argtypes = [vp, C.c_int]
+    L.rpm_group_engine.restype = vp
+    L.rpm_group_device_init.argtypes = [vp]
+    L.rpm_group_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.rpm_group_eval_f.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    L.rpm_group_eval_grad_f.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    L.rpm_group_eval_g.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, dp]
+    L.rpm_group_eval_jac_g.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_int, ip, ip, dp]
+    L.rpm_group_eval_pair.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
+    L.rpm_group_eval_h.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp, C.c_int, C.c_int, ip, ip, dp]
+    L.rpm_group_eval_pair_dev.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.rpm_group_allgather_pair_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     _LIBS[so] = L
     if so == _SO:
         _LIB = L
