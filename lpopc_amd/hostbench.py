@@ -7,7 +7,7 @@ import numpy as np
 
 VARIANTS = [
     # name, options, call pattern
-    ("two_calls_pageable", {"pin_host": 0}, "two"),
+    ("two_calls_default_staged", {"pin_host": 0}, "two"),      # the C ABI's default: CPU copies through the engine's page-locked staging buffers
     ("two_calls_pinned", {"pin_host": 1}, "two"),
     ("two_calls_pinned_const_once", {"pin_host": 1, "const_once": 1}, "two"),
     ("two_calls_pinned_delta", {"pin_host": 1, "delta_values": 1}, "two"),

@@ -33,6 +33,8 @@ def lib():
         L.orpm_create.restype = C.c_void_p
         L.orpm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.orpm_destroy.argtypes = [C.c_void_p]
+        L.orpm_set_cost_shape.argtypes = [C.c_void_p, C.c_int]
+        L.orpm_set_cost_shape.restype = None
         L.orpm_get_nlp_info.argtypes = [C.c_void_p, ip, ip, ip, ip]
         L.orpm_get_bounds_info.argtypes = [C.c_void_p, dp, dp, dp, dp]
         L.orpm_get_starting_point.argtypes = [C.c_void_p, dp]
@@ -133,6 +135,10 @@ class Oracle:
         if getattr(self, "_h", None):
             lib().orpm_destroy(self._h)
             self._h = None
+
+    def set_cost_shape(self, fair):
+        """0: the reference's cost shape (COO product, per-call Find scans); 1: the fair shape (orpm.h).  Same numbers."""
+        lib().orpm_set_cost_shape(self._h, 1 if fair else 0)
 
     def bounds(self):
         xl, xu, gl, gu = np.zeros(self.n), np.zeros(self.n), np.zeros(self.m), np.zeros(self.m)

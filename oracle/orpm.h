@@ -88,6 +88,14 @@ const orpm_functions* orpm_problem_functions(int problem_id);
 orpm* orpm_create(const rpm_problem_desc* desc, char* err, int errlen);
 void orpm_destroy(orpm* o);
 
+/* CPU-baseline cost shapes (the numbers are bit-identical either way):
+ *   0 "faithful-cost" (default): what lpopc itself pays — the COO sparse x dense loop with its column copies
+ *     (SparseMatrix/LpSparseMatrix.cpp:127-155) and a Find(Doffdiag) scan per phase in GetWholeJacbi and again in
+ *     GetPhaseJacbi on every eval_jac_g (Core/LpNLPWrapper.cpp:304, :686);
+ *   1 "fair": the same algorithm and arithmetic order without those: D as dense rows per node (ascending columns, the
+ *     order the COO loop produces per row), the Doffdiag value list found once per mesh. */
+void orpm_set_cost_shape(orpm* o, int fair);
+
 void orpm_get_nlp_info(const orpm* o, int* n, int* m, int* nnz_jac_g, int* nnz_h_lag);
 void orpm_get_bounds_info(const orpm* o, double* x_l, double* x_u, double* g_l, double* g_u);
 void orpm_get_starting_point(const orpm* o, double* x);

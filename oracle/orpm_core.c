@@ -237,6 +237,22 @@ static void coo_mul(int nnz, const int* ri, const int* ci, const double* v, int 
   free(temcol);
 }
 
+/* "fair" cost shape: the same product from dense rows.  Row i of the composite D has its non-zeros in one mesh interval,
+ * columns ascending; the COO loop above visits a row's entries in exactly that order (blocks are column-major), each time
+ * as out += v * x starting from 0, so the sums are bit-identical. */
+static void dense_rows_mul(const ophase* p, int m, const double* X, int xrows, int ncols, double* out) {
+  for (int icol = 0; icol < ncols; icol++) {
+    const double* col = X + (size_t)icol * xrows;
+    for (int i = 0; i < m; i++) {
+      const double* v = p->fr_vals + p->fr_off[i];
+      const double* xx = col + p->fr_col0[i];
+      double acc = 0.0;
+      for (int q = 0; q < p->fr_len[i]; q++) acc += v[q] * xx[q];
+      out[i + (size_t)icol * m] = acc;
+    }
+  }
+}
+
 /* dsmatrix::Find, SparseMatrix/LpSparseMatrix.cpp:240-271 (returns fresh arrays) */
 static int coo_find(int nnz, const int* ri, const int* ci, const double* v, double** oi, double** oj,
                     double** ov) {
@@ -599,6 +615,11 @@ void orpm_destroy(orpm* o) {
     free(p->off_i);
     free(p->off_j);
     free(p->off_v);
+    free(p->fr_off);
+    free(p->fr_col0);
+    free(p->fr_len);
+    free(p->fr_vals);
+    free(p->fair_fv);
   }
   for (int i = 0; i < o->L; i++) {
     free(o->lk[i].lmin);
@@ -753,7 +774,8 @@ void orpm_eval_g(orpm* o, const double* x, double* g) {
     double* pathout = NEW(double, (size_t)N * (p->nc > 0 ? p->nc : 1));
     o->fun->dae(&sd, o->consts, stateout, pathout);                                /* :110 */
     double* odeleft = NEW(double, (size_t)N * p->nx);
-    coo_mul(p->d_nnz, p->d_i, p->d_j, p->d_v, N, s.state_matrix, N + 1, p->nx, odeleft); /* :111 */
+    if (o->fair) dense_rows_mul(p, N, s.state_matrix, N + 1, p->nx, odeleft);
+    else coo_mul(p->d_nnz, p->d_i, p->d_j, p->d_v, N, s.state_matrix, N + 1, p->nx, odeleft); /* :111 */
     for (int q = 0; q < N * p->nx; q++) g[row + q] = odeleft[q] - stateout[q] * (s.tspan / 2.0); /* :113,122 */
     row += N * p->nx;
     for (int q = 0; q < N * p->nc; q++) g[row + q] = pathout[q];                   /* :138-164 */
@@ -1107,16 +1129,22 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
     dEventOut = NEW(double, (size_t)ne * (2 * nx + 2));
     deriv_event(o, &se, dEventOut);
   }
-  /* per-call Find of the off-diagonal matrix, :685-687 */
-  double *fi, *fj, *fv;
-  int nzoff = coo_find(p->off_nnz, p->off_i, p->off_j, p->off_v, &fi, &fj, &fv);
+  /* per-call Find of the off-diagonal matrix, :685-687 (the fair shape found it once) */
+  double *fi = NULL, *fj = NULL, *fv = NULL;
+  int nzoff;
+  if (o->fair) {
+    nzoff = p->fair_nzoff;
+  } else {
+    nzoff = coo_find(p->off_nnz, p->off_i, p->off_j, p->off_v, &fi, &fj, &fv);
+  }
+  const double* fvv = o->fair ? p->fair_fv : fv;
   int sh = 0;
   for (int i = 0; i < nx; i++) { /* :695-770 */
     for (int j = 0; j < nx; j++) {
       if (i == j) {
         for (int k = 0; k < N; k++) SV[sh + k] = p->diag_v[k] - DDAE(i, j, k) * (tf - t0) / 2.0; /* :712 */
         sh += N;
-        memcpy(SC + (size_t)i * nzoff, fv, sizeof(double) * nzoff);                              /* :717-718 */
+        memcpy(SC + (size_t)i * nzoff, fvv, sizeof(double) * nzoff);                             /* :717-718 */
       } else {
         for (int k = 0; k < N; k++) SV[sh + k] = -(DDAE(i, j, k) * (tf - t0) / 2.0);            /* :725-726 */
         sh += N;
@@ -1177,9 +1205,36 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
   return sh;
 }
 
+void orpm_set_cost_shape(orpm* o, int fair) {
+  o->fair = fair ? 1 : 0;
+  if (!o->fair) return;
+  for (int ip = 0; ip < o->P; ip++) {
+    ophase* p = &o->ph[ip];
+    if (p->fr_off) continue;
+    int N = p->N;
+    p->fr_off = NEW(int, N);
+    p->fr_col0 = NEW(int, N);
+    p->fr_len = NEW(int, N);
+    for (int i = 0; i < N; i++) { p->fr_col0[i] = 1 << 30; p->fr_len[i] = 0; }
+    for (int k = 0; k < p->d_nnz; k++) {
+      int i = p->d_i[k], j = p->d_j[k];
+      if (j < p->fr_col0[i]) p->fr_col0[i] = j;
+      p->fr_len[i]++;
+    }
+    int off = 0;
+    for (int i = 0; i < N; i++) { p->fr_off[i] = off; off += p->fr_len[i]; }
+    p->fr_vals = NEW(double, off);
+    for (int k = 0; k < p->d_nnz; k++) p->fr_vals[p->fr_off[p->d_i[k]] + (p->d_j[k] - p->fr_col0[p->d_i[k]])] = p->d_v[k];
+    double *fi, *fj;
+    p->fair_nzoff = coo_find(p->off_nnz, p->off_i, p->off_j, p->off_v, &fi, &fj, &p->fair_fv);
+    free(fi);
+    free(fj);
+  }
+}
+
 void orpm_eval_jac_g(orpm* o, const double* x, double* values) {
   /* GetWholeJacbi counts with a Find(Doffdiag) per phase, :278-307 */
-  for (int i = 0; i < o->P; i++) {
+  for (int i = 0; i < o->P && !o->fair; i++) {
     double *fi, *fj, *fv;
     coo_find(o->ph[i].off_nnz, o->ph[i].off_i, o->ph[i].off_j, o->ph[i].off_v, &fi, &fj, &fv);
     free(fi);

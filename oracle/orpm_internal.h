@@ -24,6 +24,11 @@ typedef struct {
   /* layout, 0-based absolute indices (phase_indices are 1-based in the reference) */
   int var0, con0, nvar, ncon;
   int state0, control0, t0_idx, tf_idx, param0;
+  /* "fair" cost shape only (orpm_set_cost_shape): D as dense rows per node, the Doffdiag value list found once */
+  int *fr_off, *fr_col0, *fr_len;
+  double* fr_vals;
+  int fair_nzoff;
+  double* fair_fv;
 } ophase;
 
 typedef struct {
@@ -49,6 +54,7 @@ struct orpm {
   int *alin_i, *alin_j;
   double* alin_v;
   double *linmin, *linmax;
+  int fair;   /* 0: the reference's cost shape (default); 1: the fair shape, see orpm_set_cost_shape */
   /* Hessian (oracle/orpm_hess.c) */
   void* hess;
 };
