@@ -252,7 +252,7 @@ def make_iterates(problems, eng, count, seed0, mode="perturb"):
 
 
 def device_workload(ctx, args, prob, B, R, K, warmup, sharded, seed0, mode="perturb", align=16, use_graph=True,
-                    role_loop=-1, pipeline=-1, dx_mode=0, tile_nodes=0, unfused=False, keep=False):
+                    role_loop=-1, pipeline=-1, dx_mode=0, tile_nodes=0, unfused=False, keep=False, persistent=False):
     """The fused pair kernel over R resident iterates, B per step; with `sharded` the mesh intervals of every iterate are split
     over the ranks and the results exchanged with ONE packed all-gather per step."""
     import numpy as np
@@ -267,6 +267,8 @@ def device_workload(ctx, args, prob, B, R, K, warmup, sharded, seed0, mode="pert
     if pipeline != -1:
         eng.set_option("pipeline", pipeline)
     eng.set_option("instance_align", align)   # every iterate's g / values array starts on a 128-byte line
+    if persistent:
+        eng.set_option("persistent_values", 1)  # the constant Doffdiag block of each resident values array is written once
     R = max(R, 2 * B)
     R -= R % B
     xs = make_iterates(problems, eng, R, seed0, mode)
@@ -598,6 +600,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="NLP iterates evaluated per launch (independent instances of the same problem): 64 amortise the\n"
                          "persistent kernel's prologue and tail (0.68 of the HBM peak; 16 per launch: 0.55-0.56)")
+    ap.add_argument("--persistent", action="store_true",
+                    help="main workload with option persistent_values (profiling of that mode; the line then says so in config.pair)")
     ap.add_argument("--intervals", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=16)
     ap.add_argument("--group-devices", type=str, default="",
@@ -636,7 +640,7 @@ def main():
     main_res, eng, xs, d_x, d_g, d_v = device_workload(
         ctx, args, prob, B, args.iterates, args.steps, args.warmup, sharded, seed0, align=args.instance_align,
         use_graph=not args.no_graph, role_loop=args.role_loop, pipeline=args.pipeline, dx_mode=args.dx_mode,
-        tile_nodes=args.tile_nodes, unfused=args.unfused, keep=True)
+        tile_nodes=args.tile_nodes, unfused=args.unfused, keep=True, persistent=args.persistent)
     R = main_res["resident_iterates"]
     if not sharded and not os.environ.get("RPM_DIAG_MASK") and not args.profile:
         check_against_single_evaluation(ctx, args, prob, eng, d_x, d_g, d_v, R)
@@ -682,8 +686,9 @@ def main():
                 "workload": "Delta-III 4-phase launch ascent, %d intervals/phase x %d LGR points (n=%d, m=%d, nnz_jac=%d), "
                             "first-derive=finite-difference tol=1e-6, %d seeded iterates resident in HBM, %d iterate(s) per step"
                             % (args.intervals, args.nodes, eng.n, eng.m, eng.nnz_jac, R, B),
-                "pair": "unfused: eval_g kernel + eval_jac_g kernel" if args.unfused else
-                        "fused: one tile-kernel launch writes g and all Jacobian values of the step's iterates",
+                "pair": ("unfused: eval_g kernel + eval_jac_g kernel" if args.unfused else
+                         "fused: one tile-kernel launch writes g and all Jacobian values of the step's iterates") +
+                        (" EXCEPT the constant Doffdiag block (--persistent: not the TNLP contract, not comparable with `value` of a default run)" if args.persistent else ""),
                 "timing": "each timed region = exactly `steps` steps between barrier+synchronize; regions repeated until >= %.2f s; "
                           "value and ms_per_step are the median region (max over ranks per region)" % MIN_TIMED_S,
                 "launch": main_res["launch"],
@@ -730,6 +735,27 @@ def main():
                                                 "median; Ipopt itself is absent, so no linear-solver time is in it"}
         except Exception as ex:
             errors["sequential"] = repr(ex)
+        try:   # SURVEY 8(d)'s persistent-buffer variant: same workload, the constant block of every resident array written once
+            pv = device_workload(ctx, args, prob, B, args.iterates, args.steps, args.warmup, False, 3, align=args.instance_align,
+                                 use_graph=not args.no_graph, role_loop=args.role_loop, pipeline=args.pipeline, tile_nodes=args.tile_nodes,
+                                 persistent=True)
+            from lpopc_amd.engine import NLPEngine
+            e1 = NLPEngine(prob)
+            i_, j_ = e1.eval_jac_g_structure()
+            nnz_const = int(sum(e1.phase_tables(p)["doff_vals"].size * e1._desc.phases[p].nx for p in range(e1.n_phases)))
+            bprime = algorithmic_bytes(e1) - 8 * nnz_const
+            e1.close()
+            ach = bprime * B / (pv["dev_ms_per_step"] * 1e-3) / 1e9
+            out["persistent_values"] = {
+                "pairs_per_s": pv["pairs_per_s"], "ms_per_step": pv["ms_per_step"], "dev_ms_per_step": pv["dev_ms_per_step"],
+                "algorithmic_bytes_per_pair_Bprime": bprime, "achieved_GBs": ach, "frac": ach / HBM_PEAK_GBS,
+                "kernel": pv["kernel"], "iterates_per_step": B,
+                "what": "option persistent_values: the %d resident values arrays keep their constant Doffdiag block (%d of %d entries) from the "
+                        "first fill; never `value` — the TNLP contract hands a caller buffer and counts every entry" % (pv["resident_iterates"], nnz_const, pv["nnz_jac"])}
+            out["roofline"]["persistent_values"] = {"frac": ach / HBM_PEAK_GBS, "achieved": ach, "bytes_per_pair": bprime,
+                                                    "avg_launch_us": pv["dev_ms_per_step"] * 1e3, "pairs_per_s": pv["pairs_per_s"]}
+        except Exception as ex:
+            errors["persistent_values"] = repr(ex)
         try:
             out["device_ipm"] = device_ipm_section(ctx, args)
         except Exception as ex:

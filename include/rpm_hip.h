@@ -335,6 +335,13 @@ int rpm_synchronize(rpm_engine* e);
  *                    (they never change, LpNLPWrapper.cpp:242, :715-718) only into a buffer it did not fill on the
  *                    previous call, afterwards just the NL prefix — for callers that hand the same array every
  *                    iteration and leave it alone in between (Ipopt's TNLPAdapter does); one instance per engine
+ * "persistent_values" 0 (default) | 1: rpm_eval_jac_g_dev / rpm_eval_pair_dev remember the device `values` arrays they have
+ *                    completely written and, called again with the same array, write only the entries that depend on x (and
+ *                    the 2(P+L) linear ones): the constant Doffdiag block (Core/LpNLPWrapper.cpp:715-718; 54 % of the
+ *                    metric problem's entries) is neither loaded nor stored again — SURVEY.md section 8(d)'s persistent-
+ *                    buffer byte count B'.  Contract: the caller leaves that block of the array alone and does not free and
+ *                    re-allocate the array in between; setting any option forgets every array (do that after re-allocating).
+ *                    Bit-identical `values`.  The device solver (rpm_ipm_*) uses it for its own Jacobian array.
  * "delta_values"     0 (default) | 1: host-pointer rpm_eval_jac_g / rpm_eval_pair deliver `values` by difference: a kernel
  *                    compares the fresh values with a device-side mirror of what this engine last stored into the SAME
  *                    host array and stores only the 512-double runs in which a bit changed — the constant Doffdiag block, the

@@ -456,14 +456,14 @@ int rpm_eval_jac_g_dev(rpm_engine* h, const double* d_x, double* d_values, void*
   if (!h) return RPM_E_INVALID;
   RPM_GUARD_BEGIN
   if (!d_x || !d_values) return fail(h->e, RPM_E_INVALID, "eval_jac_g_dev: NULL pointer");
-  return rpm::dev_eval_cons(h->e, d_x, nullptr, d_values, 2 | 4, stream);
+  return rpm::dev_eval_cons(h->e, d_x, nullptr, d_values, 2 | 4 | (h->e.opt_persistent_values ? 16 : 0), stream);
   RPM_GUARD_END(h->e)
 }
 int rpm_eval_pair_dev(rpm_engine* h, const double* d_x, double* d_g, double* d_values, void* stream) {
   if (!h) return RPM_E_INVALID;
   RPM_GUARD_BEGIN
   if (!d_x || !d_g || !d_values) return fail(h->e, RPM_E_INVALID, "eval_pair_dev: NULL pointer");
-  return rpm::dev_eval_cons(h->e, d_x, d_g, d_values, 3 | 4, stream);
+  return rpm::dev_eval_cons(h->e, d_x, d_g, d_values, 3 | 4 | (h->e.opt_persistent_values ? 16 : 0), stream);
   RPM_GUARD_END(h->e)
 }
 int rpm_eval_f_dev(rpm_engine* h, const double* d_x, double* d_obj, void* stream) {
@@ -558,6 +558,9 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
     if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "ipm_nested must be -1 (automatic), 0 or 1");
     if (e.ipm_attached > 0) return fail(e, RPM_E_INVALID, "ipm_nested must be set before rpm_ipm_create");
     e.opt_ipm_nested = value;
+  } else if (k == "persistent_values") {
+    if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "persistent_values must be 0 or 1");
+    e.opt_persistent_values = value;
   } else if (k == "delta_values") {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "delta_values must be 0 or 1");
     e.opt_delta_values = value;
@@ -581,6 +584,7 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   } else
     return fail(e, RPM_E_INVALID, "unknown option");
   rpm::host_new_x(e);   // nothing cached under the old options is handed out under the new ones
+  rpm::dev_forget_persistent(e);
   return RPM_OK;
 }
 int rpm_get_option(rpm_engine* h, const char* key, int* value) {
@@ -600,6 +604,7 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "ipm_nested") *value = e.opt_ipm_nested;
   else if (k == "ipm_nested_group") *value = e.opt_ipm_nested_group;
   else if (k == "zero_copy") *value = e.opt_zero_copy;
+  else if (k == "persistent_values") *value = e.opt_persistent_values;
   else if (k == "pin_host") *value = e.opt_pin_host;
   // page-lock registry of the process (librpm_pin.so; counters since the process started) and this engine's share of it
   else if (k == "pin_registered") *value = int(rpm::dev_pin_counter(RPM_PIN_REGISTERED));

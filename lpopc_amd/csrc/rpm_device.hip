@@ -281,6 +281,7 @@ int device_init(Engine& e, int device_id) {
   const bool sharded = e.shard_mode == RPM_SHARD_INTERVALS && e.shard_world > 1;
   k.tasks = d->d_tasks;
   k.n_tasks = (!sharded || e.shard_rank == 0) ? int(e.tasks.size()) : 0;  // rank 0 owns the endpoint rows
+  k.skip_const = 0;
   k.diag_mask = 0;
   k.trace = nullptr;
   k.chk = nullptr;
@@ -561,6 +562,9 @@ double* dev_buf(Engine& e, int which) {
   return nullptr;
 }
 bool& dev_cache_valid(Engine& e) { return e.dev->cache_valid; }
+void dev_forget_persistent(Engine& e) {
+  if (e.dev) e.dev->const_filled.clear();
+}
 void* dev_stream(Engine& e) { return e.dev->stream; }
 
 // ---- interval sharding: pack a rank's runs / scatter the gathered runs of every rank -----------

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@ struct KParams {
   long long sg, sv;                     // distance between the g / values arrays of consecutive instances (>= m, nnz)
   int max_span, max_drow;
   int max_cshare;                       // largest constant-block share of a tile (c_cnt)
+  int skip_const;                       // 1: this launch leaves the constant Doffdiag block of `values` alone (persistent arrays, dev_eval_cons)
   int diag_mask;                        // ablation mask, only honoured by the -DRPM_DIAG diagnostic build
   unsigned long long* trace;            // per-workgroup timestamps (diagnostic build with RPM_DIAG_TRACE set), else NULL
   int* chk;                             // host-pointer path: two host-visible words ORed with "a stored g / Jacobian value is NaN/Inf"; else NULL
@@ -82,6 +84,7 @@ struct Device {
   struct Stage { double* h = nullptr; double* d = nullptr; size_t cap = 0; bool busy = false; };   // busy: a queued H2D copy still reads it
   Stage stage[STAGE_SLOTS];
   bool cache_valid = false;     // d_g / d_values hold the pair of the x last uploaded
+  std::vector<const double*> const_filled;   // device `values` arrays whose constant block this engine has written (option "persistent_values")
   size_t lds_bytes = 0;
   int pl_slots = 0;             // resident workgroups the pipelined kernel is launched with (2 per CU)
   size_t pl_lds = 0;

@@ -169,6 +169,7 @@ struct Engine {
   int opt_pipeline = -1;         // rpm_tile_pl_kernel: -1 automatic (>= 2 tiles per resident workgroup), 0 never, 1 whenever the mesh fits
   int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
   const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)
+  int opt_persistent_values = 0; // device-resident Jacobian calls: skip the constant block of a `values` array this engine filled before (rpm_hip.h)
   int opt_pin_host = 0;          // 1: page-lock the caller's x / g / values arrays through the process-wide registry (librpm_pin.so); opt-in
   std::vector<std::pair<const void*, size_t>> pin_refused;   // arrays the registry refused this engine (not asked for again until "pin_host" is set again)
   std::string pin_note;          // why the last registration this engine asked for was refused (shown by rpm_last_error after the reason of a failed call)
@@ -267,6 +268,7 @@ int dev_sync(Engine& e);
 int dev_update_instance_constants(Engine& e);   // (re)uploads e.inst_consts and points the kernels at it
 double* dev_buf(Engine& e, int which);  // 0 x, 1 g, 2 values, 3 grad, 4 obj, 5 lambda, 6 hess
 bool& dev_cache_valid(Engine& e);
+void dev_forget_persistent(Engine& e);   // no device `values` array counts as filled any more (option "persistent_values")
 void* dev_stream(Engine& e);
 int dev_nonfinite(Engine& e, const double* dev, size_t count);   // 1 if a NaN/Inf is present, checked on the device
 int dev_nonfinite_enqueue(Engine& e, const double* a, size_t na, const double* b, size_t nb);   // asynchronous form, flag words 0 / 1

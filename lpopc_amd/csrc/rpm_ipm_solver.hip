@@ -514,6 +514,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   hipStream_t st = static_cast<hipStream_t>(dev_stream(e));
   const unsigned B = unsigned(D.B);
   auto eng_fail = [&](int rc) { h->err = e.err; return rc; };
+  dev_forget_persistent(e);   // the first Jacobian evaluation of this solve writes the constant block of D.jac, the later ones skip it
   h->total_factorizations = h->total_iterations = h->total_trials = h->total_soc = 0;
   h->factor_ms = h->solve_ms = 0.0;
   h->solve_pending = false;
@@ -538,7 +539,9 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   for (;;) {
     ipm_launch_pack_x(D, st);
     if ((rc = dev_eval_obj(e, D.xe, D.obj, D.grad, st))) return eng_fail(rc);
-    if ((rc = dev_eval_cons(e, D.xe, D.g, D.jac, 3 | 4, st))) return eng_fail(rc);
+    // D.jac is this solver's own array, written by the tile kernel only: its constant Doffdiag block (55 % of the metric
+    // problem's Jacobian) is written by the first evaluation of a solve and left alone afterwards (flag 16)
+    if ((rc = dev_eval_cons(e, D.xe, D.g, D.jac, 3 | 4 | 16, st))) return eng_fail(rc);
     IPM_TRY(h, hipMemsetAsync(D.cnt, 0, 4 * sizeof(int), st));
     ipm_launch_residual(D, st);
     if ((rc = fetch_counts(h, st))) return rc;

@@ -231,7 +231,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   const double ddiag = WJ ? K.diag[nidx] : 0.0;
   constexpr int CPRE = 8;                          // constant-block sources prefetched per thread
   double cpre[CPRE > 0 ? CPRE : 1];
-  if (WJ) {
+  if (WJ && !K.skip_const) {
 #pragma unroll
     for (int u = 0; u < CPRE; ++u) {
       const int q = tid + u * nthr;
@@ -415,7 +415,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
 #ifdef RPM_DIAG
   if (!(K.diag_mask & 4))
 #endif
-  if (WJ) {
+  if (WJ && !K.skip_const) {
     const double* __restrict__ src = K.doff_vals + tl.c_src0;
     double* __restrict__ dst = vals + tl.c_dst0;
 #pragma unroll
@@ -614,9 +614,9 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
   }
   RPM_TRC(4);
 #ifdef RPM_DIAG
-  if (WJ && !(K.diag_mask & 4)) {
+  if (WJ && !K.skip_const && !(K.diag_mask & 4)) {
 #else
-  if (WJ) {
+  if (WJ && !K.skip_const) {
 #endif
     // this tile's share of the constant Doffdiag block (LpNLPWrapper.cpp:715-718)
     const double* __restrict__ src = K.doff_vals + tl.c_src0;
@@ -741,62 +741,22 @@ constexpr int pl_role_groups(int R) { return (R + (R + 11) / 12 - 1) / ((R + 11)
 // (2 compute + 1 DMA, 168-VGPR budget), three passes per tile — measured best on the metric problem (33.2 us per
 // 16-iterate launch) against 2 x (6 + 2) at 128 VGPRs (35.0), one role per wave 12 + 4 (36.3) and 3 x (4 + 1) (38.6).
 // Larger problems: one half, the fewest equal passes (R = 18: 9 + 2 waves, 3 per SIMD).
-struct PlShape { int NH, RG, NDMA, NST; };
-#ifndef RPM_PL_BIG_RG
-#define RPM_PL_BIG_RG 0   // experiment: compute waves of the one-half shape (0 = the fewest equal passes)
-#endif
-#ifndef RPM_PL_BIG_MINWAVES
-#define RPM_PL_BIG_MINWAVES 0   // experiment: waves per SIMD the one-half shape is compiled for (0 = whatever fits)
-#endif
-#ifndef RPM_PL_BIG_NST
-#define RPM_PL_BIG_NST 0   // shape for more than 12 roles: 0 barrier per tile, -1 counters in LDS, n > 0 counters and n store waves (see the kernel)
-#endif
-#ifndef RPM_PL_ALL_STAGE_FIRST
-#define RPM_PL_ALL_STAGE_FIRST 0   // experiment: every wave of a half issues a share of its first tile's loads
-#endif
-#ifndef RPM_PL_BIG_NDMA
-#define RPM_PL_BIG_NDMA 2
-#endif
-#ifndef RPM_PL_ST16
-#define RPM_PL_ST16 1      // store waves write 16 bytes per lane
-#endif
-#ifndef RPM_PL_SMALL_NST
-#define RPM_PL_SMALL_NST 0   // the same for the shape of up to 12 roles
-#endif
-#ifndef RPM_PL_SMALL_NDMA
-#define RPM_PL_SMALL_NDMA 2
-#endif
-#ifndef RPM_PL_BIG_NH
-#define RPM_PL_BIG_NH 1
-#endif
-constexpr PlShape pl_shape(int R) {
-  return R <= 12 ? PlShape{2, 4, RPM_PL_SMALL_NDMA, RPM_PL_SMALL_NST} : PlShape{RPM_PL_BIG_NH, RPM_PL_BIG_RG ? RPM_PL_BIG_RG : pl_role_groups(R), RPM_PL_BIG_NDMA, RPM_PL_BIG_NST};
-}
-// doubles one half adds to its LDS when it has store waves: the second buffer of the unperturbed outputs, the counters, one
-// slot per compute wave (header + one Jacobian column of a tile)
-constexpr int pl_extra_waves(int NST) { return NST > 0 ? NST : NST == -2 ? 1 : 0; }
-constexpr size_t pl_fs_extra(int NO, int RG, int NSW) { return size_t(NO) * 64 + 16 + (NSW > 0 ? size_t(RG) * (size_t(NO) * 64 + 8) : 0); }
-// a spin on an LDS counter gives up after ~0.1 s (the launch then delivers wrong numbers, which the callers' checks see, instead of hanging the GPU)
-#define PL_SPIN(cond) do { int it_ = 0; while (!(cond)) { __builtin_amdgcn_s_sleep(1); if (++it_ > (1 << 22)) break; } } while (0)
-#define PL_LD(p) __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+struct PlShape { int NH, RG, NDMA; };
+constexpr PlShape pl_shape(int R) { return R <= 12 ? PlShape{2, 4, 2} : PlShape{1, pl_role_groups(R), 2}; }
+// (Measured and rejected shapes of this kernel — waves meeting through LDS counters instead of s_barrier, dedicated store
+// waves taking finished Jacobian columns out of LDS slots, a dedicated constant-block wave, all waves staging the first tile,
+// other wave counts — were compile-time variants of it until round 3; DESIGN.md section 4 keeps their numbers, the code is
+// in the history at commit 26aa614.)
 
 // (Tried for the one-half shape, R > 12 roles: __launch_bounds__(..., 6) so that two 11-wave workgroups share a CU and one's
 // store phases overlap the other's dynamics.  The quadrotor kernel needs ~156 VGPRs; at 80 it spills 76 of them and the
 // 1024-instance sweep takes 89.9 us instead of 51 — DESIGN.md §4.)
-template <class Prob, int NH, int RG, int NDMA, int NST, bool WG, bool WJ, bool AN, bool DXM = false>
-__global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH == 1 && RPM_PL_BIG_MINWAVES) ? RPM_PL_BIG_MINWAVES : 1) void rpm_tile_pl_kernel(
+template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN, bool DXM = false>
+__global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
     const KParams K, int n_inst, const double* __restrict__ xall, double* __restrict__ gall,
     double* __restrict__ vall) {
   constexpr int T = 64;   // a role of a tile is one wave
-  // (the waves a half has beyond its compute and DMA waves: pl_extra_waves)
-  // NST: 0 = the waves of a workgroup meet at s_barrier once per tile; -1 = they meet through counters in LDS (FS) and the
-  // compute waves store their Jacobian columns themselves; n > 0 = counters, and n store waves per half take the columns
-  // -2 = counters, and one more wave per half takes the constant block off the DMA waves
-  constexpr bool FS = NST != 0;
-  constexpr int NSW = NST > 0 ? NST : 0;
-  constexpr int NCW = NST == -2 ? 1 : 0;
-  constexpr int HT = 64 * (RG + NDMA + NSW + NCW);   // threads of one half
-  static_assert(!FS || !DXM, "the matrix-core D.X variant keeps the barrier scheme");
+  constexpr int HT = 64 * (RG + NDMA);   // threads of one half
   constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
   constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1;
   constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
@@ -819,28 +779,11 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
   const int S_TT = PL_REC, S_X = S_TT + 2, S_U = S_X + NX * K.max_span, S_D = S_U + NU * T;
   const int S_TAU = S_D + K.max_drow, S_DG = S_TAU + T, S_ND = S_DG + T, S_CV = S_ND + 2 * T;
   const int S_SIZE = S_CV + (WJ ? K.max_cshare : 0);
-  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T + 2 + (DXM ? NX * T : 0) + (FS ? pl_fs_extra(NO, RG, NSW) : 0));
-  double* Fb0 = lds + 2 * S_SIZE;
-  int* fb_ready = reinterpret_cast<int*>(Fb0 + (NX + NC) * T);   // tile count for which Fb holds the unperturbed dynamics
+  double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T + 2 + (DXM ? NX * T : 0));
+  double* Fb = lds + 2 * S_SIZE;             // [NO][T] unperturbed f and c of the current tile
+  int* fb_ready = reinterpret_cast<int*>(Fb + (NX + NC) * T);   // tile count for which Fb holds the unperturbed dynamics
   int* dx_ready = fb_ready + 1;                                 // dx_mode 1: DMA waves that have published their rows of D.X, summed over tiles
-  double* DXs = Fb0 + (NX + NC) * T + 2;                         // dx_mode 1: [NX][T] D.X of the current tile (matrix cores)
-  // With FS nothing in this kernel waits at s_barrier after the first one: the waves of a half meet through
-  // counters in LDS.  SY[0] `staged`: DMA waves whose loads of a tile have landed, summed over tiles; SY[1], SY[2] `consumed`: compute
-  // waves that have finished an even / odd tile (its staging buffer and its copy of the unperturbed outputs may be overwritten);
-  // SY[4+g] / SY[4+RG+g]: Jacobian columns compute wave g has put into its slot / the store wave has taken out of it.
-  // The compute waves then never issue a Jacobian store: they write a finished column (64 nodes x NO rows) into their slot
-  // and go on with the next pass while the store wave streams it out — a wave that issues stores into a saturated write
-  // path is held at the instruction, and with one workgroup per CU nothing else would run meanwhile.
-  double* Fb1 = Fb0 + (NX + NC) * T + 2;
-  int* SY = reinterpret_cast<int*>(Fb1 + (NX + NC) * T);
-  double* SL = Fb1 + (NX + NC) * T + 16;
-  constexpr int SLOT = NO * T + 8;
-  static_assert(!FS || 4 + 2 * RG <= 32, "counters of the store-wave scheme");
-  if constexpr (FS) {
-    if (tid < 4 + 2 * RG) SY[tid] = 0;
-    if (tid == 0) { *fb_ready = 0; *dx_ready = 0; }
-    __syncthreads();
-  }
+  double* DXs = Fb + (NX + NC) * T + 2;                         // dx_mode 1: [NX][T] D.X of the current tile (matrix cores)
 #ifdef RPM_DIAG
 #define RPM_PTRC(j, slot)                                                           \
   if (K.trace && (threadIdx.x & 63) == 0 && (j) < 2) K.trace[size_t(w) * 64 + (j)*32 + (slot)] = wall_clock64()
@@ -888,92 +831,9 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
     if (WJ) run(K.diag + tl.node0 + tl.k0, buf + S_DG, tl.cnt);
     run(reinterpret_cast<const double*>(K.nodes + tl.node0 + tl.k0), buf + S_ND, 2 * tl.cnt);
     if (WG) run(K.dvals + tl.drow0, buf + S_D, tl.drow_len);
-    if (WJ) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
+    if (WJ && !K.skip_const) run(K.doff_vals + tl.c_src0, buf + S_CV, tl.c_cnt);
   };
-  // Experiment RPM_PL_ALL_STAGE_FIRST: the FIRST tile of a half staged by all its waves — the compute waves have nothing else
-  // to do until it is there, and two DMA waves take 2.5-2.8 us to issue a tile's loads (of 4 us from the first wave's start
-  // to the first barrier, tools/trace_pipeline.py).  Bit-identical; measured 50.4 / 104.0 / 28.7 us against 50.7 / 104.4 /
-  // 27.6 (1024 quadrotor instances, 64 and 16 iterates of the metric problem): nothing, so it is off — the trace shows why: six waves
-  // issue the same ~30 direct-to-LDS loads in 1.8 us instead of 2.5, and the last of them lands 2.0 us later instead of 0.5; the
-  // CU takes these loads at a fixed rate whoever issues them.  Barrier scheme only.
-  constexpr int NP0 = (FS || !RPM_PL_ALL_STAGE_FIRST) ? NDMA : RG + NDMA;
   const auto first_runs = [&]() { return runs_of((const __attribute__((address_space(4))) int*)(K.tiles + (w - (w / nt) * nt))); };
-  if (NSW > 0 && tid >= NTHR + 64 * NDMA) {
-    // ---------------- store waves: take finished Jacobian columns out of the compute waves' slots (round robin) ----------------
-    const int lane = tid & 63;
-    const int sw = __builtin_amdgcn_readfirstlane((tid - NTHR - 64 * NDMA) >> 6);
-    int taken[RG];
-#pragma unroll
-    for (int gi = 0; gi < RG; ++gi) taken[gi] = 0;
-    int open_slots = 0;
-    for (int gi = sw; gi < RG; gi += (NSW > 0 ? NSW : 1)) ++open_slots;
-    int idle = 0;
-    while (open_slots > 0 && idle < (1 << 22)) {
-      bool any = false;
-#pragma unroll
-      for (int gi = 0; gi < RG; ++gi) {
-        if (gi % (NSW > 0 ? NSW : 1) != sw || taken[gi] < 0) continue;
-        if (PL_LD(SY + 4 + gi) <= taken[gi]) continue;
-        any = true;
-        const double* sl = SL + gi * SLOT;
-        const int* hd = reinterpret_cast<const int*>(sl);
-        const int cnt_e = __builtin_amdgcn_readfirstlane(hd[2]);
-        if (cnt_e < 0) { taken[gi] = -1; --open_slots; continue; }   // that compute wave is done
-        const int stride = __builtin_amdgcn_readfirstlane(hd[3]);
-        const long long base = (long long)(unsigned(__builtin_amdgcn_readfirstlane(hd[0]))) |
-                               ((long long)__builtin_amdgcn_readfirstlane(hd[1]) << 32);
-#if RPM_PL_ST16
-        // 16 bytes per lane: one instruction stores two rows of the column (lanes 0-31 row o, lanes 32-63 row o + 1), so a
-        // wave's 63 stores in flight carry 1 KB each
-        constexpr int NP = (NO + 1) / 2;
-        const int hl = lane & 31, ho = lane >> 5;
-        d2u pr[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          const int o = min(2 * i + ho, NO - 1);
-          pr[i] = *reinterpret_cast<const d2u*>(sl + 8 + o * T + 2 * hl);
-        }
-        ++taken[gi];
-        __hip_atomic_store(SY + 4 + RG + gi, taken[gi], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the slot is free again
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          const int o = 2 * i + ho;
-          double* __restrict__ dst = vall + base + size_t(o) * stride + 2 * hl;
-          if (o < NO) {
-            if (2 * hl + 1 < cnt_e) *reinterpret_cast<d2u*>(dst) = pr[i];
-            else if (2 * hl < cnt_e) *dst = pr[i].x;
-          }
-        }
-#else
-        double col[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) col[o] = sl[8 + o * T + lane];
-        ++taken[gi];
-        __hip_atomic_store(SY + 4 + RG + gi, taken[gi], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the slot is free again
-        if (lane < cnt_e) {
-          double* __restrict__ dst = vall + base + lane;
-#pragma unroll
-          for (int o = 0; o < NO; ++o) dst[size_t(o) * stride] = col[o];
-        }
-#endif
-      }
-      if (any) { idle = 0; } else { __builtin_amdgcn_s_sleep(1); ++idle; }
-    }
-    return;
-  }
-  if (NCW > 0 && tid >= NTHR + 64 * (NDMA + NSW)) {
-    // ---------------- constant-block wave: the tile's share of the Doffdiag block, once the tile is staged.  On a DMA wave
-    // these stores sit in front of the next tile's loads in the same counter, and `the loads have landed` then also means
-    // `the stores have drained` — behind every Jacobian store of the CU (4 us per tile of the 1024-instance quadrotor sweep) --------
-    const int lane = tid & 63;
-    for (int j = 0; j < n_iter; ++j) {
-      const double* cur = lds + (j & 1) * S_SIZE;
-      PL_SPIN(PL_LD(SY) >= NDMA * (j + 1));
-      if (WJ) pl_const_stores<NX, 1>(cur, cur + S_CV, NREC, vall, K.sv, lane, 0);
-      if (lane == 0) __hip_atomic_fetch_add(SY + 1 + (j & 1), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // its values are in registers
-    }
-    return;
-  }
   if (tid >= NTHR) {
     // ---------------- DMA waves (two: a direct-to-LDS load takes ~60 ns to issue, so the runs of a tile and the
     // chunks of the constant block are dealt alternately to them) ----------------
@@ -982,24 +842,19 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
     // The DMA waves' instruction stream is long and scalar; sharing a SIMD with three busy compute waves it would get
     // a quarter of the issue slots (4 us to issue one tile's loads).  They run at raised priority instead.
     __builtin_amdgcn_s_setprio(3);
-    if (!FS && dw == 0 && lane == 0) { *fb_ready = 0; *dx_ready = 0; }
+    if (dw == 0 && lane == 0) { *fb_ready = 0; *dx_ready = 0; }
     // the tile table never changes: constant address space, i.e. scalar loads for the first record
     {
       const auto r0 = first_runs();
       RPM_PTRC(0, 19);
-      if (n_iter > 0) stage(std::integral_constant<int, NP0>{}, NP0 == NDMA ? dw : RG + dw, lane, w, lds, r0);
+      if (n_iter > 0) stage(std::integral_constant<int, NDMA>{}, dw, lane, w, lds, r0);
       RPM_PTRC(0, 20);
     }
-    for (int j = 0; j < (FS ? n_iter : n_iter_wg); ++j) {
+    for (int j = 0; j < n_iter_wg; ++j) {
       const double* cur = lds + (j & 1) * S_SIZE;
       double* nxt = lds + ((j + 1) & 1) * S_SIZE;
       __builtin_amdgcn_s_waitcnt(0);   // the staged loads (and the constant stores before them) have landed
-      if constexpr (FS) {         // A: buffer `cur` is complete once every DMA wave has said so
-        if (lane == 0) __hip_atomic_fetch_add(SY, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        PL_SPIN(PL_LD(SY) >= NDMA * (j + 1));
-      } else {
-        __syncthreads();               // A: buffer `cur` is complete
-      }
+      __syncthreads();                 // A: buffer `cur` is complete
       RPM_PTRC(j, 16);
       if constexpr (DXM && WG) {
         // dx_mode 1: the tile's D.X on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), by the DMA waves — the matrix pipe is
@@ -1052,13 +907,9 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
       // in their first pass and store nothing; then the next tile's loads.  (The order matters twice: an LDS read of
       // this wave after the direct-to-LDS loads would wait for them, and the Jacobian stores of the later passes
       // should not meet these in the memory system.)
-      if (WJ && NCW == 0 && j < n_iter) pl_const_stores<NX, NDMA>(cur, cur + S_CV, NREC, vall, K.sv, lane, dw);
+      if (WJ && !K.skip_const && j < n_iter) pl_const_stores<NX, NDMA>(cur, cur + S_CV, NREC, vall, K.sv, lane, dw);
       RPM_PTRC(j, 17);
       if (j + 1 < n_iter) {
-        // `nxt` was tile j-1's buffer: every compute wave must be through with it.  One counter per tile parity — waves that
-        // are done with tile j-1 may already have finished tile j, and a single running count would take their second
-        // arrival for a slower wave's first; tile j+1 is not staged yet, so the counter of j-1's parity is exact here
-        if constexpr (FS) { if (j >= 1) PL_SPIN(PL_LD(SY + 1 + ((j - 1) & 1)) >= (RG + NCW) * ((j - 1) / 2 + 1)); }
         stage(std::integral_constant<int, NDMA>{}, dw, lane, w + (j + 1) * G, nxt, runs_of(reinterpret_cast<const int*>(cur) + PL_REC));
       }
       RPM_PTRC(j, 18);
@@ -1080,25 +931,12 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
 #endif
   // ---------------- compute waves: the role loop of rpm_tile_rl_kernel out of the staged buffer ----------------
   const int kk = tid % T, grp = __builtin_amdgcn_readfirstlane(tid / T);   // a wave is one role group: roles are wave-uniform (scalar branches, scalar block offsets)
-  if constexpr (NP0 != NDMA) {
-    if (n_iter > 0) stage(std::integral_constant<int, NP0>{}, grp, kk, w, lds, first_runs());
-  }
-  int n_emit = 0;   // Jacobian columns this wave has handed to the store wave
-  int* const my_full = SY + 4 + grp;
-  int* const my_done = SY + 4 + RG + grp;
-  double* const my_slot = SL + grp * SLOT;
-  for (int jt = 0; jt < (FS ? n_iter : n_iter_wg); ++jt) {
+  for (int jt = 0; jt < n_iter_wg; ++jt) {
     const double* cur = lds + (jt & 1) * S_SIZE;
-    double* const Fb = (FS && (jt & 1)) ? Fb1 : Fb0;
     // A, without draining this wave's Jacobian stores: __syncthreads() is fence + s_barrier and the fence waits for
     // vmcnt(0); the stores of tile jt-1 go to addresses nobody in this launch reads, only the LDS traffic has to be over
     // (+0.7 % at 64 iterates per launch, nothing at 16: the store phases are back-pressure, not this wait)
-    if constexpr (FS) {
-      PL_SPIN(PL_LD(SY) >= NDMA * (jt + 1));
-    } else {
-      if (NP0 != NDMA && jt == 0) __builtin_amdgcn_s_waitcnt(0);   // this wave's share of the first tile's loads has landed
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (jt >= n_iter) continue;   // the other half still has a tile: keep the barrier count
     if (grp < 4) { RPM_PTRC(jt, grp * 4 + 0); }
     const int* rec = reinterpret_cast<const int*>(cur);
@@ -1226,27 +1064,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
             J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
           }
           double* __restrict__ vb = vals + v_nl0;   // block bases stay scalar; the node index k is the only per-lane part
-          // store-wave scheme: column `c` of the tile (rows o = 0..NO-1, this lane's node) goes into the wave's slot; the
-          // header says where it belongs: element (o, lane) at vall[base + o * stride + lane] for lane < cnt
-          auto emit = [&](int c, const double (&col)[NO]) {
-            // lane 0 is active in every tile; a lane beyond a short tile's nodes skips that tile's emissions, so its own count lags
-            const int ne = __builtin_amdgcn_readfirstlane(n_emit);
-            PL_SPIN(PL_LD(my_done) >= ne);
-#pragma unroll
-            for (int o = 0; o < NO; ++o) my_slot[8 + o * T + kk] = col[o];
-            n_emit = ne + 1;
-            if (kk == 0) {
-              const long long base = (long long)inst * K.sv + v_nl0 + (long long)c * N + k0;
-              int* hd = reinterpret_cast<int*>(my_slot);
-              hd[0] = int(unsigned(base & 0xffffffffll));
-              hd[1] = int(base >> 32);
-              hd[2] = cnt;
-              hd[3] = NB * N;
-            }
-            if (kk == 0) __hip_atomic_store(my_full, n_emit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          };
           if (v < NX + NU) {            // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
-            double col[NO];
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
               double val;
@@ -1256,13 +1074,10 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
               } else {
                 val = J[o];
               }
-              if constexpr (NSW > 0) col[o] = val;
-              else RPM_JSTORE((vb + size_t(o * NB + v) * N)[k], val);
+              RPM_JSTORE((vb + size_t(o * NB + v) * N)[k], val);
             }
-            if constexpr (NSW > 0) emit(v, col);
           } else {                       // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign kept
             const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
-            double col0[NO], colf[NO];
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
               double v0, vf;
@@ -1275,17 +1090,8 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
                 v0 = a0 * J[o];
                 vf = af * J[o];
               }
-              if constexpr (NSW > 0) {
-                col0[o] = v0;
-                colf[o] = vf;
-              } else {
-                RPM_JSTORE((vb + size_t(o * NB + NX + NU) * N)[k], v0);
-                RPM_JSTORE((vb + size_t(o * NB + NX + NU + 1) * N)[k], vf);
-              }
-            }
-            if constexpr (NSW > 0) {
-              emit(NX + NU, col0);
-              emit(NX + NU + 1, colf);
+              RPM_JSTORE((vb + size_t(o * NB + NX + NU) * N)[k], v0);
+              RPM_JSTORE((vb + size_t(o * NB + NX + NU + 1) * N)[k], vf);
             }
           }
         }
@@ -1295,16 +1101,6 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA + pl_extra_waves(NST)), (NH ==
 #endif
     }
     if (grp < 4) { RPM_PTRC(jt, grp * 4 + 3); }
-    if constexpr (FS) {   // through with this tile's staging buffer and with Fb
-      if (kk == 0) __hip_atomic_fetch_add(SY + 1 + (jt & 1), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-  if constexpr (NSW > 0) {   // tell the store wave that nothing more comes out of this slot
-    if (kk == 0) {
-      PL_SPIN(PL_LD(my_done) >= n_emit);
-      reinterpret_cast<int*>(my_slot)[2] = -1;
-      __hip_atomic_store(my_full, n_emit + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
   }
 }
 
@@ -1320,13 +1116,13 @@ void tile_pipeline_setup(Engine& e, Device* d, const ProblemDims& pd, int device
     with_problem(e.problem_id, [&](auto prob) {
       using P = decltype(prob);
       constexpr PlShape S = pl_shape(P::NX + P::NU + 2);
-      d->pl_lds = S.NH * (2 * stage + size_t(pd.nx + pd.nc) * 64 + 2 + (S.NST != 0 ? pl_fs_extra(pd.nx + pd.nc, S.RG, S.NST > 0 ? S.NST : 0) : 0)) * sizeof(double);
+      d->pl_lds = S.NH * (2 * stage + size_t(pd.nx + pd.nc) * 64 + 2) * sizeof(double);
       if (d->pl_lds > 160 * 1024) return;
-      auto kern = rpm_tile_pl_kernel<P, S.NH, S.RG, S.NDMA, S.NST, true, true, false>;
+      auto kern = rpm_tile_pl_kernel<P, S.NH, S.RG, S.NDMA, true, true, false>;
       if (d->pl_lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   int(d->pl_lds));
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, S.NH * 64 * (S.RG + S.NDMA + pl_extra_waves(S.NST)), d->pl_lds) != hipSuccess)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, S.NH * 64 * (S.RG + S.NDMA), d->pl_lds) != hipSuccess)
         per_cu = 0;
       (void)hipGetLastError();
       per_cu *= S.NH;   // resident halves per CU
@@ -1386,8 +1182,7 @@ template <class Prob, bool WG, bool WJ, bool AN, bool DXM = false>
 static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
   const Device& d = *e.dev;
   constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2);
-  constexpr int NST = DXM ? 0 : S.NST;   // the matrix-core D.X variant keeps the barrier scheme
-  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, NST, WG, WJ, AN, DXM>;
+  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN, DXM>;
   const size_t lds = d.pl_lds + (DXM ? size_t(S.NH) * Prob::NX * 64 * sizeof(double) : 0);
   if (lds > 64 * 1024) {
     hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -1395,7 +1190,7 @@ static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const doubl
   }
   const long long W = (long long)d.kp.n_my_tiles * e.n_instances;
   const long long halves = W < d.pl_slots ? W : d.pl_slots;   // pl_slots: resident halves (occupancy query)
-  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA + pl_extra_waves(NST))), lds, st, kp,
+  hipLaunchKernelGGL(kern, dim3(unsigned((halves + S.NH - 1) / S.NH)), dim3(S.NH * 64 * (S.RG + S.NDMA)), lds, st, kp,
                      e.n_instances, dx, dg, dv);
   return hipGetLastError();
 }
@@ -1487,6 +1282,19 @@ int dev_eval_cons(Engine& e, const double* d_x, double* d_g, double* d_values, i
   kp.sv = (flags & 4) ? e.stride_values() : e.nnz_jac;
   // flags bit 3 (host-pointer path, one-role kernel only): OR "a stored value is NaN/Inf" into the engine's two host-visible words
   kp.chk = ((flags & 8) && dev_cons_is_one_role(e)) ? e.dev->d_flags2 : nullptr;
+  // flags bit 4 (persistent `values`, SURVEY 8d's B'): the caller keeps handing the same device array and leaves its constant
+  // Doffdiag block alone; the block (55 % of the metric problem's bytes) is written the first time this engine sees the array
+  // and skipped afterwards (neither loaded nor stored)
+  kp.skip_const = 0;
+  if (wj && (flags & 16) && d_values) {
+    auto& seen = e.dev->const_filled;
+    if (std::find(seen.begin(), seen.end(), d_values) != seen.end()) {
+      kp.skip_const = 1;
+    } else {
+      if (seen.size() >= 4096) seen.clear();
+      seen.push_back(d_values);
+    }
+  }
   hipError_t s = hipErrorInvalidValue;
   with_problem(e.problem_id, [&](auto prob) {
     using P = decltype(prob);

@@ -423,6 +423,63 @@ def test_pipelined_kernel_is_bit_identical(built, name, make, mode, B):
     pl.close()
 
 
+@pytest.mark.parametrize("layout", ["one_role", "role_looped", "pipelined"])
+def test_persistent_values_skips_only_the_constant_block(built, layout):
+    """Option persistent_values (SURVEY 8d's byte count B'): the second evaluation into a device `values` array this engine
+    filled before writes everything that depends on x and leaves the constant Doffdiag block alone — the array equals a
+    complete evaluation bit for bit; a marker the test plants inside that block survives (that the block is skipped is the
+    contract, not an accident); another array, and the same array after any rpm_set_option, get everything."""
+    import torch
+    prob, B = _launch_ragged(), 9
+    kw = {"one_role": dict(role_loop=0), "role_looped": dict(role_loop=1), "pipelined": dict(role_loop=1)}[layout]
+    eng = NLPEngine(prob, n_instances=B, device=0, **kw)
+    ref = NLPEngine(prob, n_instances=B, device=0, **kw)
+    for e in (eng, ref):
+        if layout != "one_role":
+            e.set_option("pipeline", 1 if layout == "pipelined" else 0)
+    eng.set_option("persistent_values", 1)
+    one = NLPEngine(prob, device=0)
+    xl, xu, _, _ = one.get_bounds_info()
+    x0 = one.get_starting_point()
+    nnz, nnz_const = one.nnz_jac, None
+    i, j = one.eval_jac_g_structure()
+    one.close()
+    xs = [torch.from_numpy(np.stack([problems.seeded_iterate(x0, xl, xu, 200 + 10 * r + b) for b in range(B)])).cuda() for r in range(3)]
+    dg = torch.empty((B, eng.m), dtype=torch.float64, device="cuda")
+    dv = torch.full((B, nnz), np.nan, dtype=torch.float64, device="cuda")
+    rv = torch.empty((B, nnz), dtype=torch.float64, device="cuda")
+    eng.eval_pair_dev(xs[0], dg, dv)
+    ref.eval_pair_dev(xs[0], dg, rv)
+    torch.cuda.synchronize()
+    assert torch.equal(dv, rv)
+    const_entries = (dv[0] == dv[1]) & (dv[0] == dv[2])           # certainly contains the constant block
+    marker_at = nnz - 5                                           # inside the Doffdiag copies (the CONST block is the tail)
+    assert bool(const_entries[marker_at])
+    dv[:, marker_at] = 4711.0
+    torch.cuda.synchronize()
+    eng.eval_pair_dev(xs[1], dg, dv)
+    ref.eval_pair_dev(xs[1], dg, rv)
+    torch.cuda.synchronize()
+    assert bool((dv[:, marker_at] == 4711.0).all())
+    dv[:, marker_at] = rv[:, marker_at]
+    assert torch.equal(dv, rv)
+    eng.eval_jac_g_dev(xs[2], dv)                                 # the Jacobian-only entry point takes the same shortcut
+    ref.eval_jac_g_dev(xs[2], rv)
+    other = torch.full((B, nnz), np.nan, dtype=torch.float64, device="cuda")
+    eng.eval_jac_g_dev(xs[2], other)                              # an array the engine has not seen: everything
+    torch.cuda.synchronize()
+    assert torch.equal(dv, rv) and torch.equal(other, rv)
+    dv[:, marker_at] = 4711.0
+    eng.set_option("persistent_values", 1)                        # any rpm_set_option forgets the arrays
+    torch.cuda.synchronize()
+    eng.eval_pair_dev(xs[0], dg, dv)
+    ref.eval_pair_dev(xs[0], dg, rv)
+    torch.cuda.synchronize()
+    assert torch.equal(dv, rv)
+    eng.close()
+    ref.close()
+
+
 # ---- solution extraction (Nlp2OpConverter::Nlp2OpControl, SURVEY §8 row f-4) --------------------------------
 @pytest.mark.parametrize("name,make", [("launch", lambda: problems.launch(3, 6)), ("quadrotor", lambda: problems.quadrotor(4, 5)),
                                        ("hypersensitive", lambda: problems.config("hypersensitive")),
