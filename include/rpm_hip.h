@@ -52,6 +52,8 @@ enum {
   RPM_PROBLEM_BRACHISTOCHRONE = 4, /* authored here (BASELINE config 1) */
   RPM_PROBLEM_MIN_TIME_CLIMB = 5,  /* authored here (BASELINE config 2) */
   RPM_PROBLEM_QUADROTOR = 6,       /* authored here (BASELINE config 5) */
+  RPM_PROBLEM_PARAM_SLED = 7,      /* authored here: minimum-time sled with one static parameter (nq = 1), known optimum 2.5 */
+  RPM_PROBLEM_PARAM_OSC = 8,       /* authored here: two linked phases, two static parameters each (nq = 2), path + events + links on them */
   RPM_PROBLEM_USER = 100           /* the functor `rpm::UserProblem` of a user's header, in a library built from that header
                                       (lpopc_amd/userproblem.py, INTEGRATION.md "your own problem"): the stand-in for
                                       subclassing FunctionWrapper (Core/LpFunctionWrapper.h:50-69) */

@@ -1,12 +1,18 @@
 // problems.hpp — pointwise device functors that stand where the reference's host-side
 // FunctionWrapper subclasses stand (Core/LpFunctionWrapper.h:50-69).  One struct per problem:
 //
-//   dims     NX, NU, NC, NE_MAX, NLINK_MAX, NCONST, HAS_ANALYTIC
+//   dims     NX, NU, NC, NE_MAX, NLINK_MAX, NCONST, HAS_ANALYTIC  [, NQ: static parameters per phase, default 0]
 //   dae      f(t,x,u) and path c(t,x,u) at ONE collocation node  (FunctionWrapper::DaeFunction)
 //   event    FunctionWrapper::EventFunction      link   FunctionWrapper::LinkFunction
 //   mayer    FunctionWrapper::MayerCost          lagrange  FunctionWrapper::LagrangeCost (one node)
 //   dae_jac_col / lagrange_grad_col / ...  one column of the user's analytic derivative
 //                                          (FunctionWrapper::Deriv*, used with first-derive=analytic)
+//
+// A functor with NQ > 0 takes the phase's static parameters (SolDae::parameter_ etc., Core/LpFunctionWrapper.h:12-49) as
+// one more argument `p` right before the constants: dae(ph,t,x,u,p,c,f,cp), lagrange(ph,t,x,u,p,c), mayer(ph,t0,x0,tf,xf,p,c),
+// event(ph,t0,x0,tf,xf,p,c,ev), link(lph,rph,xl,xr,pl,pr,c,nlink,lo); derivative columns are ordered [x.., u.., t, p..]
+// (dae / lagrange, Core/LpFiniteDifferenceDerive.cpp:299-317), [x0.., t0, xf.., tf, p..] (event / mayer, :326-409) and
+// [xf_left.., p_left.., x0_right.., p_right..] (link, :411-502).  The kernels call through the pf_* helpers below.
 //
 // `ph` is the 1-based phase number the reference passes as phase_num_; `c` are the problem
 // constants (the reference keeps them in globals).  Operation order follows the reference's
@@ -20,6 +26,62 @@
 namespace rpm {
 
 #define RPM_DEV __device__ __forceinline__
+
+// ---- static parameters: NQ of a functor (0 when it does not declare one) and the calls that pass `p` only to functors
+//      that take it ----
+template <class P, class = void> struct prob_nq { static constexpr int value = 0; };
+template <class P> struct prob_nq<P, decltype(void(P::NQ))> { static constexpr int value = P::NQ; };
+
+template <class P, class CP>
+RPM_DEV void pf_dae(int ph, double t, const double* x, const double* u, const double* p, CP c, double* f, double* cp) {
+  if constexpr (prob_nq<P>::value > 0) P::dae(ph, t, x, u, p, c, f, cp);
+  else P::dae(ph, t, x, u, c, f, cp);
+}
+template <class P, class CP>
+RPM_DEV void pf_dae_jac_col(int ph, int v, double t, const double* x, const double* u, const double* p, CP c, double* df, double* dc) {
+  if constexpr (prob_nq<P>::value > 0) P::dae_jac_col(ph, v, t, x, u, p, c, df, dc);
+  else P::dae_jac_col(ph, v, t, x, u, c, df, dc);
+}
+template <class P>
+RPM_DEV double pf_lagrange(int ph, double t, const double* x, const double* u, const double* p, const double* c) {
+  if constexpr (prob_nq<P>::value > 0) return P::lagrange(ph, t, x, u, p, c);
+  else return P::lagrange(ph, t, x, u, c);
+}
+template <class P>
+RPM_DEV double pf_lagrange_grad_col(int ph, int v, double t, const double* x, const double* u, const double* p, const double* c) {
+  if constexpr (prob_nq<P>::value > 0) return P::lagrange_grad_col(ph, v, t, x, u, p, c);
+  else return P::lagrange_grad_col(ph, v, t, x, u, c);
+}
+template <class P>
+RPM_DEV double pf_mayer(int ph, double t0, const double* x0, double tf, const double* xf, const double* p, const double* c) {
+  if constexpr (prob_nq<P>::value > 0) return P::mayer(ph, t0, x0, tf, xf, p, c);
+  else return P::mayer(ph, t0, x0, tf, xf, c);
+}
+template <class P>
+RPM_DEV double pf_mayer_grad_col(int ph, int q, double t0, const double* x0, double tf, const double* xf, const double* p, const double* c) {
+  if constexpr (prob_nq<P>::value > 0) return P::mayer_grad_col(ph, q, t0, x0, tf, xf, p, c);
+  else return P::mayer_grad_col(ph, q, t0, x0, tf, xf, c);
+}
+template <class P>
+RPM_DEV void pf_event(int ph, double t0, const double* x0, double tf, const double* xf, const double* p, const double* c, double* ev) {
+  if constexpr (prob_nq<P>::value > 0) P::event(ph, t0, x0, tf, xf, p, c, ev);
+  else P::event(ph, t0, x0, tf, xf, c, ev);
+}
+template <class P>
+RPM_DEV void pf_event_jac_col(int ph, int v, double t0, const double* x0, double tf, const double* xf, const double* p, const double* c, double* de) {
+  if constexpr (prob_nq<P>::value > 0) P::event_jac_col(ph, v, t0, x0, tf, xf, p, c, de);
+  else P::event_jac_col(ph, v, t0, x0, tf, xf, c, de);
+}
+template <class P>
+RPM_DEV void pf_link(int lph, int rph, const double* xl, const double* xr, const double* pl, const double* pr, const double* c, int nlink, double* lo) {
+  if constexpr (prob_nq<P>::value > 0) P::link(lph, rph, xl, xr, pl, pr, c, nlink, lo);
+  else P::link(lph, rph, xl, xr, c, nlink, lo);
+}
+template <class P>
+RPM_DEV void pf_link_jac_col(int lph, int rph, int v, const double* xl, const double* xr, const double* pl, const double* pr, const double* c, int nlink, double* dl) {
+  if constexpr (prob_nq<P>::value > 0) P::link_jac_col(lph, rph, v, xl, xr, pl, pr, c, nlink, dl);
+  else P::link_jac_col(lph, rph, v, xl, xr, c, nlink, dl);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Delta-III launch vehicle ascent — example/launch/Launch.cpp:636-765
@@ -331,6 +393,86 @@ struct QuadrotorProblem {
     const double u0 = f4[0] - hov, u1 = f4[1] - hov, u2 = f4[2] - hov, u3 = f4[3] - hov;
     const double eu = ((u0 * u0 + u1 * u1) + u2 * u2) + u3 * u3;
     return (((c[10] * ep + c[11] * evv) + c[12] * ea) + c[13] * ew) + c[14] * eu;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Minimum-time sled with a design parameter (authored here; nq = 1).  States (x, v), control u in [-1, 1], parameter p > 0
+// scales the available acceleration: x' = v, v' = p u, from rest at 0 to rest at 1; cost tf + c0 p^2.  Bang-bang in u:
+// tf = 2 / sqrt(p), so the cost 2 p^(-1/2) + c0 p^2 has its minimum at p = (2 c0)^(-2/5) — with c0 = 0.5: p = 1, cost 2.5
+// (tests/test_known_answers.py).  consts: [0] c0.
+struct ParamSledProblem {
+  static constexpr int ID = RPM_PROBLEM_PARAM_SLED;
+  static constexpr int NX = 2, NU = 1, NQ = 1, NC = 0, NE_MAX = 4, NLINK_MAX = 0, NCONST = 1;
+  static constexpr bool HAS_ANALYTIC = true;
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* u, const double* p, CP, double* f, double*) {
+    f[0] = x[1];
+    f[1] = p[0] * u[0];
+  }
+  RPM_DEV static void event(int, double, const double* x0, double, const double* xf, const double*, const double*, double* ev) {
+    ev[0] = x0[0];
+    ev[1] = x0[1];
+    ev[2] = xf[0];
+    ev[3] = xf[1];
+  }
+  RPM_DEV static void link(int, int, const double*, const double*, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer(int, double, const double*, double tf, const double*, const double* p, const double* c) {
+    return tf + c[0] * (p[0] * p[0]);
+  }
+  RPM_DEV static double lagrange(int, double, const double*, const double*, const double*, const double*) { return 0.0; }
+  // analytic columns: dae [x, v, u, t, p]; mayer / event [x0(2), t0, xf(2), tf, p]
+  template <class CP = const double*>
+  RPM_DEV static void dae_jac_col(int, int v, double, const double*, const double* u, const double* p, CP, double* df, double*) {
+    df[0] = (v == 1) ? 1.0 : 0.0;
+    df[1] = (v == 2) ? p[0] : (v == 4 ? u[0] : 0.0);
+  }
+  RPM_DEV static void event_jac_col(int, int v, double, const double*, double, const double*, const double*, const double*, double* de) {
+    de[0] = (v == 0) ? 1.0 : 0.0;
+    de[1] = (v == 1) ? 1.0 : 0.0;
+    de[2] = (v == 3) ? 1.0 : 0.0;
+    de[3] = (v == 4) ? 1.0 : 0.0;
+  }
+  RPM_DEV static void link_jac_col(int, int, int, const double*, const double*, const double*, const double*, const double*, int, double*) {}
+  RPM_DEV static double mayer_grad_col(int, int q, double, const double*, double, const double*, const double* p, const double* c) {
+    return q == 5 ? 1.0 : (q == 6 ? 2.0 * c[0] * p[0] : 0.0);
+  }
+  RPM_DEV static double lagrange_grad_col(int, int, double, const double*, const double*, const double*, const double*) { return 0.0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Damped oscillator with stiffness and weighting parameters over two linked phases (authored here; nq = 2 per phase): every
+// callback depends on the parameters — dynamics (stiffness p0), path constraint and running cost (p1), terminal cost and
+// events, and the linkage ties the parameters of the two phases together.  consts: [0] damping, [1] weight of p0^2.
+struct ParamOscProblem {
+  static constexpr int ID = RPM_PROBLEM_PARAM_OSC;
+  static constexpr int NX = 2, NU = 1, NQ = 2, NC = 1, NE_MAX = 2, NLINK_MAX = 4, NCONST = 2;
+  static constexpr bool HAS_ANALYTIC = false;
+  template <class CP = const double*>
+  RPM_DEV static void dae(int, double, const double* x, const double* u, const double* p, CP c, double* f, double* cp) {
+    f[0] = x[1];
+    f[1] = (-(p[0] * x[0]) - c[0] * x[1]) + u[0];
+    cp[0] = x[0] + p[1] * u[0];
+  }
+  RPM_DEV static void event(int ph, double, const double* x0, double, const double* xf, const double* p, const double*, double* ev) {
+    if (ph == 1) {
+      ev[0] = x0[0];
+      ev[1] = x0[1];
+    } else {
+      ev[0] = xf[0] + p[1];
+    }
+  }
+  RPM_DEV static void link(int, int, const double* xl, const double* xr, const double* pl, const double* pr, const double*, int, double* lo) {
+    lo[0] = xl[0] - xr[0];
+    lo[1] = xl[1] - xr[1];
+    lo[2] = pl[0] - pr[0];
+    lo[3] = pl[1] - pr[1];
+  }
+  RPM_DEV static double mayer(int ph, double, const double*, double, const double* xf, const double* p, const double*) {
+    return ph == 2 ? xf[0] * xf[0] + p[0] * p[1] : 0.0;
+  }
+  RPM_DEV static double lagrange(int, double, const double* x, const double* u, const double* p, const double* c) {
+    return (u[0] * u[0] + p[1] * (x[0] * x[0])) + c[1] * (p[0] * p[0]);
   }
 };
 

@@ -437,7 +437,8 @@ int rpm_final_result_save(rpm_engine* h, const char* dir) {
       return true;
     };
     if (!save("time", t.data(), M, 1) || !save("state", st.data(), M, p.nx) || !save("control", ct.data(), M, p.nu) ||
-        !save("parameter", nullptr, 0, 0) || !save("costate", cs.data(), M, p.nx) || !save("Hamiltonian", ham.data(), M, 1))
+        !save("parameter", e.sol_x.data() + p.var0 + p.nx * (p.N + 1) + p.nu * p.N + 2, p.nq, 1) ||   // result_data_i->parameter, Nlp2OPConverter.cpp:153,213-214
+ !save("costate", cs.data(), M, p.nx) || !save("Hamiltonian", ham.data(), M, 1))
       return fail(e, RPM_E_INVALID, "final_result_save: cannot write the result files");
   }
   return RPM_OK;

@@ -14,9 +14,9 @@ namespace rpm {
 template <class Prob, bool GRAD, bool AN>
 __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall, double* __restrict__ objall,
                                double* __restrict__ gradall, double* __restrict__ partial) {
-  constexpr int NX = Prob::NX, NU = Prob::NU;
-  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1;
-  __shared__ double red[3][256];
+  constexpr int NX = Prob::NX, NU = Prob::NU, NQ = prob_nq<Prob>::value;
+  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1, NQs = NQ > 0 ? NQ : 1;
+  __shared__ double red[2 + NQs][256];
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
   const int inst = blockIdx.y;
@@ -29,6 +29,10 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
   const double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
   const double tspan = tf - t0;
   double s_wl = 0.0, s_t0 = 0.0;   // sum w_k L_k ; sum (w_k dt/2 dL/dt)_k (1-tau_k)/2
+  double s_p[NQs];                 // sum (w_k dt/2) dL/dp_j  (LpNLPWrapper.cpp:1088-1097: the quadrature of the parameter column)
+  double pq[NQs];                  // the phase's static parameters
+#pragma unroll
+  for (int j = 0; j < NQs; ++j) { s_p[j] = 0.0; pq[j] = j < NQ ? x[ph.x_t0 + 2 + j] : 0.0; }
   for (int k = tid; k < N; k += blockDim.x) {
     const double tau = K.points[ph.node0 + k], w = K.weights[ph.node0 + k];
     const double tk = (tau + 1) * (tspan / 2.0) + t0;
@@ -37,7 +41,7 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
     for (int i = 0; i < NX; ++i) xs[i] = x[ph.x_state0 + i * (N + 1) + k];
 #pragma unroll
     for (int j = 0; j < NU; ++j) us[j] = x[ph.x_control0 + j * N + k];
-    const double L0 = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+    const double L0 = pf_lagrange<Prob>(ph.phase_num, tk, xs, us, pq, c);
     s_wl += w * L0;
     if (GRAD) {
       const double wk = w * tspan / 2.0;                       // Weights*tspan/2.0, :1051
@@ -45,18 +49,20 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
       if constexpr (AN) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
-          { const double gv_ = wk * Prob::lagrange_grad_col(ph.phase_num, i, tk, xs, us, c); grad[ph.x_state0 + i * (N + 1) + k] = gv_; chk_note(bad, gv_); }
+          { const double gv_ = wk * pf_lagrange_grad_col<Prob>(ph.phase_num, i, tk, xs, us, pq, c); grad[ph.x_state0 + i * (N + 1) + k] = gv_; chk_note(bad, gv_); }
 #pragma unroll
         for (int j = 0; j < NU; ++j)
-          { const double gv_ = wk * Prob::lagrange_grad_col(ph.phase_num, NX + j, tk, xs, us, c); grad[ph.x_control0 + j * N + k] = gv_; chk_note(bad, gv_); }
-        dLt = Prob::lagrange_grad_col(ph.phase_num, NX + NU, tk, xs, us, c);
+          { const double gv_ = wk * pf_lagrange_grad_col<Prob>(ph.phase_num, NX + j, tk, xs, us, pq, c); grad[ph.x_control0 + j * N + k] = gv_; chk_note(bad, gv_); }
+        dLt = pf_lagrange_grad_col<Prob>(ph.phase_num, NX + NU, tk, xs, us, pq, c);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) s_p[j] += wk * pf_lagrange_grad_col<Prob>(ph.phase_num, NX + NU + 1 + j, tk, xs, us, pq, c);
       } else {
         // LpFDderive::DerivLagrange, LpFiniteDifferenceDerive.cpp:100-192
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           const double b = xs[i], hh = K.tol * (1 + fabs(b));
           xs[i] = b + hh;
-          const double Lp = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+          const double Lp = pf_lagrange<Prob>(ph.phase_num, tk, xs, us, pq, c);
           xs[i] = b;
           { const double gv_ = wk * ((Lp - L0) / hh); grad[ph.x_state0 + i * (N + 1) + k] = gv_; chk_note(bad, gv_); }
         }
@@ -64,23 +70,35 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
         for (int j = 0; j < NU; ++j) {
           const double b = us[j], hh = K.tol * (1 + fabs(b));
           us[j] = b + hh;
-          const double Lp = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+          const double Lp = pf_lagrange<Prob>(ph.phase_num, tk, xs, us, pq, c);
           us[j] = b;
           { const double gv_ = wk * ((Lp - L0) / hh); grad[ph.x_control0 + j * N + k] = gv_; chk_note(bad, gv_); }
         }
         const double ht = K.tol * (1 + fabs(tk));
-        dLt = (Prob::lagrange(ph.phase_num, tk + ht, xs, us, c) - L0) / ht;
+        dLt = (pf_lagrange<Prob>(ph.phase_num, tk + ht, xs, us, pq, c) - L0) / ht;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {   // LpFDderive::DerivLagrange's parameter columns, LpFiniteDifferenceDerive.cpp:165-182
+          const double b = pq[j], hh = K.tol * (1 + fabs(b));
+          pq[j] = b + hh;
+          const double Lp = pf_lagrange<Prob>(ph.phase_num, tk, xs, us, pq, c);
+          pq[j] = b;
+          s_p[j] += wk * ((Lp - L0) / hh);
+        }
       }
       s_t0 += ((w * (tspan / 2.0)) * dLt) * (tau * (-0.5) + 0.5);   // ret2*ret3, :1072-1077
     }
   }
   red[0][tid] = s_wl;
   red[1][tid] = s_t0;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) red[2 + j][tid] = s_p[j];
   __syncthreads();
   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
     if (tid < s) {
       red[0][tid] += red[0][tid + s];
       red[1][tid] += red[1][tid + s];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) red[2 + j][tid] += red[2 + j][tid + s];
     }
     __syncthreads();
   }
@@ -92,27 +110,33 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
       xf[i] = x[ph.x_state0 + i * (N + 1) + N];
     }
     const double wl = red[0][0];
-    const double mayer = Prob::mayer(ph.phase_num, t0, x0, tf, xf, c);
+    const double mayer = pf_mayer<Prob>(ph.phase_num, t0, x0, tf, xf, pq, c);
     // per-phase cost  Mayer + (w'L)(dt/2)  (:926-932); phases are summed in order by phase 0's thread below
     partial[size_t(inst) * K.P + p] = mayer + wl * (tspan / 2.0);
     if (GRAD) {
       // Mayer derivative w.r.t. [x0.., t0, xf.., tf]  (LpFDderive::DerivMayer :11-98 or the analytic callback)
-      double dM[2 * NXs + 2];
+      double dM[2 * NXs + 2 + NQs];   // [x0.., t0, xf.., tf, p..]  (LpFDderive::DerivMayer)
       if constexpr (AN) {
-        for (int q = 0; q < 2 * NX + 2; ++q) dM[q] = Prob::mayer_grad_col(ph.phase_num, q, t0, x0, tf, xf, c);
+        for (int q = 0; q < 2 * NX + 2 + NQ; ++q) dM[q] = pf_mayer_grad_col<Prob>(ph.phase_num, q, t0, x0, tf, xf, pq, c);
       } else {
         const double m0 = mayer;
         const double h0 = K.tol * (1 + fabs(t0)), hf = K.tol * (1 + fabs(tf));
-        dM[NX] = (Prob::mayer(ph.phase_num, t0 + h0, x0, tf, xf, c) - m0) / h0;
-        dM[2 * NX + 1] = (Prob::mayer(ph.phase_num, t0, x0, tf + hf, xf, c) - m0) / hf;
+        dM[NX] = (pf_mayer<Prob>(ph.phase_num, t0 + h0, x0, tf, xf, pq, c) - m0) / h0;
+        dM[2 * NX + 1] = (pf_mayer<Prob>(ph.phase_num, t0, x0, tf + hf, xf, pq, c) - m0) / hf;
+        for (int j = 0; j < NQ; ++j) {
+          const double b = pq[j], hb = K.tol * (1 + fabs(b));
+          pq[j] = b + hb;
+          dM[2 * NX + 2 + j] = (pf_mayer<Prob>(ph.phase_num, t0, x0, tf, xf, pq, c) - m0) / hb;
+          pq[j] = b;
+        }
         for (int i = 0; i < NX; ++i) {
           const double b0 = x0[i], hb0 = K.tol * (1 + fabs(b0));
           x0[i] = b0 + hb0;
-          dM[i] = (Prob::mayer(ph.phase_num, t0, x0, tf, xf, c) - m0) / hb0;
+          dM[i] = (pf_mayer<Prob>(ph.phase_num, t0, x0, tf, xf, pq, c) - m0) / hb0;
           x0[i] = b0;
           const double bf = xf[i], hbf = K.tol * (1 + fabs(bf));
           xf[i] = bf + hbf;
-          dM[NX + 1 + i] = (Prob::mayer(ph.phase_num, t0, x0, tf, xf, c) - m0) / hbf;
+          dM[NX + 1 + i] = (pf_mayer<Prob>(ph.phase_num, t0, x0, tf, xf, pq, c) - m0) / hbf;
           xf[i] = bf;
         }
       }
@@ -129,14 +153,17 @@ __global__ void rpm_obj_kernel(const KParams K, const double* __restrict__ xall,
         const double tau = K.points[ph.node0];
         const double tk = (tau + 1) * (tspan / 2.0) + t0;
         if constexpr (AN) {
-          dLt0 = Prob::lagrange_grad_col(ph.phase_num, NX + NU, tk, xs, us, c);
+          dLt0 = pf_lagrange_grad_col<Prob>(ph.phase_num, NX + NU, tk, xs, us, pq, c);
         } else {
           const double ht = K.tol * (1 + fabs(tk));
-          dLt0 = (Prob::lagrange(ph.phase_num, tk + ht, xs, us, c) - Prob::lagrange(ph.phase_num, tk, xs, us, c)) / ht;
+          dLt0 = (pf_lagrange<Prob>(ph.phase_num, tk + ht, xs, us, pq, c) - pf_lagrange<Prob>(ph.phase_num, tk, xs, us, pq, c)) / ht;
         }
         const double r2 = (K.weights[ph.node0] * (tspan / 2.0)) * dLt0;
         { const double gv_ = (dM[2 * NX + 1] + 0.5 * wl) + (tau * 0.5 + 0.5) * r2; grad[ph.x_t0 + 1] = gv_; chk_note(bad, gv_); }
       }
+      // d/dp_j = dMayer/dp_j + sum_k w_k (dt/2) dL/dp_j  (:1088-1097; the reference multiplies two column vectors there and
+      // never fills SolCost.parameter_ — SURVEY B-21 — so this is the formula it means, not the code it has)
+      for (int j = 0; j < NQ; ++j) { const double gv_ = dM[2 * NX + 2 + j] + red[2 + j][0]; grad[ph.x_t0 + 2 + j] = gv_; chk_note(bad, gv_); }
     }
   }
   (void)objall;
@@ -156,7 +183,7 @@ __global__ void rpm_obj_sum_kernel(int P, int B, const double* __restrict__ part
 bool problem_dims(int id, ProblemDims* out) {
   return with_problem(id, [&](auto prob) {
     using P = decltype(prob);
-    *out = ProblemDims{P::NX, P::NU, P::NC, P::NE_MAX, P::NLINK_MAX, P::NCONST, P::HAS_ANALYTIC};
+    *out = ProblemDims{P::NX, P::NU, P::NC, P::NE_MAX, P::NLINK_MAX, P::NCONST, P::HAS_ANALYTIC, prob_nq<P>::value};
   });
 }
 

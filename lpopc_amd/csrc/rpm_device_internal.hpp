@@ -136,6 +136,8 @@ inline bool with_problem(int id, F&& fn) {
     case RPM_PROBLEM_BRACHISTOCHRONE: fn(BrachistochroneProblem{}); return true;
     case RPM_PROBLEM_MIN_TIME_CLIMB: fn(MinTimeClimbProblem{}); return true;
     case RPM_PROBLEM_QUADROTOR: fn(QuadrotorProblem{}); return true;
+    case RPM_PROBLEM_PARAM_SLED: fn(ParamSledProblem{}); return true;
+    case RPM_PROBLEM_PARAM_OSC: fn(ParamOscProblem{}); return true;
 #endif
 #ifdef RPM_USER_PROBLEM_HEADER
     case RPM_PROBLEM_USER: fn(UserProblem{}); return true;

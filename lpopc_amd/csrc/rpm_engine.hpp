@@ -18,6 +18,7 @@ namespace rpm {
 // ---- device-visible POD tables (copied to HBM verbatim by rpm_device_init) ---------------
 struct PhaseDev {
   int N, nx, nu, nc, ne;
+  int nq;            // static parameters: x[x_t0 + 2 + j]
   int phase_num;     // 1-based, what the reference hands the user callbacks (LpNLPWrapper.cpp:107)
   int x_state0;      // index of X(0,0) in x          (phase_indices[i]->state[0]-1)
   int x_control0;    // index of U(0,0) in x
@@ -237,7 +238,7 @@ int dev_shard_pack_all(Engine& e, const double* d_g, const double* d_values, dou
 int dev_shard_unpack_all(Engine& e, const double* d_gathered, double* d_g, double* d_values, int skip_own, void* stream);
 
 // problem registry (rpm_device.hip): static dimensions of a functor, for validation on the host
-struct ProblemDims { int nx, nu, nc, ne_max, nlink_max, nconst; bool has_analytic; };
+struct ProblemDims { int nx, nu, nc, ne_max, nlink_max, nconst; bool has_analytic; int nq; };
 bool problem_dims(int problem_id, ProblemDims* out);
 
 // rpm_device.hip

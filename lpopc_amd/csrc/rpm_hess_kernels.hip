@@ -24,7 +24,7 @@ __global__ void rpm_dep_probe_kernel(const KParams K, const double* __restrict__
   double xs[NX > 0 ? NX : 1], us[NU > 0 ? NU : 1], f[NX > 0 ? NX : 1], cp[NC > 0 ? NC : 1];
   for (int i = 0; i < NX; ++i) xs[i] = (i == v) ? __builtin_nan("") : xg[ph.x_state0 + i * (ph.N + 1) + 1];
   for (int j = 0; j < NU; ++j) us[j] = (NX + j == v) ? __builtin_nan("") : xg[ph.x_control0 + j * ph.N + 1];
-  Prob::dae(ph.phase_num, tk, xs, us, K.consts, f, cp);
+  pf_dae<Prob>(ph.phase_num, tk, xs, us, xg + ph.x_t0 + 2, K.consts, f, cp);
   int* out = dep + dep_off[blockIdx.x] + v * (NX + NC);
   for (int r = 0; r < NX; ++r) out[r] = isfinite(f[r]) ? 0 : 1;
   for (int r = 0; r < NC; ++r) out[NX + r] = isfinite(cp[r]) ? 0 : 1;
@@ -92,10 +92,10 @@ __global__ void rpm_hess_kernel(const KParams K, const HParams Hp, const double*
   double F[NF];
   {
     double cp[NCs];
-    Prob::dae(ph.phase_num, tk, xs, us, c, F, cp);
+    pf_dae<Prob>(ph.phase_num, tk, xs, us, x + ph.x_t0 + 2, c, F, cp);
 #pragma unroll
     for (int j = 0; j < NC; ++j) F[NX + j] = cp[j];
-    F[NX + NC] = Prob::lagrange(ph.phase_num, tk, xs, us, c);
+    F[NX + NC] = pf_lagrange<Prob>(ph.phase_num, tk, xs, us, x + ph.x_t0 + 2, c);
   }
   if (act) {
 #pragma unroll
@@ -138,13 +138,13 @@ __global__ void rpm_hess_kernel(const KParams K, const HParams Hp, const double*
       for (int i = 0; i < NX; ++i) xs0[i] = x[ph.x_state0 + i * (N + 1) + k];
 #pragma unroll
       for (int j = 0; j < NU; ++j) us0[j] = x[ph.x_control0 + j * N + k];
-      Prob::dae_jac_col(ph.phase_num, b, tk0, xs0, us0, c, df, dc);
+      pf_dae_jac_col<Prob>(ph.phase_num, b, tk0, xs0, us0, x + ph.x_t0 + 2, c, df, dc);
 #pragma unroll
       for (int o = 0; o < NX; ++o) {
         const double term = lam[o * N + k] * df[o];
         sdd = (o == 0) ? term : sdd + term;
       }
-      dL = Prob::lagrange_grad_col(ph.phase_num, b, tk0, xs0, us0, c);
+      dL = pf_lagrange_grad_col<Prob>(ph.phase_num, b, tk0, xs0, us0, x + ph.x_t0 + 2, c);
     } else {
 #pragma unroll
       for (int o = 0; o < NX; ++o) {
@@ -243,8 +243,8 @@ __global__ void rpm_hess_end_kernel(const KParams K, const HParams Hp, const dou
         if (v == 2 * NX + 1) sf += hh;
       }
       for (int i = 0; i < NE; ++i) ev[q][i] = 0.0;
-      if (ph.ne > 0) Prob::event(ph.phase_num, s0, y0, sf, yf, c, ev[q]);
-      my[q] = Prob::mayer(ph.phase_num, s0, y0, sf, yf, c);
+      if (ph.ne > 0) pf_event<Prob>(ph.phase_num, s0, y0, sf, yf, x + ph.x_t0 + 2, c, ev[q]);
+      my[q] = pf_mayer<Prob>(ph.phase_num, s0, y0, sf, yf, x + ph.x_t0 + 2, c);
     }
     const double hM = (my[3] - my[1] - my[2] + my[0]) / den;
     double v1 = 0.0, v2 = 0.0;   // accu(hEvents % event_lambda): two interleaved accumulators
@@ -274,7 +274,7 @@ __global__ void rpm_hess_end_kernel(const KParams K, const HParams Hp, const dou
       if (q == 1 || q == 3) w[le.a] += pa;
       if (q == 2 || q == 3) w[le.b] += pb;
       for (int i = 0; i < NL; ++i) lo[q][i] = 0.0;
-      Prob::link(lk.left + 1, lk.right + 1, w, w + NX, c, lk.nlink, lo[q]);
+      pf_link<Prob>(lk.left + 1, lk.right + 1, w, w + NX, x + K.phases[lk.left].x_t0 + 2, x + K.phases[lk.right].x_t0 + 2, c, lk.nlink, lo[q]);
     }
     // link multipliers: the reference reads the FIRST pair's rows for every pair (link_indices are built
     // without advancing the offset, Core/LpBoundsChecker.cpp:240-244) — kept

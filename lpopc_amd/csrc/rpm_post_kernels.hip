@@ -67,7 +67,7 @@ __global__ void rpm_mesh_err_kernel(const KParams K, int phase, const double* __
 #pragma unroll
     for (int j = 0; j < NU; ++j) us[j] = Us[q * NU + j];
     const double t = half * ttem[v.q0 + q] + half;   // t0 is not added, LpSolutionError.cpp:124
-    Prob::dae(ph.phase_num, t, xs, us, K.consts, f, cp);
+    pf_dae<Prob>(ph.phase_num, t, xs, us, x + ph.x_t0 + 2, K.consts, f, cp);
 #pragma unroll
     for (int s = 0; s < NX; ++s) Fs[q * NX + s] = f[s] * ((tf - t0) / 2.0);
   }
@@ -180,8 +180,8 @@ __global__ void rpm_post_kernel(const KParams K, int phase, const double* __rest
   for (int j = 0; j < NC; ++j)   // lambda WITHOUT the phase offset, exactly as Nlp2OPConverter.cpp:88 reads it
     o_pathmult[j * M + k] = k < N ? 2 * ((1 / K.weights[ph.node0 + k]) * lam[N * NX + j * N + k]) / (tf - t0) : pm_end[j];
   double f[NXs], cp[NCs];
-  Prob::dae(ph.phase_num, t, xs, us, K.consts, f, cp);
-  const double L = Prob::lagrange(ph.phase_num, t, xs, us, K.consts);
+  pf_dae<Prob>(ph.phase_num, t, xs, us, x + ph.x_t0 + 2, K.consts, f, cp);
+  const double L = pf_lagrange<Prob>(ph.phase_num, t, xs, us, x + ph.x_t0 + 2, K.consts);
   double sum = 0.0;
 #pragma unroll
   for (int s = 0; s < NX; ++s) {
@@ -197,7 +197,7 @@ __global__ void rpm_post_kernel(const KParams K, int phase, const double* __rest
       x0[s] = x[ph.x_state0 + s * M];
       xf[s] = x[ph.x_state0 + s * M + N];
     }
-    o_mayer[0] = Prob::mayer(ph.phase_num, t0, x0, tf, xf, K.consts);
+    o_mayer[0] = pf_mayer<Prob>(ph.phase_num, t0, x0, tf, xf, x + ph.x_t0 + 2, K.consts);
   }
 }
 

@@ -323,10 +323,13 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     if (q.nx != pd.nx || q.nu != pd.nu || q.nc != pd.nc)
       return bad(e, RPM_E_INVALID, "phase dimensions (nx,nu,nc) do not match the problem functor" + tag);
     if (q.ne < 0 || q.ne > pd.ne_max) return bad(e, RPM_E_INVALID, "too many event constraints for the functor" + tag);
-    if (q.nq != 0)
-      return bad(e, RPM_E_UNSUPPORTED,
-                 "static parameters (nq>0) are not supported: the reference's nq>0 path is inconsistent "
-                 "(SURVEY.md B-6..B-9)" + tag);
+    // static parameters: layout and derivative columns as the reference lays them out (LpBoundsChecker.cpp:117-138,
+    // LpFiniteDifferenceDerive.cpp:299-317), values by the mathematically correct formulas where the reference's own
+    // parameter path is inconsistent (DESIGN.md section 3 lists each departure)
+    if (q.nq != pd.nq) return bad(e, RPM_E_INVALID, "the number of static parameters (nq) does not match the problem functor" + tag);
+    if (q.nq > 0 && e.hessian_mode == RPM_HESSIAN_EXACT)
+      return bad(e, RPM_E_UNSUPPORTED, "hessian-approximation=exact is not built for problems with static parameters (nq > 0): the reference's "
+                                       "parameter Hessian is inconsistent (SURVEY.md App. A.6 quirks); use limited-memory" + tag);
     if (q.n_intervals < 1 || !q.mesh_points || !q.nodes_per_interval)
       return bad(e, RPM_E_INVALID, "MeshRefinement need at least two  meshPoints" + tag);
     if (q.mesh_points[0] != -1 || q.mesh_points[q.n_intervals] != 1)
@@ -404,6 +407,11 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     }
     e.xl[vi] = q.t0_min; e.xu[vi++] = q.t0_max;
     e.xl[vi] = q.tf_min; e.xu[vi++] = q.tf_max;
+    for (int j = 0; j < p.nq; ++j) {   // LpBoundsChecker.cpp:117-138
+      if (!q.parameter_min || !q.parameter_max || !(q.parameter_min[j] <= q.parameter_max[j]))
+        return bad(e, RPM_E_INVALID, "Bounds on parameter are Inconsistent (i.e. max < min) in Phase:" + tag);
+      e.xl[vi] = q.parameter_min[j]; e.xu[vi++] = q.parameter_max[j];
+    }
     for (int j = 0; j < p.nc; ++j) {
       if (!(q.path_min[j] <= q.path_max[j]))
         return bad(e, RPM_E_INVALID, "Bounds on path are Inconsistent (i.e. max < min) in Phase:" + tag);
@@ -476,6 +484,9 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
       for (int k = 0; k < p.N; ++k) g[r++] = spline_eval(p.points[k], tau.data(), q.control_guess + size_t(j) * ng, ng);
     g[r++] = t0g;
     g[r++] = tfg;
+    if (p.nq > 0 && !q.parameter_guess)
+      return bad(e, RPM_E_INVALID, "Number of parameters in guess does not match limits in phase " + tag);
+    for (int j = 0; j < p.nq; ++j) g[r++] = q.parameter_guess[j];   // LpGuessChecker.cpp:186-189
   }
 
   // ---- Jacobian layout: values = [NL | LIN | CONST]  (LpNLPWrapper.cpp:244-252) -----------
@@ -483,16 +494,16 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
   for (int i = 0; i < e.P; ++i) {
     PhaseHost& p = e.ph[i];
     PhaseDev& q = e.phd[i];
-    q.N = p.N; q.nx = p.nx; q.nu = p.nu; q.nc = p.nc; q.ne = p.ne;
+    q.N = p.N; q.nx = p.nx; q.nu = p.nu; q.nc = p.nc; q.ne = p.ne; q.nq = p.nq;
     q.phase_num = i + 1;
     q.x_state0 = p.var0;
     q.x_control0 = p.var0 + p.nx * (p.N + 1);
     q.x_t0 = q.x_control0 + p.nu * p.N;
     q.g0 = p.con0;
     q.v_nl0 = v;
-    v += (p.nx + p.nc) * (p.nx + p.nu + 2) * p.N;   // dependencies.fill(1): every block present (:1345)
+    v += (p.nx + p.nc) * (p.nx + p.nu + 2 + p.nq) * p.N;   // dependencies.fill(1): every block present (:1345); :682-683
     q.v_evt0 = v;
-    v += p.ne * (2 * p.nx + 2);
+    v += p.ne * (2 * p.nx + 2 + p.nq);
     q.node0 = node0;
     node0 += p.N;
     q.doff_base = doff0;
@@ -505,8 +516,12 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     LinkDev& l = e.links[i];
     if (e.ph[l.left].nx != e.ph[l.right].nx)
       return bad(e, RPM_E_UNSUPPORTED, "linked phases must have the same number of states (SURVEY.md B-11)");
+    if (e.ph[l.left].nq != e.ph[l.right].nq)
+      return bad(e, RPM_E_UNSUPPORTED, "linked phases must have the same number of static parameters (SURVEY.md B-11)");
     l.v0 = v;
-    v += l.nlink * (e.ph[l.left].nx + e.ph[l.right].nx);
+    // columns [xf_left, p_left, x0_right, p_right] (:461-519); the reference counts the LEFT phase's sizes twice (B-11),
+    // which is the same number whenever the linked phases have equal nx and nq
+    v += l.nlink * (e.ph[l.left].nx + e.ph[l.left].nq + e.ph[l.right].nx + e.ph[l.right].nq);
   }
   e.nnz_nl = v;
   e.nnz_lin = int(e.alin_v.size());
@@ -520,7 +535,7 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
     int s = 0, sc = e.nnz_nl + e.nnz_lin;
     for (int ip = 0; ip < e.P; ++ip) {
       const PhaseHost& p = e.ph[ip];
-      const int N = p.N, nx = p.nx, nu = p.nu, nc = p.nc, ne = p.ne, disc = N + 1;
+      const int N = p.N, nx = p.nx, nu = p.nu, nc = p.nc, ne = p.ne, nq = p.nq, disc = N + 1;
       const int r0 = p.con0, c0 = p.var0;
       auto diag_block = [&](int rs, int cs) {
         for (int k = 0; k < N; ++k) { e.jac_i[s] = r0 + rs + k; e.jac_j[s++] = c0 + cs + k; }
@@ -534,6 +549,9 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
         for (int j = 0; j < nu; ++j) diag_block(rs, nx * disc + j * N);
         col_block(rs, nx * disc + nu * N);
         col_block(rs, nx * disc + nu * N + 1);
+        // one block per static parameter: every node's row, the parameter's ONE column (the reference writes a diagonal
+        // run `indexvector + colstart` here, LpNLPWrapper.cpp:1211,1262 — SURVEY B-8; not reproduced)
+        for (int j = 0; j < nq; ++j) col_block(rs, nx * disc + nu * N + 2 + j);
       }
       for (int i = 0; i < ne; ++i) {
         const int row = r0 + (nx + nc) * N + i;
@@ -543,6 +561,7 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
         }
         e.jac_i[s] = row; e.jac_j[s++] = c0 + nx * disc + nu * N;
         e.jac_i[s] = row; e.jac_j[s++] = c0 + nx * disc + nu * N + 1;
+        for (int j = 0; j < nq; ++j) { e.jac_i[s] = row; e.jac_j[s++] = c0 + nx * disc + nu * N + 2 + j; }   // :854-859
       }
       for (int i = 0; i < nx; ++i)
         for (size_t q = 0; q < p.off_v.size(); ++q) {
@@ -556,8 +575,12 @@ int setup_engine(Engine& e, const rpm_problem_desc* d) {
       const PhaseHost& pr = e.ph[l.right];
       for (int jc = 0; jc < pl.nx; ++jc)
         for (int ir = 0; ir < l.nlink; ++ir) { e.jac_i[s] = l.g0 + ir; e.jac_j[s++] = pl.var0 + (jc + 1) * pl.N + jc; }
+      for (int jc = 0; jc < pl.nq; ++jc)
+        for (int ir = 0; ir < l.nlink; ++ir) { e.jac_i[s] = l.g0 + ir; e.jac_j[s++] = pl.var0 + pl.nx * (pl.N + 1) + pl.nu * pl.N + 2 + jc; }
       for (int jc = 0; jc < pr.nx; ++jc)
         for (int ir = 0; ir < l.nlink; ++ir) { e.jac_i[s] = l.g0 + ir; e.jac_j[s++] = pr.var0 + jc * (pr.N + 1); }
+      for (int jc = 0; jc < pr.nq; ++jc)
+        for (int ir = 0; ir < l.nlink; ++ir) { e.jac_i[s] = l.g0 + ir; e.jac_j[s++] = pr.var0 + pr.nx * (pr.N + 1) + pr.nu * pr.N + 2 + jc; }
     }
     for (int q = 0; q < e.nnz_lin; ++q) {
       e.jac_i[e.nnz_nl + q] = e.m_nl + e.alin_i[q];

@@ -32,20 +32,20 @@ std::vector<rpm_segment> shard_segments(const Engine& e, int which, int rank, in
     const PhaseDev& q = e.phd[ip];
     int ka, kb;
     owned_nodes(e, ip, rank, &ka, &kb);
-    const int NO = q.nx + q.nc, NB = q.nx + q.nu + 2;
+    const int NO = q.nx + q.nc, NB = q.nx + q.nu + 2 + q.nq;
     if (which == 0) {
       for (int o = 0; o < NO; ++o) add(q.g0 + o * q.N + ka, kb - ka);
       if (rank == 0) add(q.g0 + NO * q.N, q.ne);
     } else {
       for (int b = 0; b < NO * NB; ++b) add(q.v_nl0 + b * q.N + ka, kb - ka);
-      if (rank == 0) add(q.v_evt0, q.ne * (2 * q.nx + 2));
+      if (rank == 0) add(q.v_evt0, q.ne * (2 * q.nx + 2 + q.nq));
     }
   }
   if (rank == 0) {
     for (int i = 0; i < e.L; ++i) {
       const LinkDev& l = e.links[i];
       if (which == 0) add(l.g0, l.nlink);
-      else add(l.v0, l.nlink * (e.ph[l.left].nx + e.ph[l.right].nx));
+      else add(l.v0, l.nlink * (e.ph[l.left].nx + e.ph[l.left].nq + e.ph[l.right].nx + e.ph[l.right].nq));
     }
     if (which == 0) add(e.m_nl, e.P + e.L);
     else add(e.nnz_nl, e.nnz_lin);

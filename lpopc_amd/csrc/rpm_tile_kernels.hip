@@ -30,11 +30,11 @@ namespace rpm {
 template <class Prob, bool WG, bool WJ, bool AN, bool WAVE = false>
 __device__ void endpoint_block(const KParams& K, const TaskDev task, const double* __restrict__ x,
                                double* __restrict__ g, double* __restrict__ vals, double* lds, int inst) {
-  constexpr int NX = Prob::NX;
+  constexpr int NX = Prob::NX, NQ = prob_nq<Prob>::value, NQs = NQ > 0 ? NQ : 1;
   bool bad_g = false, bad_j = false;
   constexpr int NE = Prob::NE_MAX > 0 ? Prob::NE_MAX : 1;
   constexpr int NL = Prob::NLINK_MAX > 0 ? Prob::NLINK_MAX : 1;
-  static_assert(!WAVE || 2 * NX + 3 <= 64, "endpoint perturbations must fit one wave");
+  static_assert(!WAVE || 2 * NX + 3 + 2 * NQ <= 64, "endpoint perturbations must fit one wave");
   const int tid = WAVE ? int(threadIdx.x & 63) : int(threadIdx.x);
   const int nthr = WAVE ? 64 : int(blockDim.x);
   const double* c = K.consts + size_t(inst) * K.consts_stride;
@@ -55,12 +55,14 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       }
     }
   } else if (task.type == 1) {
-    // ---- events of one phase: lane 0 = base, lanes 1..2NX+2 = perturbations [x0.., t0, xf.., tf]
+    // ---- events of one phase: lane 0 = base, lanes 1..2NX+2+NQ = perturbations [x0.., t0, xf.., tf, p..]
     //      (LpFDderive::DerivEvent, LpFiniteDifferenceDerive.cpp:326-409)
     const PhaseDev ph = K.phases[task.idx];
     const int pi = tid;
-    const bool act = pi <= 2 * NX + 2;
-    double x0[NX], xf[NX], ev[NE];
+    const bool act = pi <= 2 * NX + 2 + NQ;
+    double x0[NX], xf[NX], ev[NE], pp[NQs];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) pp[j] = x[ph.x_t0 + 2 + j];
     double t0 = x[ph.x_t0], tf = x[ph.x_t0 + 1];
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
@@ -77,10 +79,13 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       }
       if (v == NX) { h = K.tol * (1 + fabs(t0)); t0 += h; }
       if (v == 2 * NX + 1) { h = K.tol * (1 + fabs(tf)); tf += h; }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+        if (v == 2 * NX + 2 + j) { h = K.tol * (1 + fabs(pp[j])); pp[j] += h; }
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) ev[i] = 0.0;
-    if (act && (pi == 0 || !AN)) Prob::event(ph.phase_num, t0, x0, tf, xf, c, ev);
+    if (act && (pi == 0 || !AN)) pf_event<Prob>(ph.phase_num, t0, x0, tf, xf, pp, c, ev);
     double base[NE];
     if constexpr (WAVE) {
 #pragma unroll
@@ -103,30 +108,36 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       const int v = pi - 1;
       double de[NE];
       if constexpr (AN) {
-        Prob::event_jac_col(ph.phase_num, v, t0, x0, tf, xf, c, de);
+        pf_event_jac_col<Prob>(ph.phase_num, v, t0, x0, tf, xf, pp, c, de);
       } else {
 #pragma unroll
         for (int i = 0; i < NE; ++i) de[i] = (ev[i] - base[i]) / h;
       }
-      // position inside an event's row of entries: (x0_j, xf_j) pairs, then t0, tf (:837-853)
+      // position inside an event's row of entries: (x0_j, xf_j) pairs, then t0, tf, then the parameters (:837-859)
       int pos;
       if (v < NX) pos = 2 * v;
       else if (v == NX) pos = 2 * NX;
       else if (v <= 2 * NX) pos = 2 * (v - NX - 1) + 1;
-      else pos = 2 * NX + 1;
+      else pos = v;   // tf at 2NX+1, parameter j at 2NX+2+j
 #pragma unroll
       for (int i = 0; i < NE; ++i)
-        if (i < ph.ne) { vals[ph.v_evt0 + i * (2 * NX + 2) + pos] = de[i]; chk_note(bad_j, de[i]); }
+        if (i < ph.ne) { vals[ph.v_evt0 + i * (2 * NX + 2 + NQ) + pos] = de[i]; chk_note(bad_j, de[i]); }
     }
   } else {
-    // ---- one linkage pair: lane 0 = base, 1..NX = xf_left perturbations, NX+1..2NX = x0_right
-    //      (LpFDderive::DerivLink, LpFiniteDifferenceDerive.cpp:411-502)
+    // ---- one linkage pair: lane 0 = base, then the perturbations [xf_left.., p_left.., x0_right.., p_right..]
+    //      (LpFDderive::DerivLink, LpFiniteDifferenceDerive.cpp:411-502; each parameter by its own step and the right phase's
+    //      parameters from the right phase — the reference hands the left ones twice, SURVEY B-9)
     const LinkDev lk = K.links[task.idx];
     const PhaseDev pl = K.phases[lk.left];
     const PhaseDev pr = K.phases[lk.right];
     const int pi = tid;
-    const bool act = pi <= 2 * NX;
-    double xl[NX], xr[NX], lo[NL];
+    const bool act = pi <= 2 * NX + 2 * NQ;
+    double xl[NX], xr[NX], lo[NL], ql[NQs], qr[NQs];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      ql[j] = x[pl.x_t0 + 2 + j];
+      qr[j] = x[pr.x_t0 + 2 + j];
+    }
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       xl[j] = x[pl.x_state0 + j * (pl.N + 1) + pl.N];
@@ -138,12 +149,17 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
         if (v == j) { h = K.tol * (1 + fabs(xl[j])); xl[j] += h; }
-        if (v == NX + j) { h = K.tol * (1 + fabs(xr[j])); xr[j] += h; }
+        if (v == NX + NQ + j) { h = K.tol * (1 + fabs(xr[j])); xr[j] += h; }
+      }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        if (v == NX + j) { h = K.tol * (1 + fabs(ql[j])); ql[j] += h; }
+        if (v == 2 * NX + NQ + j) { h = K.tol * (1 + fabs(qr[j])); qr[j] += h; }
       }
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) lo[i] = 0.0;
-    if (act && (pi == 0 || !AN)) Prob::link(lk.left + 1, lk.right + 1, xl, xr, c, lk.nlink, lo);
+    if (act && (pi == 0 || !AN)) pf_link<Prob>(lk.left + 1, lk.right + 1, xl, xr, ql, qr, c, lk.nlink, lo);
     double base[NL];
     if constexpr (WAVE) {
 #pragma unroll
@@ -166,7 +182,7 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
       const int v = pi - 1;
       double dl[NL];
       if constexpr (AN) {
-        Prob::link_jac_col(lk.left + 1, lk.right + 1, v, xl, xr, c, lk.nlink, dl);
+        pf_link_jac_col<Prob>(lk.left + 1, lk.right + 1, v, xl, xr, ql, qr, c, lk.nlink, dl);
       } else {
 #pragma unroll
         for (int i = 0; i < NL; ++i) dl[i] = (lo[i] - base[i]) / (1.0 * h);
@@ -183,10 +199,10 @@ __device__ void endpoint_block(const KParams& K, const TaskDev task, const doubl
 template <class Prob, int T, bool WG, bool WJ, bool AN, bool DXM = false>
 __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall,
                                 double* __restrict__ gall, double* __restrict__ vall) {
-  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC, NQ = prob_nq<Prob>::value;
   constexpr int NO = NX + NC;              // outputs per node: f then c
-  constexpr int NV = NX + NU + 1;          // perturbation variables: states, controls, time
-  constexpr int NB = NX + NU + 2;          // Jacobian blocks per output row: x.., u.., t0, tf
+  constexpr int NV = NX + NU + 1 + NQ;     // perturbation variables: states, controls, time, static parameters
+  constexpr int NB = NX + NU + 2 + NQ;     // Jacobian blocks per output row: x.., u.., t0, tf, p..
   constexpr int R = WJ ? NV + 1 : (NX > 0 ? NX : 1);
   constexpr int NCs = NC > 0 ? NC : 1;
   extern __shared__ double lds[];
@@ -265,11 +281,13 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   const bool act = kk < tl.cnt && role < R;
   const double tspan = tf - t0;
   double tk = (tau + 1) * (tspan / 2.0) + t0;      // LpNLPWrapper.cpp:80
-  double xs[NX > 0 ? NX : 1], us[NU > 0 ? NU : 1];
+  double xs[NX > 0 ? NX : 1], us[NU + NQ > 0 ? NU + NQ : 1];   // us = [controls, static parameters]
 #pragma unroll
   for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - tl.span0)];
 #pragma unroll
   for (int j = 0; j < NU; ++j) us[j] = Us[j * T + kc];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) us[NU + j] = x[ph.x_t0 + 2 + j];
 
   // ---- D.X for this thread's state: ascending-column sum, separate multiply and add, exactly the
   //      order of the reference's COO loop for one output row (LpSparseMatrix.cpp:142-153) ----
@@ -328,6 +346,9 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
     for (int j = 0; j < NU; ++j)
       if (v == NX + j) { h = K.tol * (1 + fabs(us[j])); us[j] += h; }
     if (v == NX + NU) { h = K.tol * (1 + fabs(tk)); tk += h; }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+      if (v == NX + NU + 1 + j) { h = K.tol * (1 + fabs(us[NU + j])); us[NU + j] += h; }
   }
   double f[NX > 0 ? NX : 1], cp[NCs];
 #ifdef RPM_DIAG
@@ -337,9 +358,9 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
   } else
 #endif
   if (!AN || role == 0) {
-    Prob::dae(ph.phase_num, tk, xs, us, c, f, cp);
+    pf_dae<Prob>(ph.phase_num, tk, xs, us, us + NU, c, f, cp);
   } else if constexpr (AN) {
-    Prob::dae_jac_col(ph.phase_num, v, tk, xs, us, c, f, cp);  // f, cp now hold column v of the Jacobian
+    pf_dae_jac_col<Prob>(ph.phase_num, v, tk, xs, us, us + NU, c, f, cp);  // f, cp now hold column v of the Jacobian
   }
   if (role == 0 && act) {
 #pragma unroll
@@ -370,8 +391,10 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
         J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
       }
       double* vb = vals + ph.v_nl0 + k;
-      if (v < NX + NU) {
-        // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
+      if (v != NX + NU) {
+        // blocks d/dx_v, d/du_v or d/dp_j of every output row (:698-743, :763-769, :776-796, :814-820; the parameter
+        // blocks follow the two time blocks and take their derivative column, not the time column — SURVEY B-6, B-7)
+        const int bv = v < NX + NU ? v : v + 1;
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
           double val;
@@ -381,7 +404,7 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
           } else {
             val = J[o];
           }
-          vb[size_t(o * NB + v) * N] = val;
+          vb[size_t(o * NB + bv) * N] = val;
           chk_note(bad_j, val);
         }
       } else {
@@ -451,8 +474,8 @@ __global__ void rpm_tile_kernel(const KParams K, const double* __restrict__ xall
 template <class Prob, int T, int RG, bool WG, bool WJ, bool AN>
 __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, const double* __restrict__ xall,
                                                             double* __restrict__ gall, double* __restrict__ vall) {
-  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
-  constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC, NQ = prob_nq<Prob>::value;
+  constexpr int NO = NX + NC, NV = NX + NU + 1 + NQ, NB = NX + NU + 2 + NQ;
   constexpr int R = WJ ? NV + 1 : (NX > 0 ? NX : 1);
   constexpr int NCs = NC > 0 ? NC : 1;
   constexpr int NTHR = T * RG;
@@ -508,11 +531,13 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
   bool first = true;
   for (int role = grp; role < R || first; role += RG) {
     const bool act = node_ok && role < R;
-    double xs[NX > 0 ? NX : 1], us[NU > 0 ? NU : 1];
+    double xs[NX > 0 ? NX : 1], us[NU + NQ > 0 ? NU + NQ : 1];   // us = [controls, static parameters]
 #pragma unroll
     for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - tl.span0)];
 #pragma unroll
     for (int j = 0; j < NU; ++j) us[j] = Us[j * T + kc];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) us[NU + j] = x[ph.x_t0 + 2 + j];
     double tk = tk0;
     const int sv = WJ ? role - 1 : role;
     double dx = 0.0;
@@ -528,7 +553,8 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
       double pv;
       if (v < NX) pv = Xs[v * K.max_span + (k - tl.span0)];
       else if (v < NX + NU) pv = Us[(v - NX) * T + kc];
-      else pv = tk;
+      else if (v == NX + NU) pv = tk;
+      else pv = x[ph.x_t0 + 1 + (v - NX - NU)];   // static parameter v - NX - NU - 1
       h = K.tol * (1 + fabs(pv));
       const double pp = pv + h;
 #pragma unroll
@@ -536,6 +562,8 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
 #pragma unroll
       for (int j = 0; j < NU; ++j) us[j] = (v == NX + j) ? pp : us[j];
       tk = (v == NX + NU) ? pp : tk;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) us[NU + j] = (v == NX + NU + 1 + j) ? pp : us[NU + j];
     }
     double f[NX > 0 ? NX : 1], cp[NCs];
 #ifdef RPM_DIAG
@@ -547,9 +575,9 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
     } else
 #endif
     if (!AN || role == 0) {
-      Prob::dae(ph.phase_num, tk, xs, us, c, f, cp);
+      pf_dae<Prob>(ph.phase_num, tk, xs, us, us + NU, c, f, cp);
     } else if constexpr (AN) {
-      Prob::dae_jac_col(ph.phase_num, v, tk, xs, us, c, f, cp);
+      pf_dae_jac_col<Prob>(ph.phase_num, v, tk, xs, us, us + NU, c, f, cp);
     }
     if (first) {   // wave-uniform: the first pass publishes the unperturbed outputs before anyone forms a difference
       if (role == 0 && act) {
@@ -579,7 +607,8 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
           J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
         }
         double* vb = vals + ph.v_nl0 + k;
-        if (v < NX + NU) {            // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
+        if (v != NX + NU) {           // blocks d/dx_v, d/du_v or d/dp_j of every output row (:698-743, :763-769, :776-796, :814-820)
+          const int bv = v < NX + NU ? v : v + 1;
 #pragma unroll
           for (int o = 0; o < NO; ++o) {
             double val;
@@ -589,7 +618,7 @@ __global__ __launch_bounds__(T* RG) void rpm_tile_rl_kernel(const KParams K, con
             } else {
               val = J[o];
             }
-            vb[size_t(o * NB + v) * N] = val;
+            vb[size_t(o * NB + bv) * N] = val;
           }
         } else {                       // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign kept
           const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
@@ -757,9 +786,10 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
     double* __restrict__ vall) {
   constexpr int T = 64;   // a role of a tile is one wave
   constexpr int HT = 64 * (RG + NDMA);   // threads of one half
-  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC;
-  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU > 0 ? NU : 1;
-  constexpr int NO = NX + NC, NV = NX + NU + 1, NB = NX + NU + 2;
+  constexpr int NX = Prob::NX, NU = Prob::NU, NC = Prob::NC, NQ = prob_nq<Prob>::value;
+  constexpr int NXs = NX > 0 ? NX : 1, NUs = NU + NQ > 0 ? NU + NQ : 1;
+  constexpr int NQE = (NQ + 1) & ~1;   // the staged [t0 tf p..] run, padded to an even count
+  constexpr int NO = NX + NC, NV = NX + NU + 1 + NQ, NB = NX + NU + 2 + NQ;
   constexpr int R = WJ ? NV + 1 : (NX > 0 ? NX : 1);
   constexpr int NCs = NC > 0 ? NC : 1;
   constexpr int NTHR = T * RG;
@@ -776,7 +806,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
   const int n_iter_wg = (W - NH * int(blockIdx.x) + G - 1) / G;       // of half 0: the barrier count of the workgroup
   // one staging buffer (doubles): record, next tile's record | t0 tf | X rows | U rows | D rows | tau | diag | node
   // records | const share
-  const int S_TT = PL_REC, S_X = S_TT + 2, S_U = S_X + NX * K.max_span, S_D = S_U + NU * T;
+  const int S_TT = PL_REC, S_X = S_TT + 2 + NQE, S_U = S_X + NX * K.max_span, S_D = S_U + NU * T;
   const int S_TAU = S_D + K.max_drow, S_DG = S_TAU + T, S_ND = S_DG + T, S_CV = S_ND + 2 * T;
   const int S_SIZE = S_CV + (WJ ? K.max_cshare : 0);
   double* lds = lds_all + half * (2 * S_SIZE + (NX + NC) * T + 2 + (DXM ? NX * T : 0));
@@ -822,7 +852,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
       const int item2 = item + G, inst2 = item2 / nt;
       run(reinterpret_cast<const double*>(K.tiles + (item2 - inst2 * nt)), buf + PL_REC / 2, NREC / 2);
     }
-    run(x + tl.x_t0, buf + S_TT, 2);
+    run(x + tl.x_t0, buf + S_TT, 2 + NQ);   // t0, tf and the static parameters behind them
 #pragma unroll
     for (int i = 0; i < NX; ++i) run(x + tl.x_state0 + i * (tl.N + 1) + tl.span0, buf + S_X + i * K.max_span, tl.span_len);
 #pragma unroll
@@ -967,11 +997,13 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
       const bool trc = role == 5;
       if (trc) { RPM_PTRC(jt, 24); }
 #endif
-      double xs[NXs], us[NUs];
+      double xs[NXs], us[NUs];   // us = [controls, static parameters]
 #pragma unroll
       for (int i = 0; i < NX; ++i) xs[i] = Xs[i * K.max_span + (k - span0)];
 #pragma unroll
       for (int j = 0; j < NU; ++j) us[j] = Us[j * T + kc];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) us[NU + j] = cur[S_TT + 2 + j];
       double tk;
       {
         const double tau = cur[S_TAU + kc], t0 = cur[S_TT], tf = cur[S_TT + 1];
@@ -1006,7 +1038,8 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
         double pv;
         if (v < NX) pv = Xs[v * K.max_span + (k - span0)];
         else if (v < NX + NU) pv = Us[(v - NX) * T + kc];
-        else pv = tk;
+        else if (v == NX + NU) pv = tk;
+        else pv = cur[S_TT + 1 + (v - NX - NU)];   // static parameter v - NX - NU - 1
         h = K.tol * (1 + fabs(pv));
         const double pp = pv + h;
 #pragma unroll
@@ -1014,12 +1047,14 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
 #pragma unroll
         for (int j = 0; j < NU; ++j) us[j] = (v == NX + j) ? pp : us[j];
         tk = (v == NX + NU) ? pp : tk;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) us[NU + j] = (v == NX + NU + 1 + j) ? pp : us[NU + j];
       }
       double f[NXs], cp[NCs];
       if (!AN || role == 0) {
-        Prob::dae(phase_num, tk, xs, us, c4, f, cp);
+        pf_dae<Prob>(phase_num, tk, xs, us, us + NU, c4, f, cp);
       } else if constexpr (AN) {
-        Prob::dae_jac_col(phase_num, v, tk, xs, us, c4, f, cp);
+        pf_dae_jac_col<Prob>(phase_num, v, tk, xs, us, us + NU, c4, f, cp);
       }
 #ifdef RPM_DIAG
       if (trc) { if (f[0] == 1e300) cp[0] = 0; RPM_PTRC(jt, 26); }
@@ -1064,7 +1099,8 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
             J[o] = AN ? pert : (pert - Fb[o * T + kk]) / h;
           }
           double* __restrict__ vb = vals + v_nl0;   // block bases stay scalar; the node index k is the only per-lane part
-          if (v < NX + NU) {            // blocks d/dx_v or d/du_v of every output row (:698-743, :776-796)
+          if (v != NX + NU) {           // blocks d/dx_v, d/du_v or d/dp_j of every output row (:698-743, :763-769, :776-796, :814-820)
+            const int bv = v < NX + NU ? v : v + 1;
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
               double val;
@@ -1074,7 +1110,7 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
               } else {
                 val = J[o];
               }
-              RPM_JSTORE((vb + size_t(o * NB + v) * N)[k], val);
+              RPM_JSTORE((vb + size_t(o * NB + bv) * N)[k], val);
             }
           } else {                       // d/dt0 and d/dtf blocks (:748-760, :801-811); B-5 sign kept
             const double a0 = -(tau * 0.5) + 0.5, af = (tau * 0.5) + 0.5;
@@ -1111,11 +1147,11 @@ void tile_pipeline_setup(Engine& e, Device* d, const ProblemDims& pd, int device
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu <= 0) ncu = 256;
     const int max_c = d->kp.max_cshare;
-    const size_t stage = size_t(PL_REC + 2) + size_t(pd.nx) * e.max_span + size_t(pd.nu) * 64 + e.max_drow + 4 * 64 + max_c;
+    const size_t stage = size_t(PL_REC + 2 + ((pd.nq + 1) & ~1)) + size_t(pd.nx) * e.max_span + size_t(pd.nu) * 64 + e.max_drow + 4 * 64 + max_c;
     int per_cu = 0;
     with_problem(e.problem_id, [&](auto prob) {
       using P = decltype(prob);
-      constexpr PlShape S = pl_shape(P::NX + P::NU + 2);
+      constexpr PlShape S = pl_shape(P::NX + P::NU + 2 + prob_nq<P>::value);
       d->pl_lds = S.NH * (2 * stage + size_t(pd.nx + pd.nc) * 64 + 2) * sizeof(double);
       if (d->pl_lds > 160 * 1024) return;
       auto kern = rpm_tile_pl_kernel<P, S.NH, S.RG, S.NDMA, true, true, false>;
@@ -1128,14 +1164,14 @@ void tile_pipeline_setup(Engine& e, Device* d, const ProblemDims& pd, int device
       per_cu *= S.NH;   // resident halves per CU
     });
     d->pl_slots = per_cu * ncu;
-    d->pl_ok = e.role_looped && e.tile_nodes == 64 && max_c <= PL_CMAX && max_c >= 2 && 2 * pd.nx + 3 <= 64 &&
+    d->pl_ok = e.role_looped && e.tile_nodes == 64 && max_c <= PL_CMAX && max_c >= 2 && 2 * pd.nx + 3 + 2 * pd.nq <= 64 &&
                per_cu >= 1;
 }
 
 // ------------------------------------------------------------------------------------------
 template <class Prob, int T, bool WG, bool WJ, bool AN, bool DXM = false>
 static hipError_t launch_tile_inst(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
-  constexpr int R = WJ ? Prob::NX + Prob::NU + 2 : (Prob::NX > 0 ? Prob::NX : 1);
+  constexpr int R = WJ ? Prob::NX + Prob::NU + 2 + prob_nq<Prob>::value : (Prob::NX > 0 ? Prob::NX : 1);
   int threads = T * R;
   threads = (threads + 63) / 64 * 64;
   if (threads < 64) threads = 64;
@@ -1171,7 +1207,7 @@ static hipError_t launch_tile_rl(const Engine& e, const KParams& kp, const doubl
 static size_t pl_dxm_extra(const Engine& e) {
   ProblemDims pd;
   problem_dims(e.problem_id, &pd);
-  return size_t(pd.nx + pd.nu + 2 <= 12 ? 2 : 1) * size_t(pd.nx) * 64 * sizeof(double);
+  return size_t(pd.nx + pd.nu + 2 + pd.nq <= 12 ? 2 : 1) * size_t(pd.nx) * 64 * sizeof(double);
 }
 // dx_mode 1 on the pipelined kernel: finite-difference mode only (as in the one-role kernel), and the extra buffer must fit
 static bool pl_dxm_ok(const Engine& e) {
@@ -1181,7 +1217,7 @@ static bool pl_dxm_ok(const Engine& e) {
 template <class Prob, bool WG, bool WJ, bool AN, bool DXM = false>
 static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
   const Device& d = *e.dev;
-  constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2);
+  constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2 + prob_nq<Prob>::value);
   auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN, DXM>;
   const size_t lds = d.pl_lds + (DXM ? size_t(S.NH) * Prob::NX * 64 * sizeof(double) : 0);
   if (lds > 64 * 1024) {

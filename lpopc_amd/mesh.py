@@ -6,6 +6,7 @@ Core/Nlp2OPConverter.cpp:149-193 (the extracted
 solution becomes the next mesh's guess).  The per-node work runs on the device behind rpm_solution_error /
 rpm_ph_refine_mesh / rpm_hpliu_refine; this class only keeps the reference's bookkeeping and error behaviour.
 """
+import numpy as np
 from .problem import LpopcException
 
 
@@ -66,6 +67,8 @@ class MeshRefiner:
 def install_guess(engine, optpro, x=None, lam=None):
     """Nlp2OpControl's tail (Core/Nlp2OPConverter.cpp:160-193): the extracted time / state / control arrays of every
     phase become that phase's guess for the next mesh."""
+    xs = np.asarray(x if x is not None else engine.get_solution()[0], dtype=np.float64)
+    off = 0
     for i in range(optpro.GetPhaseNum()):
         ph = optpro.GetPhase(i)
         r = engine.nlp2op_control(i, x=x, lam=lam)
@@ -74,4 +77,7 @@ def install_guess(engine, optpro, x=None, lam=None):
         nx, nu = r["state"].size // M, r["control"].size // M
         ph.vstateguess = [[float(v) for v in r["state"][s * M:(s + 1) * M]] for s in range(nx)]
         ph.vcontrolguess = [[float(v) for v in r["control"][j * M:(j + 1) * M]] for j in range(nu)]
-        ph.vparameterguess = []
+        nq = ph.get_optimal_info()[2]
+        p0 = off + nx * M + nu * (M - 1) + 2                      # [X | U | t0 tf | p], Core/LpBoundsChecker.cpp:51-138
+        ph.vparameterguess = [float(v) for v in xs[p0:p0 + nq]]   # vparameterguess, Nlp2OPConverter.cpp:185-193
+        off = p0 + nq

@@ -20,6 +20,8 @@ RPM_PROBLEM_BRYSON_DENHAM = 3
 RPM_PROBLEM_BRACHISTOCHRONE = 4
 RPM_PROBLEM_MIN_TIME_CLIMB = 5
 RPM_PROBLEM_QUADROTOR = 6
+RPM_PROBLEM_PARAM_SLED = 7
+RPM_PROBLEM_PARAM_OSC = 8
 
 
 def set_uniform_mesh(phase, n_intervals, nodes):
@@ -433,6 +435,88 @@ def quadrotor(n_intervals=8, nodes=8, pref=(1.0, -0.5, 1.5)):
     return op
 
 
+# --------------------------------------------------------------------------- static parameters (nq > 0), authored here
+def param_sled(n_intervals=4, nodes=8, c0=0.5):
+    """Minimum-time sled with a design parameter: x' = v, v' = p u, |u| <= 1, rest to rest over unit distance, cost
+    tf + c0 p^2.  Bang-bang: tf = 2 / sqrt(p), so with c0 = 0.5 the optimum is p = 1, cost 2.5.  nx=2, nu=1, nq=1, ne=4."""
+    P1 = Phase(1, 2, 1, 1, 0, 4)
+    P1.SetTimeMin(0.0, 0.1)
+    P1.SetTimeMax(0.0, 20.0)
+    for _ in range(2):
+        P1.SetStateMin(-5, -5, -5)
+        P1.SetStateMax(5, 5, 5)
+    P1.SetcontrolMin(-1.0)
+    P1.SetcontrolMax(1.0)
+    P1.SetparameterlMin(0.05)
+    P1.SetparameterMax(10.0)
+    for v in (0, 0, 1, 0):
+        P1.SeteventMin(v)
+        P1.SeteventMax(v)
+    P1.SetTimeGuess(0.0)
+    P1.SetTimeGuess(3.0)
+    P1.SetStateGuess(1, 0.0)
+    P1.SetStateGuess(1, 1.0)
+    P1.SetStateGuess(2, 0.3)
+    P1.SetStateGuess(2, 0.2)
+    P1.SetControlGuess(1, 0.5)
+    P1.SetControlGuess(1, -0.5)
+    P1.SetparameterGuess(2.0)
+    set_uniform_mesh(P1, n_intervals, nodes)
+    op = OptimalProblem(1, 0, ProblemFunctor(RPM_PROBLEM_PARAM_SLED, [c0]))
+    op.AddPhase(P1)
+    return op
+
+
+def param_oscillator(n_intervals=(5, 3), nodes=(6, 9)):
+    """Damped oscillator with a stiffness parameter p0 and a weighting parameter p1 over two linked phases (nq = 2 each):
+    dynamics, path constraint, running and terminal cost, events and the linkage (states AND parameters continuous across
+    the phases) all depend on the parameters.  nx=2, nu=1, nq=2, nc=1, ne=2 / 1, 4 linkage constraints."""
+    phases = []
+    for ip in range(2):
+        P = Phase(ip + 1, 2, 1, 2, 1, 2 if ip == 0 else 1)
+        P.SetTimeMin(2.0 * ip, 2.0 * ip + 1.0)
+        P.SetTimeMax(2.0 * ip, 2.0 * ip + 3.0)
+        for _ in range(2):
+            P.SetStateMin(-4, -4, -4)
+            P.SetStateMax(4, 4, 4)
+        P.SetcontrolMin(-3.0)
+        P.SetcontrolMax(3.0)
+        P.SetparameterlMin(0.2)
+        P.SetparameterMax(5.0)
+        P.SetparameterlMin(0.1)
+        P.SetparameterMax(2.0)
+        P.SetpathMin(-6.0)
+        P.SetpathMax(6.0)
+        if ip == 0:
+            for v in (1.0, 0.0):
+                P.SeteventMin(v)
+                P.SeteventMax(v)
+        else:
+            P.SeteventMin(0.0)
+            P.SeteventMax(1.5)
+        P.SetTimeGuess(2.0 * ip)
+        P.SetTimeGuess(2.0 * ip + 2.0)
+        P.SetStateGuess(1, 1.0 - 0.4 * ip)
+        P.SetStateGuess(1, 0.6 - 0.4 * ip)
+        P.SetStateGuess(2, -0.3)
+        P.SetStateGuess(2, -0.1)
+        P.SetControlGuess(1, 0.2)
+        P.SetControlGuess(1, -0.1)
+        P.SetparameterGuess(1.3)
+        P.SetparameterGuess(0.7)
+        set_uniform_mesh(P, n_intervals[ip], nodes[ip])
+        phases.append(P)
+    lk = Linkage(1, 1, 2)
+    for _ in range(4):
+        lk.SetLinkMin(0)
+        lk.SetLinkMax(0)
+    op = OptimalProblem(2, 1, ProblemFunctor(RPM_PROBLEM_PARAM_OSC, [0.4, 0.05]))
+    for P in phases:
+        op.AddPhase(P)
+    op.AddLinkage(lk)
+    return op
+
+
 # --------------------------------------------------------------------------- configs + iterates
 def config(name):
     """BASELINE.json configs by short name -> OptimalProblem."""
@@ -453,6 +537,10 @@ def config(name):
         return quadrotor(8, 8)
     if name == "bryson_denham":
         return bryson_denham()
+    if name == "param_sled":
+        return param_sled()
+    if name == "param_oscillator":
+        return param_oscillator()
     raise KeyError(name)
 
 

@@ -367,8 +367,21 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
     p->nc = pd->nc;
     p->ne = pd->ne;
     p->K = pd->n_intervals;
-    if (pd->nq > 0) {
-      fail(err, errlen, "static parameters (nq>0) are outside the parity domain (SURVEY B-6..B-9)");
+    /* Static parameters (nq > 0).  Layout, bounds, guess and the ORDER of every derivative column / Jacobian block follow
+     * the reference (LpBoundsChecker.cpp:117-138, LpGuessChecker.cpp:186-189, LpFiniteDifferenceDerive.cpp:282-317,
+     * LpNLPWrapper.cpp:763-769,814-820,854-859,461-519,1088-1097).  Its VALUES do not: the reference's parameter path is
+     * inconsistent with itself, and this oracle restates the formulas it means —
+     *   B-6  dDae/dPath_parameter read derivative column nx+nu+ip, the TIME column for ip = 0 (:618,621): column nx+nu+1+ip here;
+     *   B-7  the path rows' parameter block inserts dDae_parameter (:817): dPath_parameter here;
+     *   B-8  the parameter blocks' sparsity is a diagonal run indexvector + colstart (:1211,1262): the parameter's ONE column here;
+     *   B-9  right_parameter_ = p_left, right-parameter differences divided by the left step, DLink_p_left stored twice
+     *        (:203,423, LpFiniteDifferenceDerive.cpp:485,500): the right phase's parameters, each by its own step, here;
+     *   B-21 GetObjGrad never fills SolCost.parameter_ and multiplies two column vectors for dCost/dp (:975,1094): the phase's
+     *        parameters and the quadrature sum_k w_k (dt/2) dL/dp_j here; dLagrange_time is read from the LAST column (:1025),
+     *        the time column nx+nu here.
+     * So for nq > 0 this oracle is the specification, not a restatement; the exact Hessian is not defined for nq > 0. */
+    if (pd->nq > 0 && d->hessian_approximation == RPM_HESSIAN_EXACT) {
+      fail(err, errlen, "hessian-approximation=exact is not defined here for static parameters (nq>0)");
       orpm_destroy(o);
       return NULL;
     }
@@ -470,6 +483,15 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
     o->xu[vi++] = pd->t0_max;
     o->xl[vi] = pd->tf_min;
     o->xu[vi++] = pd->tf_max;
+    for (int j = 0; j < p->nq; j++) { /* :117-138 */
+      if (!(pd->parameter_min[j] <= pd->parameter_max[j])) {
+        fail(err, errlen, "Bounds on parameter are Inconsistent (i.e. max < min)");
+        orpm_destroy(o);
+        return NULL;
+      }
+      o->xl[vi] = pd->parameter_min[j];
+      o->xu[vi++] = pd->parameter_max[j];
+    }
     for (int j = 0; j < p->nc; j++) { /* :141-162 */
       if (!(pd->path_min[j] <= pd->path_max[j])) {
         fail(err, errlen, "Bounds on path are Inconsistent (i.e. max < min)");
@@ -575,6 +597,7 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
       for (int k = 0; k < p->N; k++) g[r++] = orpm_spline_interp(p->points[k], tauG, pd->control_guess + (size_t)j * ng, ng);
     g[r++] = t0G;
     g[r++] = tfG;
+    for (int j = 0; j < p->nq; j++) g[r++] = pd->parameter_guess[j]; /* LpGuessChecker.cpp:186-189 */
     free(tauG);
   }
 
@@ -591,6 +614,11 @@ orpm* orpm_create(const rpm_problem_desc* d, char* err, int errlen) {
   for (int i = 0; i < o->L; i++) {
     /* :1362-1373 queries the LEFT phase twice (SURVEY B-11) */
     ophase* pl = &o->ph[o->lk[i].left];
+    if (pl->nq != o->ph[o->lk[i].right].nq || pl->nx != o->ph[o->lk[i].right].nx) {
+      fail(err, errlen, "linked phases must have equal nx and nq (SURVEY B-11)");
+      orpm_destroy(o);
+      return NULL;
+    }
     o->nnz_nl += o->lk[i].nlink * (pl->nx + pl->nq + pl->nx + pl->nq);
   }
   o->nnz_lin = o->alin_nnz;
@@ -708,6 +736,7 @@ void orpm_slice_phase(const orpm* o, int i, const double* x, pslice* s) {
     s->xf[j] = s->state_matrix[(size_t)j * (N + 1) + N];
   }
   s->control = orpm_dupd(x + p->control0, N * p->nu);
+  s->parameter = orpm_dupd(x + p->param0, p->nq); /* :90-96 */
 }
 void orpm_free_slice(pslice* s) {
   free(s->t_radau);
@@ -716,6 +745,7 @@ void orpm_free_slice(pslice* s) {
   free(s->control);
   free(s->x0);
   free(s->xf);
+  free(s->parameter);
 }
 void orpm_mk_soldae(const pslice* s, int phase_num, orpm_soldae* d) {
   d->phase_num = phase_num;
@@ -727,7 +757,7 @@ void orpm_mk_soldae(const pslice* s, int phase_num, orpm_soldae* d) {
   d->time = s->t_radau;
   d->state = s->state_radau;
   d->control = s->control;
-  d->parameter = NULL;
+  d->parameter = s->parameter;
 }
 void orpm_mk_solcost(const pslice* s, int phase_num, orpm_solcost* c) {
   c->phase_num = phase_num;
@@ -742,7 +772,7 @@ void orpm_mk_solcost(const pslice* s, int phase_num, orpm_solcost* c) {
   c->time = s->t_radau;
   c->state = s->state_radau;
   c->control = s->control;
-  c->parameter = NULL;
+  c->parameter = s->parameter;
 }
 void orpm_mk_solevent(const pslice* s, int phase_num, orpm_solevent* e) {
   e->phase_num = phase_num;
@@ -753,7 +783,7 @@ void orpm_mk_solevent(const pslice* s, int phase_num, orpm_solevent* e) {
   e->ne = s->ne;
   e->initial_state = s->x0;
   e->terminal_state = s->xf;
-  e->parameter = NULL;
+  e->parameter = s->parameter;
 }
 
 /* ===========================================================================
@@ -804,11 +834,13 @@ void orpm_eval_g(orpm* o, const double* x, double* g) {
     sl.ipair = ip + 1;
     sl.nxl = o->ph[l->left].nx;
     sl.nxr = o->ph[l->right].nx;
-    sl.nql = sl.nqr = 0;
+    sl.nql = o->ph[l->left].nq;
+    sl.nqr = o->ph[l->right].nq;
     sl.nlink = l->nlink;
     sl.left_state = xfs[l->left];
     sl.right_state = x0s[l->right];
-    sl.left_parameter = sl.right_parameter = NULL;
+    sl.left_parameter = x + o->ph[l->left].param0;
+    sl.right_parameter = x + o->ph[l->right].param0; /* the RIGHT phase's (the reference hands p_left twice, :203 - B-9) */
     double* lo = NEW(double, l->nlink);
     o->fun->link(&sl, o->consts, lo);
     for (int q = 0; q < l->nlink; q++) g[row + q] = lo[q];
@@ -828,11 +860,11 @@ void orpm_eval_g(orpm* o, const double* x, double* g) {
 /* ===========================================================================
  * finite differences, Core/LpFiniteDifferenceDerive.cpp
  * ======================================================================== */
-/* LpFDderive::DerivDae :194-324.  Output dstate [(N nx) x (nx+nu+1)], dpath [(N nc) x (...)],
- * column order [x.., u.., t], rows output-major then node (:299-317). */
+/* LpFDderive::DerivDae :194-324.  Output dstate [(N nx) x (nx+nu+1+nq)], dpath [(N nc) x (...)],
+ * column order [x.., u.., t, p..], rows output-major then node (:299-317). */
 static void fd_deriv_dae(orpm* o, const orpm_soldae* base, double* dstate, double* dpath) {
-  int N = base->N, nx = base->nx, nu = base->nu, nc = base->nc;
-  int nout = nx + nc, ncolD = nx + nu + 1;
+  int N = base->N, nx = base->nx, nu = base->nu, nc = base->nc, nq = base->nq;
+  int nout = nx + nc, ncolD = nx + nu + 1 + nq;
   double tol = o->tol;
   double* daeout = NEW(double, (size_t)N * nx);
   double* pathout = NEW(double, (size_t)N * (nc > 0 ? nc : 1));
@@ -893,6 +925,23 @@ static void fd_deriv_dae(orpm* o, const orpm_soldae* base, double* dstate, doubl
     STORE(nx + ic, pertControl + (size_t)ic * N);
     memcpy(work_control + (size_t)ic * N, base->control + (size_t)ic * N, sizeof(double) * N);
   }
+  /* static parameters, :280-297: one whole-vector call per parameter, the same step at every node */
+  if (nq > 0) {
+    double* work_par = orpm_dupd(base->parameter, nq);
+    double* pertPar = NEW(double, N);
+    sd.control = base->control;
+    sd.parameter = work_par;
+    for (int ip = 0; ip < nq; ip++) {
+      double hp = tol * (1 + fabs(base->parameter[ip]));
+      for (int k = 0; k < N; k++) pertPar[k] = hp;
+      work_par[ip] = base->parameter[ip] + hp;
+      o->fun->dae(&sd, o->consts, pso, ppo);
+      STORE(nx + nu + 1 + ip, pertPar);
+      work_par[ip] = base->parameter[ip];
+    }
+    free(work_par);
+    free(pertPar);
+  }
 #undef STORE
   (void)ncolD;
   free(daeout);
@@ -909,9 +958,9 @@ static void fd_deriv_dae(orpm* o, const orpm_soldae* base, double* dstate, doubl
   free(work_control);
 }
 
-/* LpFDderive::DerivEvent :326-409.  Output [ne x (2nx+2)] = [x0.., t0, xf.., tf], column-major. */
+/* LpFDderive::DerivEvent :326-409.  Output [ne x (2nx+2+nq)] = [x0.., t0, xf.., tf, p..], column-major. */
 static void fd_deriv_event(orpm* o, const orpm_solevent* base, double* d) {
-  int nx = base->nx, ne = base->ne;
+  int nx = base->nx, ne = base->ne, nq = base->nq;
   double tol = o->tol;
   double pert0 = tol * (1 + fabs(base->initial_time));
   double pertf = tol * (1 + fabs(base->terminal_time));
@@ -943,15 +992,27 @@ static void fd_deriv_event(orpm* o, const orpm_solevent* base, double* d) {
     for (int q = 0; q < ne; q++) d[q + (size_t)(nx + 1 + is) * ne] = (pe[q] - ev[q]) / (pxf * 1.0);
     xf[is] = base->terminal_state[is];
   }
+  if (nq > 0) { /* :385-400 */
+    double* wp = orpm_dupd(base->parameter, nq);
+    se.parameter = wp;
+    for (int ip = 0; ip < nq; ip++) {
+      double hp = tol * (1 + fabs(base->parameter[ip]));
+      wp[ip] = base->parameter[ip] + hp;
+      o->fun->event(&se, o->consts, pe);
+      for (int q = 0; q < ne; q++) d[q + (size_t)(2 * nx + 2 + ip) * ne] = (pe[q] - ev[q]) / hp;
+      wp[ip] = base->parameter[ip];
+    }
+    free(wp);
+  }
   free(ev);
   free(pe);
   free(x0);
   free(xf);
 }
 
-/* LpFDderive::DerivLink :411-502.  Output [nlink x (nxl+nxr)] = [xf_left.., x0_right..]. */
+/* LpFDderive::DerivLink :411-502.  Output [nlink x (nxl+nql+nxr+nqr)] = [xf_left.., p_left.., x0_right.., p_right..]. */
 static void fd_deriv_link(orpm* o, const orpm_sollink* base, double* d) {
-  int nl = base->nlink, nxl = base->nxl, nxr = base->nxr;
+  int nl = base->nlink, nxl = base->nxl, nxr = base->nxr, nql = base->nql, nqr = base->nqr;
   double tol = o->tol;
   double* lo = NEW(double, nl);
   double* pl = NEW(double, nl);
@@ -972,8 +1033,30 @@ static void fd_deriv_link(orpm* o, const orpm_sollink* base, double* d) {
     double pert = tol * (1 + fabs(base->right_state[is]));
     xr[is] = base->right_state[is] + pert;
     o->fun->link(&sl, o->consts, pl);
-    for (int q = 0; q < nl; q++) d[q + (size_t)(nxl + is) * nl] = (pl[q] - lo[q]) / (1.0 * pert);
+    for (int q = 0; q < nl; q++) d[q + (size_t)(nxl + nql + is) * nl] = (pl[q] - lo[q]) / (1.0 * pert);
     xr[is] = base->right_state[is];
+  }
+  if (nql + nqr > 0) { /* :455-500; each parameter by its own step (SURVEY B-9) */
+    double* wl = orpm_dupd(base->left_parameter, nql);
+    double* wr = orpm_dupd(base->right_parameter, nqr);
+    sl.left_parameter = wl;
+    sl.right_parameter = wr;
+    for (int ip = 0; ip < nql; ip++) {
+      double pert = tol * (1 + fabs(base->left_parameter[ip]));
+      wl[ip] = base->left_parameter[ip] + pert;
+      o->fun->link(&sl, o->consts, pl);
+      for (int q = 0; q < nl; q++) d[q + (size_t)(nxl + ip) * nl] = (pl[q] - lo[q]) / (1.0 * pert);
+      wl[ip] = base->left_parameter[ip];
+    }
+    for (int ip = 0; ip < nqr; ip++) {
+      double pert = tol * (1 + fabs(base->right_parameter[ip]));
+      wr[ip] = base->right_parameter[ip] + pert;
+      o->fun->link(&sl, o->consts, pl);
+      for (int q = 0; q < nl; q++) d[q + (size_t)(nxl + nql + nxr + ip) * nl] = (pl[q] - lo[q]) / (1.0 * pert);
+      wr[ip] = base->right_parameter[ip];
+    }
+    free(wl);
+    free(wr);
   }
   free(lo);
   free(pl);
@@ -981,9 +1064,9 @@ static void fd_deriv_link(orpm* o, const orpm_sollink* base, double* d) {
   free(xr);
 }
 
-/* LpFDderive::DerivMayer :11-98.  Output [1 x (2nx+2)] = [x0.., t0, xf.., tf]. */
+/* LpFDderive::DerivMayer :11-98.  Output [1 x (2nx+2+nq)] = [x0.., t0, xf.., tf, p..]. */
 static void fd_deriv_mayer(orpm* o, const orpm_solcost* base, double* d) {
-  int nx = base->nx;
+  int nx = base->nx, nq = base->nq;
   double tol = o->tol;
   double pert0 = tol * (1 + fabs(base->initial_time));
   double pertf = tol * (1 + fabs(base->terminal_time));
@@ -1014,13 +1097,25 @@ static void fd_deriv_mayer(orpm* o, const orpm_solcost* base, double* d) {
     d[nx + 1 + is] = (mp - m0) / pxf;
     xf[is] = base->terminal_state[is];
   }
+  if (nq > 0) { /* :74-90 */
+    double* wp = orpm_dupd(base->parameter, nq);
+    sc.parameter = wp;
+    for (int ip = 0; ip < nq; ip++) {
+      double hp = tol * (1 + fabs(base->parameter[ip]));
+      wp[ip] = base->parameter[ip] + hp;
+      o->fun->mayer(&sc, o->consts, &mp);
+      d[2 * nx + 2 + ip] = (mp - m0) / hp;
+      wp[ip] = base->parameter[ip];
+    }
+    free(wp);
+  }
   free(x0);
   free(xf);
 }
 
-/* LpFDderive::DerivLagrange :100-192.  Output [N x (nx+nu+1)] = [x.., u.., t]. */
+/* LpFDderive::DerivLagrange :100-192.  Output [N x (nx+nu+1+nq)] = [x.., u.., t, p..]. */
 static void fd_deriv_lagrange(orpm* o, const orpm_solcost* base, double* d) {
-  int N = base->N, nx = base->nx, nu = base->nu;
+  int N = base->N, nx = base->nx, nu = base->nu, nq = base->nq;
   double tol = o->tol;
   double* L0 = NEW(double, N);
   double* Lp = NEW(double, N);
@@ -1059,6 +1154,19 @@ static void fd_deriv_lagrange(orpm* o, const orpm_solcost* base, double* d) {
       d[k + (size_t)(nx + ic) * N] = (Lp[k] - L0[k]) / (tol * (1 + fabs(b)));
       wc[k + (size_t)ic * N] = b;
     }
+  }
+  if (nq > 0) { /* :165-182 */
+    double* wp = orpm_dupd(base->parameter, nq);
+    sc.control = base->control;
+    sc.parameter = wp;
+    for (int ip = 0; ip < nq; ip++) {
+      double hp = tol * (1 + fabs(base->parameter[ip]));
+      wp[ip] = base->parameter[ip] + hp;
+      o->fun->lagrange(&sc, o->consts, Lp);
+      for (int k = 0; k < N; k++) d[k + (size_t)(nx + nu + 1 + ip) * N] = (Lp[k] - L0[k]) / hp;
+      wp[ip] = base->parameter[ip];
+    }
+    free(wp);
   }
   free(L0);
   free(Lp);
@@ -1108,8 +1216,8 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
   const ophase* p = &o->ph[iphase];
   pslice s;
   orpm_slice_phase(o, iphase, x, &s);
-  int N = s.N, nx = p->nx, nu = p->nu, nc = p->nc, ne = p->ne;
-  int ncolD = nx + nu + 1;
+  int N = s.N, nx = p->nx, nu = p->nu, nc = p->nc, ne = p->ne, nq = p->nq;
+  int ncolD = nx + nu + 1 + nq;
   double t0 = s.t0, tf = s.tf;
   orpm_soldae sd;
   orpm_mk_soldae(&s, iphase + 1, &sd);
@@ -1126,7 +1234,7 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
   if (ne > 0) { /* :638-669 */
     orpm_solevent se;
     orpm_mk_solevent(&s, iphase + 1, &se);
-    dEventOut = NEW(double, (size_t)ne * (2 * nx + 2));
+    dEventOut = NEW(double, (size_t)ne * (2 * nx + 2 + nq));
     deriv_event(o, &se, dEventOut);
   }
   /* per-call Find of the off-diagonal matrix, :685-687 (the fair shape found it once) */
@@ -1168,6 +1276,10 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
       SV[sh + k] = ret;
     }
     sh += N;
+    for (int j = 0; j < nq; j++) { /* d/dp_j :763-769, from the parameter's own derivative column (B-6) */
+      for (int k = 0; k < N; k++) SV[sh + k] = -(DDAE(i, nx + nu + 1 + j, k) * (tf - t0) / 2.0);
+      sh += N;
+    }
   }
   for (int i = 0; i < nc; i++) { /* :773-820 */
     for (int j = 0; j < nx; j++) {
@@ -1182,6 +1294,10 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
     sh += N;
     for (int k = 0; k < N; k++) SV[sh + k] = ((p->points[k] * 0.5) + 0.5) * DPATH(i, nx + nu, k);
     sh += N;
+    for (int j = 0; j < nq; j++) { /* dc/dp_j :814-820, the PATH derivative (B-7) */
+      for (int k = 0; k < N; k++) SV[sh + k] = DPATH(i, nx + nu + 1 + j, k);
+      sh += N;
+    }
   }
   for (int i = 0; i < ne; i++) { /* :833-861 */
     for (int j = 0; j < nx; j++) {
@@ -1190,6 +1306,7 @@ static int phase_jac(orpm* o, int iphase, const double* x, double* SV, double* S
     }
     SV[sh++] = dEventOut[i + (size_t)nx * ne];           /* t0 */
     SV[sh++] = dEventOut[i + (size_t)(2 * nx + 1) * ne]; /* tf */
+    for (int j = 0; j < nq; j++) SV[sh++] = dEventOut[i + (size_t)(2 * nx + 2 + j) * ne]; /* :854-859 */
   }
 #undef DDAE
 #undef DPATH
@@ -1263,15 +1380,18 @@ void orpm_eval_jac_g(orpm* o, const double* x, double* values) {
     sl.ipair = ip + 1;
     sl.nxl = pl->nx;
     sl.nxr = pr->nx;
-    sl.nql = sl.nqr = 0;
+    sl.nql = pl->nq;
+    sl.nqr = pr->nq;
     sl.nlink = l->nlink;
     sl.left_state = xfl;
     sl.right_state = x0r;
-    sl.left_parameter = sl.right_parameter = NULL;
-    double* dL = NEW(double, (size_t)l->nlink * (pl->nx + pr->nx));
+    sl.left_parameter = x + pl->param0;
+    sl.right_parameter = x + pr->param0;
+    int ncl = pl->nx + pl->nq + pr->nx + pr->nq;
+    double* dL = NEW(double, (size_t)l->nlink * ncl);
     deriv_link(o, &sl, dL);
-    /* column-major walk over DLink_xf_left then DLink_x0_Right, :461-501 */
-    for (int q = 0; q < l->nlink * (pl->nx + pr->nx); q++) NL[sj++] = dL[q];
+    /* column-major walk over DLink_xf_left, DLink_p_left, DLink_x0_Right, DLink_p_right, :461-519 */
+    for (int q = 0; q < l->nlink * ncl; q++) NL[sj++] = dL[q];
     free(dL);
     free(xfl);
     free(x0r);
@@ -1295,7 +1415,7 @@ void orpm_jac_structure(orpm* o, int* iRow, int* jCol) {
   int rowshift = 0, colshift = 0;
   for (int ip = 0; ip < o->P; ip++) {
     const ophase* p = &o->ph[ip];
-    int N = p->N, nx = p->nx, nu = p->nu, nc = p->nc, ne = p->ne, disc = N + 1;
+    int N = p->N, nx = p->nx, nu = p->nu, nc = p->nc, ne = p->ne, nq = p->nq, disc = N + 1;
 #define BLOCK_DIAG(r0, c0)                       \
   for (int k = 0; k < N; k++) {                  \
     iRow[sj] = rowshift + (r0) + k;              \
@@ -1321,6 +1441,7 @@ void orpm_jac_structure(orpm* o, int* iRow, int* jCol) {
       cs += nu * N;
       BLOCK_COL(rowstart, cs);
       BLOCK_COL(rowstart, cs + 1);
+      for (int j = 0; j < nq; j++) BLOCK_COL(rowstart, cs + 2 + j); /* every node's row, the parameter's one column (B-8) */
     }
     int rs = nx * N;
     for (int i = 0; i < nc; i++) { /* :1217-1265 */
@@ -1331,6 +1452,7 @@ void orpm_jac_structure(orpm* o, int* iRow, int* jCol) {
       cs += nu * N;
       BLOCK_COL(rowstart, cs);
       BLOCK_COL(rowstart, cs + 1);
+      for (int j = 0; j < nq; j++) BLOCK_COL(rowstart, cs + 2 + j);
     }
     rs = nx * N + nc * N;
     for (int i = 0; i < ne; i++) { /* :1278-1311 */
@@ -1346,6 +1468,10 @@ void orpm_jac_structure(orpm* o, int* iRow, int* jCol) {
       jCol[sj++] = colshift + cols;
       iRow[sj] = rowshift + row;
       jCol[sj++] = colshift + cols + 1;
+      for (int j = 0; j < nq; j++) {
+        iRow[sj] = rowshift + row;
+        jCol[sj++] = colshift + cols + 2 + j;
+      }
     }
 #undef BLOCK_DIAG
 #undef BLOCK_COL
@@ -1363,10 +1489,20 @@ void orpm_jac_structure(orpm* o, int* iRow, int* jCol) {
         iRow[sj] = ir + linkrow;
         jCol[sj++] = (jc + 1) * pl->N + jc + pl->state0; /* :1488-1489 */
       }
+    for (int jc = 0; jc < pl->nq; jc++)
+      for (int ir = 0; ir < l->nlink; ir++) {
+        iRow[sj] = ir + linkrow;
+        jCol[sj++] = pl->param0 + jc; /* :1495-1510 */
+      }
     for (int jc = 0; jc < pr->nx; jc++)
       for (int ir = 0; ir < l->nlink; ir++) {
         iRow[sj] = ir + linkrow;
         jCol[sj++] = jc * (pr->N + 1) + pr->state0; /* :1520-1521 */
+      }
+    for (int jc = 0; jc < pr->nq; jc++)
+      for (int ir = 0; ir < l->nlink; ir++) {
+        iRow[sj] = ir + linkrow;
+        jCol[sj++] = pr->param0 + jc; /* :1527-1543 */
       }
     linkrow += l->nlink;
   }
@@ -1416,18 +1552,18 @@ void orpm_eval_grad_f(orpm* o, const double* x, double* grad_f) {
     const ophase* p = &o->ph[ip];
     pslice s;
     orpm_slice_phase(o, ip, x, &s);
-    int N = p->N, nx = p->nx, nu = p->nu;
+    int N = p->N, nx = p->nx, nu = p->nu, nq = p->nq;
     double tspan = s.tspan;
     orpm_solcost sc;
     orpm_mk_solcost(&s, ip + 1, &sc);
     double* Lout = NEW(double, N);
-    double* dM = NEW(double, 2 * nx + 2);
-    double* dL = NEW(double, (size_t)N * (nx + nu + 1));
+    double* dM = NEW(double, 2 * nx + 2 + nq);
+    double* dL = NEW(double, (size_t)N * (nx + nu + 1 + nq));
     o->fun->lagrange(&sc, o->consts, Lout);  /* :989 */
     deriv_mayer(o, &sc, dM);                 /* :990 */
     orpm_deriv_lagrange(o, &sc, dL);              /* :991 */
     double dMayer_t0 = dM[nx], dMayer_tf = dM[2 * nx + 1];
-    const double* dLt = dL + (size_t)(nx + nu) * N; /* last column, :1025 */
+    const double* dLt = dL + (size_t)(nx + nu) * N; /* the time column (the reference takes the LAST column, :1025: the same for nq = 0) */
     double* J = grad_f + gs;
     for (int j = 0; j < nx; j++) { /* :1045-1055 */
       int col0 = N * j + j, colf = N * (j + 1) + j;
@@ -1456,6 +1592,11 @@ void orpm_eval_grad_f(orpm* o, const double* x, double* grad_f) {
     ret = orpm_arma_dot(a, Lout, N);
     double ret3_00 = (p->points[0] * (0.5) + 0.5) * r2[0];
     J[cs + 1] = dMayer_tf + ret + ret3_00;
+    /* d/dp_j, :1088-1097: dMayer/dp_j + sum_k w_k (tspan/2) dL/dp_j (the quadrature the reference means, B-21) */
+    for (int j = 0; j < nq; j++) {
+      for (int k = 0; k < N; k++) a[k] = p->weights[k] * (tspan / 2.0);
+      J[cs + 2 + j] = dM[2 * nx + 2 + j] + orpm_arma_dot(a, dL + (size_t)(nx + nu + 1 + j) * N, N);
+    }
     free(a);
     free(r2);
     free(r3);

@@ -68,6 +68,7 @@ typedef struct {
   double* state_radau;  /* N x nx */
   double* control;      /* N x nu */
   double *x0, *xf;      /* nx */
+  double* parameter;    /* nq */
 } pslice;
 
 

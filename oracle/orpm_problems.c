@@ -402,6 +402,101 @@ static void zero_mayer(const orpm_solcost* s, const double* c, double* m) {
   *m = 0.0;
 }
 
+/* ===========================================================================
+ * Minimum-time sled with a design parameter (authored; nq = 1).  x' = v, v' = p u, rest to rest over unit distance,
+ * cost tf + c0 p^2; with c0 = 0.5 the optimum is p = 1, cost 2.5.  Analytic derivatives given.  consts: 0 c0.
+ * ======================================================================== */
+static void sled_dae(const orpm_soldae* s, const double* c, double* so, double* po) {
+  (void)c;
+  (void)po;
+  int N = s->N;
+  for (int k = 0; k < N; k++) {
+    COL(so, 0, N)[k] = COL(s->state, 1, N)[k];
+    COL(so, 1, N)[k] = s->parameter[0] * s->control[k];
+  }
+}
+static void sled_event(const orpm_solevent* s, const double* c, double* e) {
+  (void)c;
+  e[0] = s->initial_state[0];
+  e[1] = s->initial_state[1];
+  e[2] = s->terminal_state[0];
+  e[3] = s->terminal_state[1];
+}
+static void sled_mayer(const orpm_solcost* s, const double* c, double* m) {
+  *m = s->terminal_time + c[0] * (s->parameter[0] * s->parameter[0]);
+}
+static void sled_deriv_dae(const orpm_soldae* s, const double* c, double* ds, double* dp) {
+  (void)c;
+  (void)dp;
+  int N = s->N, nx = 2;
+  size_t cs_ = (size_t)N * nx;
+  memset(ds, 0, sizeof(double) * cs_ * 5); /* columns [x, v, u, t, p] */
+  for (int k = 0; k < N; k++) {
+    ds[(k + 0 * (size_t)N) + 1 * cs_] = 1.0;             /* f0 / v */
+    ds[(k + 1 * (size_t)N) + 2 * cs_] = s->parameter[0]; /* f1 / u */
+    ds[(k + 1 * (size_t)N) + 4 * cs_] = s->control[k];   /* f1 / p */
+  }
+}
+static void sled_deriv_event(const orpm_solevent* s, const double* c, double* d) {
+  (void)c;
+  int ne = 4, nx = s->nx;
+  memset(d, 0, sizeof(double) * (size_t)ne * (2 * nx + 2 + 1)); /* [x0(2), t0, xf(2), tf, p] */
+  d[0 + (size_t)0 * ne] = 1.0;
+  d[1 + (size_t)1 * ne] = 1.0;
+  d[2 + (size_t)(nx + 1 + 0) * ne] = 1.0;
+  d[3 + (size_t)(nx + 1 + 1) * ne] = 1.0;
+}
+static void sled_deriv_mayer(const orpm_solcost* s, const double* c, double* d) {
+  for (int j = 0; j < 2 * s->nx + 2 + 1; j++) d[j] = 0.0;
+  d[2 * s->nx + 1] = 1.0;
+  d[2 * s->nx + 2] = 2.0 * c[0] * s->parameter[0];
+}
+static void sled_deriv_lagrange(const orpm_solcost* s, const double* c, double* d) {
+  (void)c;
+  memset(d, 0, sizeof(double) * (size_t)s->N * (s->nx + s->nu + 1 + s->nq));
+}
+
+/* ===========================================================================
+ * Damped oscillator with stiffness / weighting parameters over two linked phases (authored; nq = 2 per phase).
+ * consts: 0 damping, 1 weight of p0^2.
+ * ======================================================================== */
+static void posc_dae(const orpm_soldae* s, const double* c, double* so, double* po) {
+  int N = s->N;
+  for (int k = 0; k < N; k++) {
+    double x1 = COL(s->state, 0, N)[k], x2 = COL(s->state, 1, N)[k], u = s->control[k];
+    COL(so, 0, N)[k] = x2;
+    COL(so, 1, N)[k] = (-(s->parameter[0] * x1) - c[0] * x2) + u;
+    po[k] = x1 + s->parameter[1] * u;
+  }
+}
+static void posc_event(const orpm_solevent* s, const double* c, double* e) {
+  (void)c;
+  if (s->phase_num == 1) {
+    e[0] = s->initial_state[0];
+    e[1] = s->initial_state[1];
+  } else {
+    e[0] = s->terminal_state[0] + s->parameter[1];
+  }
+}
+static void posc_link(const orpm_sollink* s, const double* c, double* lo) {
+  (void)c;
+  lo[0] = s->left_state[0] - s->right_state[0];
+  lo[1] = s->left_state[1] - s->right_state[1];
+  lo[2] = s->left_parameter[0] - s->right_parameter[0];
+  lo[3] = s->left_parameter[1] - s->right_parameter[1];
+}
+static void posc_mayer(const orpm_solcost* s, const double* c, double* m) {
+  (void)c;
+  *m = s->phase_num == 2 ? s->terminal_state[0] * s->terminal_state[0] + s->parameter[0] * s->parameter[1] : 0.0;
+}
+static void posc_lagrange(const orpm_solcost* s, const double* c, double* L) {
+  int N = s->N;
+  for (int k = 0; k < N; k++) {
+    double x1 = COL(s->state, 0, N)[k], u = s->control[k];
+    L[k] = (u * u + s->parameter[1] * (x1 * x1)) + c[1] * (s->parameter[0] * s->parameter[0]);
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 static const orpm_functions F_LAUNCH = {launch_mayer, zero_lagrange, launch_dae, launch_event, diff_link,
                                         NULL, NULL, NULL, NULL, NULL};
@@ -415,6 +510,10 @@ static const orpm_functions F_CLIMB = {tf_mayer, zero_lagrange, climb_dae, climb
                                        NULL, NULL, NULL, NULL, NULL};
 static const orpm_functions F_QUAD = {zero_mayer, quad_lagrange, quad_dae, no_event, no_link,
                                       NULL, NULL, NULL, NULL, NULL};
+static const orpm_functions F_SLED = {sled_mayer, zero_lagrange, sled_dae, sled_event, no_link,
+                                      sled_deriv_mayer, sled_deriv_lagrange, sled_deriv_dae, sled_deriv_event, NULL};
+static const orpm_functions F_POSC = {posc_mayer, posc_lagrange, posc_dae, posc_event, posc_link,
+                                      NULL, NULL, NULL, NULL, NULL};
 
 const orpm_functions* orpm_problem_functions(int id) {
   switch (id) {
@@ -424,6 +523,8 @@ const orpm_functions* orpm_problem_functions(int id) {
     case RPM_PROBLEM_BRACHISTOCHRONE: return &F_BRACH;
     case RPM_PROBLEM_MIN_TIME_CLIMB: return &F_CLIMB;
     case RPM_PROBLEM_QUADROTOR: return &F_QUAD;
+    case RPM_PROBLEM_PARAM_SLED: return &F_SLED;
+    case RPM_PROBLEM_PARAM_OSC: return &F_POSC;
   }
   return NULL;
 }
