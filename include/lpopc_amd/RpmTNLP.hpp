@@ -84,4 +84,65 @@ class RpmTNLPT : public Base {
   bool owned_;   // the caller's promise about the arrays (constructor)
 };
 
+// The same adaptor over a group of engines, one per GPU (rpm_group_*, include/rpm_hip.h): lpopc's NLPSolver::SolveNlp is one
+// process driving ONE TNLP object, so this is how its callbacks reach more than one device.  The constraint callbacks go to
+// every device (each stores its share into Ipopt's arrays, which a group page-locks once for all devices); objective,
+// gradient and exact Hessian to rank 0; sizes, bounds, starting point and the stored solution to rank 0's engine.
+template <class Base>
+class RpmGroupTNLPT : public Base {
+ public:
+  using Index = typename Base::Index;
+  using Number = typename Base::Number;
+  using IndexStyleEnum = typename Base::IndexStyleEnum;
+  using SolverReturn = typename Base::SolverReturn;
+
+  explicit RpmGroupTNLPT(rpm_group* group) : g_(group), e0_(rpm_group_engine(group, 0)) {}
+
+  bool get_nlp_info(Index& n, Index& m, Index& nnz_jac_g, Index& nnz_h_lag, IndexStyleEnum& index_style) override {
+    int n_, m_, nj, nh, st;
+    if (rpm_get_nlp_info(e0_, &n_, &m_, &nj, &nh, &st)) return false;
+    n = n_; m = m_; nnz_jac_g = nj; nnz_h_lag = nh;
+    index_style = Base::C_STYLE;
+    return true;
+  }
+  bool get_bounds_info(Index n, Number* x_l, Number* x_u, Index m, Number* g_l, Number* g_u) override {
+    return rpm_get_bounds_info(e0_, n, x_l, x_u, m, g_l, g_u) == RPM_OK;
+  }
+  bool get_starting_point(Index n, bool init_x, Number* x, bool init_z, Number* z_L, Number* z_U, Index m,
+                          bool init_lambda, Number* lambda) override {
+    return rpm_get_starting_point(e0_, n, init_x, x, init_z, z_L, z_U, m, init_lambda, lambda) == RPM_OK;
+  }
+  bool eval_f(Index n, const Number* x, bool new_x, Number& obj_value) override {
+    return rpm_group_eval_f(g_, n, x, new_x, &obj_value) == RPM_OK;
+  }
+  bool eval_grad_f(Index n, const Number* x, bool new_x, Number* grad_f) override {
+    return rpm_group_eval_grad_f(g_, n, x, new_x, grad_f) == RPM_OK;
+  }
+  bool eval_g(Index n, const Number* x, bool new_x, Index m, Number* g) override {
+    return rpm_group_eval_g(g_, n, x, new_x, m, g) == RPM_OK;
+  }
+  bool eval_jac_g(Index n, const Number* x, bool new_x, Index m, Index nele_jac, Index* iRow, Index* jCol,
+                  Number* values) override {
+    return rpm_group_eval_jac_g(g_, n, x, new_x, m, nele_jac, iRow, jCol, values) == RPM_OK;
+  }
+  bool eval_h(Index n, const Number* x, bool new_x, Number obj_factor, Index m, const Number* lambda, bool new_lambda,
+              Index nele_hess, Index* iRow, Index* jCol, Number* values) override {
+    return rpm_group_eval_h(g_, n, x, new_x, obj_factor, m, lambda, new_lambda, nele_hess, iRow, jCol, values) == RPM_OK;
+  }
+  void finalize_solution(SolverReturn status, Index n, const Number* x, const Number* z_L, const Number* z_U, Index m,
+                         const Number* g, const Number* lambda, Number obj_value,
+                         const typename Base::IpoptData* /*ip_data*/,
+                         typename Base::IpoptCalculatedQuantities* /*ip_cq*/) override {
+    rpm_finalize_solution(e0_, int(status), n, x, z_L, z_U, m, g, lambda, obj_value);   // LpopcIpopt.cpp:220-246
+    // Ipopt's arrays may be freed before this object is: every engine lets go of them now; the next host-consumer call
+    // of the group registers whatever arrays it is handed then
+    rpm_group_set_option(g_, "pin_host", 0);
+  }
+  std::string last_error() const { return rpm_group_last_error(g_); }
+
+ private:
+  rpm_group* g_;
+  rpm_engine* e0_;
+};
+
 }  // namespace lpopc_amd

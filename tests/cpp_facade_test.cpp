@@ -90,5 +90,20 @@ int main() {
   int held = -1;
   if (rpm_get_option(eng, "pin_held", &held) != RPM_OK || held != 0) return 15;   // finalize released Ipopt's arrays
   rpm_destroy(eng);
+  // the same problem through a group of three engines (one process, several GPUs; here the same device three times)
+  {
+    const int devs[3] = {0, 0, 0};
+    rpm_group* grp = nullptr;
+    if (rpm_group_create(&optpro->Lower(), 3, devs, &grp) != RPM_OK || rpm_group_size(grp) != 3) return 20;
+    RpmGroupTNLPT<FakeTNLP> gnlp(grp);
+    int gn, gm, gnj, gnh;
+    if (!gnlp.get_nlp_info(gn, gm, gnj, gnh, st) || gn != n || gm != m || gnj != nj) return 21;
+    std::vector<int> gir(gnj), gjc(gnj);
+    if (!gnlp.eval_jac_g(gn, nullptr, false, gm, gnj, gir.data(), gjc.data(), nullptr) || gir != ir || gjc != jc) return 22;
+    const bool gok = gnlp.eval_g(gn, x.data(), true, gm, g.data());
+    std::printf("group eval_g -> %s%s%s\n", gok ? "true" : "false", gok ? "" : ": ", gok ? "" : gnlp.last_error().c_str());
+    gnlp.finalize_solution(0, gn, x.data(), nullptr, nullptr, gm, g.data(), g.data(), 1.5, nullptr, nullptr);
+    rpm_group_destroy(grp);
+  }
   return 0;
 }

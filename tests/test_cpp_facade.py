@@ -16,3 +16,4 @@ def test_cpp_facade_and_tnlp_adaptor(built, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "n=85 m=66 nnz_jac=1602" in r.stdout                 # SURVEY App. C, Bryson-Denham 1x20
     assert "eval_g -> true" in r.stdout or "no CPU fallback" in r.stdout
+    assert "group eval_g -> true" in r.stdout or ("group eval_g -> false" in r.stdout and "rank 0" in r.stdout)
