@@ -226,12 +226,15 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  * The reference hands the TNLP to Ipopt 3.12.3 (NLPSolver::SolveNlp, Core/LpNLPSolver.cpp:13-53: "tol" from the
  * Ipopt-tol option, hessian_approximation from the option list; Ipopt is a third-party dependency that is not in the
  * reference tree).  rpm_ipm restates Ipopt's published algorithm (Waechter & Biegler 2006: primal-dual barrier,
- * fraction-to-the-boundary rule, filter line search, inertia correction; monotone barrier update; a Gauss-Newton
- * feasibility restoration instead of Ipopt's l1 restoration NLP,
- * no second-order correction, no scaling) for the engine's n_instances independent NLPs at once — the MPC sweep —
- * with iterates, multipliers, the band + border KKT matrices and their LDL^T factors resident in HBM; per iteration
- * only three counters cross PCIe.  The engine must be created with hessian_approximation = exact; set the engine's
- * "instance_align" before rpm_ipm_create.
+ * fraction-to-the-boundary rule, filter line search with second-order correction, inertia correction, l1 restoration
+ * phase, monotone or adaptive barrier update; no NLP scaling, no watchdog, no quality-function oracle) for the engine's
+ * n_instances independent NLPs at once — the MPC sweep — with iterates, multipliers, the KKT matrices and their LDL^T
+ * factors resident in HBM; per iteration only a few counters cross PCIe.  The engine's hessian_approximation decides what
+ * stands for the Hessian of the Lagrangian: RPM_HESSIAN_EXACT = lpopc's finite-difference Hessian (rpm_eval_h);
+ * RPM_HESSIAN_LIMITED_MEMORY — lpopc's default, Core/LpNLPWrapper.hpp:71 — = Ipopt's limited-memory BFGS (history 6, scaling
+ * s'y / s's, its skipping rule; csrc/rpm_ipm_lbfgs.hip): the KKT matrix of a diagonal Hessian is factored and the low-rank
+ * part enters every solve through the Sherman-Morrison-Woodbury formula (12 more substitutions per iteration); also the only
+ * mode for problems with static parameters (nq > 0).  Set the engine's "instance_align" before rpm_ipm_create.
  *   rpm_ipm_set_option: "tol" (1e-8), "max_iter" (3000), "mu_init" (0.1), "bound_push", "bound_frac" (1e-2),
  *                       "delta_c" (1e-9, constraint regularisation that makes the pivot-free LDL^T well defined; keep it
  *                       well below bound_relax_factor),

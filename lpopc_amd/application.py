@@ -67,7 +67,7 @@ class ScipyNLPSolver:
 class DeviceIPMSolver:
     """NLPSolver::SolveNlp (Core/LpNLPSolver.cpp:13-53) on the device: rpm_ipm_* restates the interior-point algorithm of
     the Ipopt the reference calls (see include/rpm_hip.h, row f-2), with "tol" = the Ipopt-tol option exactly as the
-    reference passes it.  Needs hessian-approximation=exact (eval_h).  Its multipliers are the NLP's (lambda of the
+    reference passes it, and the engine's hessian-approximation (exact: eval_h; limited-memory: BFGS pairs).  Its multipliers are the NLP's (lambda of the
     primal-dual system), so costates and the Hamiltonian extracted from them are meaningful."""
 
     def __init__(self, tol=1e-6, maxiter=3000, retry_bound_relax=(1e-7, 1e-6), **solver_options):
@@ -151,10 +151,12 @@ class LpopcApplication:
             raise LpopcException("No optimal control problem has been set")
         if nlp_solver is not None:
             solver = nlp_solver
-        elif self.optionlist_.GetStringValue("hessian-approximation") == "exact":
-            solver = DeviceIPMSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))     # the whole solve stays on the device
         else:
-            solver = ScipyNLPSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))
+            # the whole solve stays on the device, with lpopc's exact (finite-difference) Hessian or — its default,
+            # Core/LpNLPWrapper.hpp:71 — Ipopt's limited-memory BFGS (csrc/rpm_ipm_lbfgs.hip).  ScipyNLPSolver remains for
+            # callers that ask for it (nlp_solver=ScipyNLPSolver(...)).
+            solver = DeviceIPMSolver(self.optionlist_.GetNumericValue("Ipopt-tol"))
+        self.last_solver = solver
         self.meshrefiner_ = MeshRefiner(self.optionlist_)
         if (self.optionlist_.GetStringValue("first-derive") == "analytic"
                 and self.optionlist_.GetStringValue("analytic-derive-check") == "yes"):

@@ -11,6 +11,8 @@ constexpr int IPM_W = 16;        // block width of the factorisation
 constexpr int IPM_FMAX = 1024;   // filter entries kept per instance (the filter empties whenever mu changes; a long Delta-III phase at one mu adds hundreds)
 constexpr int IPM_TRACE = 8;     // doubles per trace record: f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks
 constexpr double IPM_INF = 1e19; // Ipopt's nlp_lower_bound_inf / nlp_upper_bound_inf
+constexpr int IPM_LB_H = 6;      // limited-memory BFGS: Ipopt's limited_memory_max_history
+constexpr int IPM_LB_SMALL = 8 + 2 * (2 * IPM_LB_H) * (2 * IPM_LB_H) + 2 * (2 * IPM_LB_H);   // doubles of an instance's small record (rpm_ipm_lbfgs.hip)
 
 struct IpmOpts {
   double tol = 1e-8, mu_init = 0.1, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99;
@@ -109,6 +111,13 @@ struct IpmDev {
   int n_cg_long, n_cg2_long;             // leading corner-gather destinations with >= 32 sources (a wave each)
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
+  // hessian-approximation = limited-memory (rpm_ipm_lbfgs.hip): no Hessian entries, sigma on the diagonal of x, low-rank part by Woodbury
+  int lb_on;
+  double *lb_S, *lb_Y;        // B x IPM_LB_H x n pairs, oldest first
+  double *lb_xprev;           // B x n: the iterate the stored gradient / Jacobian belong to
+  double *lb_gold;            // B x nv: grad_x L(x_prev, lambda) with the CURRENT multipliers (first n of every row)
+  double *lb_small;           // B x IPM_LB_SMALL
+  double *lb_Z;               // 2 IPM_LB_H x B x Nt: K0^-1 E, column-major by column
 };
 
 constexpr int IPM_FILL_CHUNK = 2048;   // doubles of KKT storage one workgroup of ipm_fill_kernel zeroes and fills at a time
@@ -129,6 +138,13 @@ void ipm_launch_accept(const IpmDev& D, hipStream_t st);
 void ipm_launch_update(const IpmDev& D, hipStream_t st);
 void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st);          // right-hand side of the second-order correction
 void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st);    // its step and step lengths
+// limited-memory BFGS (rpm_ipm_lbfgs.hip)
+void lb_launch_reset(const IpmDev& D, hipStream_t st);
+void lb_launch_update(const IpmDev& D, hipStream_t st);               // after the residual kernel of an iteration
+void lb_launch_column(const IpmDev& D, int j, hipStream_t st);        // Z_j <- column j of E
+void lb_launch_small(const IpmDev& D, hipStream_t st);                // C = M - E'Z, LU
+void lb_launch_correct(const IpmDev& D, int check_status, hipStream_t st);   // Woodbury correction of the solution in D.rhs
+void ipm_launch_jt_lambda_into(const IpmDev& D, double* out, hipStream_t st);   // grad f + A'lambda of the running instances into out (B x nv)
 // factorisation / substitution of every running instance; tiles_per_wave 4 or IPM_MT
 size_t kkt_factor_lds_bytes(const IpmPlan& p);
 hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes);

@@ -411,7 +411,7 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   // mode 0: (13).  mode 2 (restoration, p and n eliminated): [[zeta D_R^2 + Sigma_v, A^T], [A, -(Sigma_p^-1 + Sigma_n^-1)]], no
   // Hessian (Gauss-Newton model).  mode 3 (least-squares multipliers): [[I, A^T], [A, -delta_c]].
   const int mode = S.mode;
-  if (mode == 0)   // duplicates of a slot (I-part / E-part of the reference's COO) are summed in COO order: bit-reproducible.  The
+  if (mode == 0 && !D.lb_on)   // duplicates of a slot (I-part / E-part of the reference's COO) are summed in COO order: bit-reproducible.  The
     for (int i = t0; i < D.n_hg; i += stride) {   // slot may also take the diagonal term below: two atomic adds onto zero commute
       double acc = 0.0;
       for (int j = D.hg_ptr[i]; j < D.hg_ptr[i + 1]; ++j) acc += D.hess[size_t(bi) * D.nnz_h + D.hg_src[j]];
@@ -431,6 +431,7 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
         r = (i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0) - zL[i] + zU[i];
       } else {
         diag = S.delta_w;
+        if (mode == 0 && D.lb_on && i < D.n) diag += D.lb_small[size_t(bi) * IPM_LB_SMALL];   // sigma I of the limited-memory Hessian
         r = D.glag[size_t(bi) * D.nv + i];
         if (mode == 2) {
           const double w2 = S.zeta * D.dr2[size_t(bi) * D.nv + i];
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
     // 0: a Hessian slot; 3: the diagonal of variable idx (with the Hessian slot that shares it)
     const int hgi = kind == 0 ? idx : D.as_hg[e];
     double acc = 0.0;
-    if (mode == 0 && hgi >= 0)
+    if (mode == 0 && hgi >= 0 && !D.lb_on)
       for (int j = D.hg_ptr[hgi]; j < D.hg_ptr[hgi + 1]; ++j) acc += D.hess[size_t(bi) * D.nnz_h + D.hg_src[j]];
     if (kind == 0) return 0.0 + acc;   // as the add onto the zeroed slot gave it (a sum of -0.0 becomes +0.0)
     const int i = idx;
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
         r = (i < D.n ? D.grad[size_t(bi) * D.n + i] : 0.0) - zL[i] + zU[i];
       } else {
         diag = delta_w;
+        if (mode == 0 && D.lb_on && i < D.n) diag += D.lb_small[size_t(bi) * IPM_LB_SMALL];   // sigma I of the limited-memory Hessian
         r = D.glag[size_t(bi) * D.nv + i];
         if (mode == 2) {
           const double w2 = zeta * D.dr2[size_t(bi) * D.nv + i];
@@ -1726,6 +1728,12 @@ void ipm_launch_residual(const IpmDev& D, hipStream_t st) {
   const int tb = (D.nv + 255) / 256;
   hipLaunchKernelGGL(ipm_jt_lambda_kernel, dim3(unsigned(tb + D.n_long), unsigned(D.B)), dim3(256), 0, st, D, tb);
   hipLaunchKernelGGL(ipm_residual_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
+}
+void ipm_launch_jt_lambda_into(const IpmDev& D, double* out, hipStream_t st) {
+  IpmDev D2 = D;
+  D2.glag = out;
+  const int tb = (D.nv + 255) / 256;
+  hipLaunchKernelGGL(ipm_jt_lambda_kernel, dim3(unsigned(tb + D.n_long), unsigned(D.B)), dim3(256), 0, st, D2, tb);
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
   if (D.as_nchunk > 0) {

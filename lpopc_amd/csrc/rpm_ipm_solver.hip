@@ -31,6 +31,8 @@ struct rpm_ipm {
   double factor_ms = 0.0, solve_ms = 0.0;
   bool solve_pending = false;
   bool attached = false;
+  bool lbfgs = false;            // hessian-approximation = limited-memory (rpm_ipm_lbfgs.hip)
+  int lb_iterations = 0;         // iterations of the running solve: an upper bound of the pairs any instance holds
   ~rpm_ipm() {
     if (attached && eng && eng->e.ipm_attached > 0) eng->e.ipm_attached -= 1;
     for (void* p : allocs) (void)hipFree(p);
@@ -93,10 +95,9 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   if (!eng || !out) return RPM_E_INVALID;
   *out = nullptr;
   Engine& e = eng->e;
-  if (e.hessian_mode != RPM_HESSIAN_EXACT) {
-    e.err = "rpm_ipm_create: the engine must be created with hessian-approximation=exact";
-    return RPM_E_UNSUPPORTED;
-  }
+  // hessian-approximation: exact = lpopc's finite-difference Hessian (rpm_eval_h); limited-memory = the reference's default
+  // (Core/LpNLPWrapper.hpp:71): Ipopt's limited-memory BFGS, restated in rpm_ipm_lbfgs.hip
+  const bool lbfgs = e.hessian_mode != RPM_HESSIAN_EXACT;
   if (e.shard_world > 1) {
     e.err = "rpm_ipm_create: interval-sharded engines are not supported (shard instances across ranks instead)";
     return RPM_E_UNSUPPORTED;
@@ -105,11 +106,12 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     int rc = device_init(e, 0);
     if (rc) return rc;
   }
-  int rc = ensure_hessian(e);
+  int rc = lbfgs ? RPM_OK : ensure_hessian(e);
   if (rc) return rc;
   rpm_ipm* h = new (std::nothrow) rpm_ipm;
   if (!h) return RPM_E_INVALID;
   h->eng = eng;
+  h->lbfgs = lbfgs;
   e.ipm_attached += 1;   // freezes the engine's instance strides (rpm_set_option "instance_align"); released by ~rpm_ipm
   h->attached = true;
   std::string why;
@@ -193,6 +195,14 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc(h, &D.inst, B)); A_(ipm_alloc(h, &D.cnt, size_t(4)));
   A_(ipm_alloc(h, &D.vR, B * p.nv)); A_(ipm_alloc(h, &D.dr2, B * p.nv));
   A_(ipm_alloc(h, &D.vl0, B * p.nv)); A_(ipm_alloc(h, &D.vu0, B * p.nv));
+  D.lb_on = lbfgs ? 1 : 0;
+  D.lb_S = D.lb_Y = D.lb_xprev = D.lb_gold = D.lb_small = D.lb_Z = nullptr;
+  if (lbfgs) {
+    A_(ipm_alloc(h, &D.lb_S, B * IPM_LB_H * p.n)); A_(ipm_alloc(h, &D.lb_Y, B * IPM_LB_H * p.n));
+    A_(ipm_alloc(h, &D.lb_xprev, B * p.n)); A_(ipm_alloc(h, &D.lb_gold, B * p.nv));
+    A_(ipm_alloc(h, &D.lb_small, B * IPM_LB_SMALL));
+    A_(ipm_alloc(h, &D.lb_Z, size_t(2 * IPM_LB_H) * B * size_t(p.Nt_alloc)));
+  }
   {   // restoration phase and second-order correction work space (m >= 1 keeps the allocations non-empty)
     const size_t Bm = B * size_t(std::max(p.m, 1));
     A_(ipm_alloc(h, &D.pp, Bm)); A_(ipm_alloc(h, &D.nn, Bm)); A_(ipm_alloc(h, &D.zp, Bm)); A_(ipm_alloc(h, &D.zn, Bm));
@@ -515,6 +525,8 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   const unsigned B = unsigned(D.B);
   auto eng_fail = [&](int rc) { h->err = e.err; return rc; };
   dev_forget_persistent(e);   // the first Jacobian evaluation of this solve writes the constant block of D.jac, the later ones skip it
+  if (h->lbfgs) lb_launch_reset(D, st);
+  h->lb_iterations = 0;
   h->total_factorizations = h->total_iterations = h->total_trials = h->total_soc = 0;
   h->factor_ms = h->solve_ms = 0.0;
   h->solve_pending = false;
@@ -544,10 +556,11 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
     if ((rc = dev_eval_cons(e, D.xe, D.g, D.jac, 3 | 4 | 16, st))) return eng_fail(rc);
     IPM_TRY(h, hipMemsetAsync(D.cnt, 0, 4 * sizeof(int), st));
     ipm_launch_residual(D, st);
+    if (h->lbfgs) lb_launch_update(D, st);     // the pair of the step just taken (grad_x L at the new point is in D.glag)
     if ((rc = fetch_counts(h, st))) return rc;
     if (h->h_cnt[0] == 0) break;
     h->total_iterations += 1;
-    if ((rc = dev_eval_h(e, D.xe, 1.0, D.lam, D.hess, st))) return eng_fail(rc);
+    if (!h->lbfgs && (rc = dev_eval_h(e, D.xe, 1.0, D.lam, D.hess, st))) return eng_fail(rc);
     for (int tries = 0; tries < 80; ++tries) {
       IPM_TRY(h, hipMemsetAsync(D.cnt + 1, 0, sizeof(int), st));
       ipm_launch_assemble(D, std::max(e.nnz_jac, e.nnz_h), st);
@@ -562,7 +575,20 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       if (h->h_cnt[1] == 0) break;
     }
     IPM_TRY(h, hipEventRecord(h->ev[2], st));
+    if (h->lbfgs && h->lb_iterations > 0) {
+      // Z = K0^-1 E with the factors in place: one substitution per column any instance can hold by now, then C = M - E'Z
+      const int hmax = std::min(IPM_LB_H, h->lb_iterations);
+      for (int a = 0; a < hmax; ++a)
+        for (int j : {a, IPM_LB_H + a}) {
+          lb_launch_column(D, j, st);
+          IpmDev Dj = D;
+          Dj.rhs = D.lb_Z + size_t(j) * D.B * D.Nt;
+          kkt_launch_solve(Dj, 1, st);
+        }
+      lb_launch_small(D, st);
+    }
     if ((rc = factor_and_solve_launch(h, st, false, true, 1))) return rc;
+    if (h->lbfgs) lb_launch_correct(D, 1, st);
     IPM_TRY(h, hipEventRecord(h->ev[3], st));
     h->solve_pending = true;
     IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, 2 * sizeof(int), st));
@@ -574,6 +600,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       if (h->h_cnt[3] > 0) {
         ipm_launch_soc_rhs(D, st);
         if ((rc = factor_and_solve_launch(h, st, false, true, 2))) return rc;
+        if (h->lbfgs) lb_launch_correct(D, 2, st);
         ipm_launch_soc_direction(D, st);
         h->total_soc += 1;
       }
@@ -592,6 +619,10 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       if (h->h_cnt[2] == 0 && h->h_cnt[3] == 0) break;
     }
     ipm_launch_update(D, st);
+    if (h->lbfgs) {
+      ipm_launch_jt_lambda_into(D, D.lb_gold, st);   // grad_x L(x_old, lambda_new): D.grad / D.jac still belong to the old iterate
+      h->lb_iterations += 1;
+    }
     if ((rc = launch_check(h, "ipm iteration"))) return rc;
   }
   // results: x back into the caller's array, multipliers, per-instance verdicts

@@ -516,8 +516,9 @@ class HpLiuRefiner:
 
 class BatchedIPM:
     """rpm_ipm_* : the NLP solve (the reference's NLPSolver::SolveNlp -> Ipopt, Core/LpNLPSolver.cpp:13-53) for all of an
-    engine's instances at once, iterates and KKT factors resident on the device.  The engine must have been created
-    with hessian-approximation=exact."""
+    engine's instances at once, iterates and KKT factors resident on the device.  The engine's hessian-approximation option
+    decides what stands for the Hessian: "exact" lpopc's finite-difference Hessian (rpm_eval_h), "limited-memory" (lpopc's
+    default) Ipopt's limited-memory BFGS."""
 
     STATUS = {0: "converged", 1: "converged to the acceptable level", 2: "iteration limit", 3: "line search and restoration phase failed",
               4: "inertia correction failed", 5: "NaN/Inf"}

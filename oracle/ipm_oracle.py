@@ -30,6 +30,13 @@ Restated in round 2 (what the metric problem, Delta-III, turned out to need — 
     monotone rule from mu = 0.8 * average complementarity until it is again); the filter is emptied whenever mu changes.
     Ipopt's default oracle there is the quality function (two more solves and a line search over sigma per iteration): not restated.
     The default because it is what the reference configures and the more robust rule on Delta-III.
+Restated in round 3: hessian_approximation = "limited-memory" — what the reference configures by default (Core/LpNLPWrapper.hpp:71,
+Core/LpNLPSolver.cpp:27-33), Ipopt's LimMemQuasiNewtonUpdater with its defaults: BFGS, limited_memory_max_history 6, the pair
+s = x+ - x, y = grad_x L(x+, lambda+) - grad_x L(x, lambda+) (x only; the slacks' Hessian block is zero), skipped when
+s'y <= sqrt(eps) |s| |y| (two skips in a row empty the memory), initial scaling "scalar1" sigma = s'y / s's in [1e-8, 1e8], and the
+compact representation B = sigma I - [sigma S  Y] [[sigma S'S, L], [L', -D]]^-1 [sigma S'; Y'] (Byrd, Nocedal, Schnabel 1994) in the
+place of the exact Hessian W.  B is positive definite, so the inertia is right without a correction.  The memory is emptied when
+the restoration phase returns.  Entries of y at fixed variables are dropped (their rows of the KKT matrix are identity rows).
 Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle, NLP scaling,
 least-squares multipliers at the very first iterate by default (option init_ls_multipliers; lambda_0 = 0 otherwise), watchdog.  One deviation:
 the constraint regularisation delta_c = 1e-9 is always on
@@ -54,6 +61,8 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 mu_strategy="adaptive", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
                 adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3,
                 init_ls_multipliers=0,                # 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
+                hessian_approximation="exact", limited_memory_max_history=6, limited_memory_max_skipping=2,
+                limited_memory_init_val_min=1e-8, limited_memory_init_val_max=1e8,
                 dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,                      # Ipopt's unscaled termination thresholds
                 acceptable_dual_inf_tol=1e10, acceptable_constr_viol_tol=1e-2, acceptable_compl_inf_tol=1e-2)
 
@@ -103,7 +112,9 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
     if x_l is not None:
         xl, xu = np.asarray(x_l, float), np.asarray(x_u, float)
     ji, jj = orc.jac_structure()
-    hi, hj = orc.hess_structure()
+    lbfgs = o["hessian_approximation"] == "limited-memory"
+    hi, hj = (np.zeros(0, dtype=int), np.zeros(0, dtype=int)) if lbfgs else orc.hess_structure()
+    lm = dict(S=[], Y=[], sigma=1.0, skipped=0, prev=None, updates=0, skips=0)
     ineq = np.nonzero(gl != gu)[0]
     ns, nv = ineq.size, n + ineq.size
     row_slack = -np.ones(m, dtype=int)
@@ -162,6 +173,46 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
 
     n_resto = n_acc = n_recalc = 0
     free_mode, refs, mu_max = True, [], None          # mu_strategy = adaptive
+
+    def lm_update(x_new, glag_x_new, lam_new):
+        """Ipopt's LimMemQuasiNewtonUpdater::UpdateHessian (BFGS): one pair per accepted step."""
+        if lm["prev"] is None:
+            return
+        x_old, grad_old, jv_old = lm["prev"]
+        g_old = grad_old.copy()
+        np.add.at(g_old, jj, jv_old * lam_new[ji])     # grad_x L(x_old, lambda_new): the SAME multipliers on both sides
+        s_, y_ = x_new - x_old, glag_x_new - g_old
+        y_ = np.where(free[:n], y_, 0.0)
+        sn, yn = np.linalg.norm(s_), np.linalg.norm(y_)
+        if sn == 0.0:
+            return                                      # lambda changed only (recalc_y): nothing to learn
+        sty = float(s_ @ y_)
+        if not (sty > np.sqrt(np.finfo(float).eps) * sn * yn):
+            lm["skips"] += 1
+            lm["skipped"] += 1
+            if lm["skipped"] >= o["limited_memory_max_skipping"]:
+                lm["S"], lm["Y"], lm["sigma"], lm["skipped"] = [], [], 1.0, 0
+            return
+        lm["skipped"] = 0
+        lm["S"].append(s_)
+        lm["Y"].append(y_)
+        if len(lm["S"]) > o["limited_memory_max_history"]:
+            lm["S"].pop(0)
+            lm["Y"].pop(0)
+        lm["sigma"] = min(o["limited_memory_init_val_max"], max(o["limited_memory_init_val_min"], sty / float(s_ @ s_)))
+        lm["updates"] += 1
+
+    def lm_matrix():
+        """B (n x n) from the compact representation."""
+        Bm = lm["sigma"] * np.eye(n)
+        if lm["S"]:
+            Sm, Ym = np.array(lm["S"]).T, np.array(lm["Y"]).T
+            SY = Sm.T @ Ym
+            Lm, Dm = np.tril(SY, -1), np.diag(np.diag(SY))
+            Mm = np.block([[lm["sigma"] * (Sm.T @ Sm), Lm], [Lm.T, -Dm]])
+            Q = np.hstack([lm["sigma"] * Sm, Ym])
+            Bm = Bm - Q @ np.linalg.solve(Mm, Q.T)
+        return Bm
 
     def ls_multipliers(xr, jR):
         """least-squares multipliers (section 3.6): [[I, A^T], [A, -delta_c]] [w; lambda] = -[grad f - zL + zU; 0]; 0 when they exceed mult_reset"""
@@ -299,6 +350,9 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         np.add.at(glag, jj, jv * lam[ji])
         glag[n:] = -lam[ineq]
         c = cons(v, g)
+        if lbfgs:
+            lm_update(x.copy(), glag[:n].copy(), lam)
+            lm["prev"] = (x.copy(), grad.copy(), jv.copy())
         dinf = np.max(np.abs((glag - zL + zU)[free])) if free.any() else 0.0
         cinf, theta = (np.max(np.abs(c)), np.abs(c).sum()) if m else (0.0, 0.0)
         prods = np.concatenate([zL[lo] * (v[lo] - vl[lo]), zU[up] * (vu[up] - v[up])])
@@ -361,10 +415,14 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
                 filt = []
         tau = max(o["tau_min"], 1.0 - mu)                                                         # (8)
         phi = f - mu * ln
-        hv = orc.eval_h(x, 1.0, lam)
         W = np.zeros((nv, nv))
-        np.add.at(W, (hi, hj), hv)
-        W = W + np.tril(W, -1).T
+        if lbfgs:
+            hv = np.zeros(0)
+            W[:n, :n] = lm_matrix()
+        else:
+            hv = orc.eval_h(x, 1.0, lam)
+            np.add.at(W, (hi, hj), hv)
+            W = W + np.tril(W, -1).T
         A = jac_dense(jv)
         dl, du = np.where(lo, v - vl, 1.0), np.where(up, vu - v, 1.0)
         sigma = np.where(lo, zL / dl, 0.0) + np.where(up, zU / du, 0.0)
@@ -467,6 +525,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
                 break
         if not accepted and status == 3 and o["resto"] and theta > o["tol"]:
             status = _restore()
+            lm.update(S=[], Y=[], sigma=1.0, skipped=0, prev=None)      # the point moved by another problem's steps
             if status is None:
                 continue
         elif not accepted and status == 3 and o["resto"] and n_recalc < o["max_recalc_y"]:
@@ -489,4 +548,4 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
                           smin=float(min(dl[lo].min(initial=1e300), du[up].min(initial=1e300)))))
         it += 1
     return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto,
-                multiplier_recalculations=n_recalc)
+                multiplier_recalculations=n_recalc, lm_updates=lm["updates"], lm_skips=lm["skips"])

@@ -392,11 +392,17 @@ def test_device_pointer_entry_and_limits(built):
         ipm.set_option("no-such-option", 1.0)
     ipm.close()
     eng.close()
-    # the solver needs eval_h: an engine without hessian-approximation=exact is refused, loudly
+    # an engine with lpopc's default hessian-approximation = limited-memory gets Ipopt's limited-memory BFGS in the place of
+    # eval_h (round 3, tests/test_ipm_limited_memory.py); an interval-sharded engine is refused, loudly
     lm = NLPEngine(prob, device=0)
-    with pytest.raises(RpmError):
-        BatchedIPM(lm)
+    s_lm = BatchedIPM(lm)
+    assert s_lm.info()["half_bandwidth"] > 0
+    s_lm.close()
     lm.close()
+    sh = NLPEngine(prob, shard_mode=1, shard_rank=0, shard_world=2, device=0)
+    with pytest.raises(RpmError):
+        BatchedIPM(sh)
+    sh.close()
 
 
 @pytest.mark.gpu

@@ -113,7 +113,8 @@ def test_application_loop_on_gpu_reaches_the_analytic_optimum(built, tmp_path):
     app.Options().SetIntegerValue("max-grid-num", 3)
     app.Options().SetIntegerValue("Nmax", 12)
     try:
-        finished = app.SolveOptimalProblem(result_dir=tmp_path)
+        from lpopc_amd.application import ScipyNLPSolver   # the stand-in this test is about (the default is the device solver now)
+        finished = app.SolveOptimalProblem(nlp_solver=ScipyNLPSolver(app.Options().GetNumericValue("Ipopt-tol")), result_dir=tmp_path)
     except LpopcException as e:
         finished = False
         assert "max number of refine grid" in str(e)
@@ -144,7 +145,8 @@ def test_application_loop_with_hp_liu_refinement(built):
     app.Options().SetIntegerValue("max-grid-num", 4)
     app.Options().SetIntegerValue("Nmax", 12)
     try:
-        app.SolveOptimalProblem()
+        from lpopc_amd.application import ScipyNLPSolver   # the stand-in this test was written around (the default is the device solver now)
+        app.SolveOptimalProblem(nlp_solver=ScipyNLPSolver(app.Options().GetNumericValue("Ipopt-tol")))
     except (LpopcException, RpmError):
         pass
     assert app.meshrefiner_.CurrentGrid() >= 1 and abs(app.objective - 4.0) < 1e-3
