@@ -396,6 +396,23 @@ def device_ipm_section(ctx, args):
                                  4, args.intervals, args.nodes)}
     ipm.close()
     eng.close()
+    # the same problem with lpopc's DEFAULT option hessian-approximation = limited-memory (Core/LpNLPWrapper.hpp:71): Ipopt's
+    # limited-memory BFGS on the device (csrc/rpm_ipm_lbfgs.hip), no Hessian evaluation, 12 more substitutions per iteration
+    try:
+        eng = NLPEngine(problems.launch(args.intervals, args.nodes), device=ctx.local_rank)
+        ipm = BatchedIPM(eng, max_iter=3000)
+        t0 = time.perf_counter()
+        r = ipm.solve(eng.get_starting_point()[None, :])
+        dt = time.perf_counter() - t0
+        st, info = ipm.stats(), ipm.info()
+        out["metric_problem_limited_memory"] = {
+            "solve_s": dt, "status": int(r["status"][0]), "iterations": int(r["iterations"][0]), "ms_per_ipm_iteration": 1e3 * dt / max(1, st["iterations"]),
+            "final_mass_kg": -float(r["obj"][0]) * 301454.0, "kkt_error": float(r["kkt_error"][0]), "factorizations": st["factorizations"],
+            "half_bandwidth": info["half_bandwidth"], "hessian": "limited-memory BFGS, history 6 (lpopc's default option)"}
+        ipm.close()
+        eng.close()
+    except Exception as ex:
+        out["metric_problem_limited_memory"] = {"error": repr(ex)}
     B = 1024
     prob = problems.quadrotor(8, 8)
     eng = NLPEngine(prob, o, n_instances=B, device=ctx.local_rank)

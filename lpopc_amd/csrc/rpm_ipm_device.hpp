@@ -112,6 +112,7 @@ struct IpmDev {
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
   // hessian-approximation = limited-memory (rpm_ipm_lbfgs.hip): no Hessian entries, sigma on the diagonal of x, low-rank part by Woodbury
+  int rhs_mult;               // kkt_launch_solve: right-hand sides per instance in `rhs` (0 / 1: one; j-th of instance bi at row j * B + bi)
   int lb_on;
   double *lb_S, *lb_Y;        // B x IPM_LB_H x n pairs, oldest first
   double *lb_xprev;           // B x n: the iterate the stored gradient / Jacobian belong to
@@ -141,7 +142,7 @@ void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st);    // its step a
 // limited-memory BFGS (rpm_ipm_lbfgs.hip)
 void lb_launch_reset(const IpmDev& D, hipStream_t st);
 void lb_launch_update(const IpmDev& D, hipStream_t st);               // after the residual kernel of an iteration
-void lb_launch_column(const IpmDev& D, int j, hipStream_t st);        // Z_j <- column j of E
+void lb_launch_columns_and_solve(const IpmDev& D, hipStream_t st);   // Z <- K0^-1 E, every column in one pass
 void lb_launch_small(const IpmDev& D, hipStream_t st);                // C = M - E'Z, LU
 void lb_launch_correct(const IpmDev& D, int check_status, hipStream_t st);   // Woodbury correction of the solution in D.rhs
 void ipm_launch_jt_lambda_into(const IpmDev& D, double* out, hipStream_t st);   // grad f + A'lambda of the running instances into out (B x nv)

@@ -1127,16 +1127,17 @@ hipError_t kkt_factor_dense_prepare(size_t lds_bytes) {
 template <bool RL>
 __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
                                                         const IpmInst* inst, double* rhs_all, long long rhs_stride, int check_status,
-                                                        int phase) {
+                                                        int phase, int kmod) {
   // phase 0: forward and backward over all blocks; nested dissection level 1: phase 1 = forward over the band blocks only
   // (the border work space receives -L_border y, this interval's contribution to the separator system's right-hand side),
   // phase 2 = backward over the band blocks only (the work space then holds the separator / border solution)
   constexpr int W = IPM_W;
-  const int bi = blockIdx.x / n_here, t = threadIdx.x, nt = blockDim.x;
-  if (check_status && (inst[bi].status != 0 || (check_status == 2 && !inst[bi].soc_req))) return;
+  // several right-hand sides per instance (IpmDev::rhs_mult): right-hand side bi belongs to instance bi % kmod
+  const int bi = blockIdx.x / n_here, bk = bi % kmod, t = threadIdx.x, nt = blockDim.x;
+  if (check_status && (inst[bk].status != 0 || (check_status == 2 && !inst[bk].soc_req))) return;
   const KktSub sub = subs[sub0 + int(blockIdx.x) % n_here];
   const KktGeom G = sub.g;
-  const double* K = Kall + size_t(bi) * kstride + sub.koff;
+  const double* K = Kall + size_t(bk) * kstride + sub.koff;
   double* rg = rhs_all + size_t(bi) * rhs_stride + sub.roff;
   extern __shared__ double rsh[];
   double* r = RL ? rsh : rg;
@@ -1787,9 +1788,9 @@ hipError_t kkt_factor_prepare(int tiles_per_wave, size_t lds_bytes) {
 // global border's corner entries collect one contribution from EVERY interval, 256 on the metric problem) take a wave each —
 // lanes stride the list, partial sums combined in a fixed butterfly order — the rest a thread each.
 __global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int* __restrict__ ptr, const int* __restrict__ src,
-                                      const int* __restrict__ dst, int n, const IpmInst* inst, int need_refactor, int n_long) {
-  const int bi = blockIdx.y;
-  if (inst[bi].status != 0 || (need_refactor && !inst[bi].refactor)) return;
+                                      const int* __restrict__ dst, int n, const IpmInst* inst, int need_refactor, int n_long, int kmod) {
+  const int bi = blockIdx.y, bk = bi % kmod;
+  if (inst[bk].status != 0 || (need_refactor && !inst[bk].refactor)) return;
   double* K = Kall + size_t(bi) * kstride;
   const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
   for (int i = wave; i < n_long; i += n_waves) {
@@ -1806,9 +1807,9 @@ __global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int
 }
 // mode 0: v[pos[i]] = 0;  mode 1: v[dst[i]] = v[src[i]]
 __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __restrict__ dst, const int* __restrict__ src, int n, int mode,
-                               const IpmInst* inst, int check_status) {
-  const int bi = blockIdx.y;
-  if (check_status && (inst[bi].status != 0 || (check_status == 2 && !inst[bi].soc_req))) return;
+                               const IpmInst* inst, int check_status, int kmod) {
+  const int bi = blockIdx.y, bk = bi % kmod;
+  if (check_status && (inst[bk].status != 0 || (check_status == 2 && !inst[bk].soc_req))) return;
   double* v = vall + size_t(bi) * vstride;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[dst[i]] = mode ? v[src[i]] : 0.0;
 }
@@ -1828,13 +1829,13 @@ static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partia
                        partial);
 }
 static void launch_solve_subs(const IpmDev& D, int sub0, int n_here, int phase, int check_status, hipStream_t st) {
-  const dim3 grid(unsigned(D.B) * unsigned(n_here));
+  const dim3 grid(unsigned(D.B) * unsigned(D.rhs_mult > 1 ? D.rhs_mult : 1) * unsigned(n_here));
   if (size_t(D.max_sub_nt) * sizeof(double) <= 48 * 1024)
     hipLaunchKernelGGL(kkt_solve_kernel<true>, grid, dim3(256), size_t(D.max_sub_nt) * sizeof(double), st, D.K, D.kstride, D.subs, sub0, n_here,
-                       D.inst, D.rhs, (long long)D.Nt, check_status, phase);
+                       D.inst, D.rhs, (long long)D.Nt, check_status, phase, D.B);
   else
     hipLaunchKernelGGL(kkt_solve_kernel<false>, grid, dim3(256), 0, st, D.K, D.kstride, D.subs, sub0, n_here, D.inst, D.rhs, (long long)D.Nt,
-                       check_status, phase);
+                       check_status, phase, D.B);
 }
 void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
   if (D.n_l1 == 0) {
@@ -1844,7 +1845,7 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
   auto corners = [&](const int* ptr, const int* src, const int* dst, int n, int n_long) {
     if (!n) return;
     const unsigned blocks = unsigned(std::max(1, std::min(1024, (n + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1, n_long);
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1, n_long, D.B);
   };
   if (D.l1_dense_lds)                                                                  // every interval up to its corner
     hipLaunchKernelGGL(kkt_factor_dense_kernel, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
@@ -1859,6 +1860,7 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
   launch_factor_subs(D, D.n_l1 + D.n_l2, 1, 0, tiles_per_wave, lds_bytes, st);        // last level: (group) separators + border
 }
 void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
+  const unsigned VB = unsigned(D.B) * unsigned(D.rhs_mult > 1 ? D.rhs_mult : 1);   // right-hand sides in D.rhs (rhs_mult per instance)
   if (D.n_l1 == 0) {
     launch_solve_subs(D, 0, 1, 0, check_status, st);
     return;
@@ -1866,13 +1868,13 @@ void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
   auto vec = [&](const int* dst, const int* src, int n, int mode) {
     if (!n) return;
     const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
-    hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, dst, src, n, mode, D.inst,
-                       check_status);
+    hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, VB), dim3(256), 0, st, D.rhs, (long long)D.Nt, dst, src, n, mode, D.inst,
+                       check_status, D.B);
   };
   auto gather = [&](const int* ptr, const int* src, const int* dst, int n) {
     if (!n) return;
     const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0, 0);
+    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, VB), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0, 0, D.B);
   };
   vec(D.gap_pos, nullptr, D.n_gap, 0);                                                 // border work spaces start at zero
   launch_solve_subs(D, 0, D.n_l1, 1, check_status, st);                                // forward, every interval

@@ -122,12 +122,12 @@ __global__ __launch_bounds__(1024) void lb_update_kernel(IpmDev D) {
   if (t == 0) rec[3] = 1.0;
 }
 
-// Z_j <- column j of E (Q at the positions of x, zero elsewhere), to be solved in place
-__global__ __launch_bounds__(1024) void lb_column_kernel(IpmDev D, int j, double* Zj) {
-  const int bi = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+// Z_j <- column j of E (Q at the positions of x, zero elsewhere), to be solved in place; blockIdx.x = column
+__global__ __launch_bounds__(1024) void lb_column_kernel(IpmDev D) {
+  const int bi = blockIdx.y, t = threadIdx.x, nt = blockDim.x, j = blockIdx.x;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
-  double* z = Zj + size_t(bi) * D.Nt;
+  double* z = D.lb_Z + (size_t(j) * D.B + bi) * D.Nt;
   for (int p = t; p < D.Nt; p += nt) z[p] = 0.0;
   const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
   const int c = int(rec[1]), a = j < IPM_LB_H ? j : j - IPM_LB_H;
@@ -244,8 +244,14 @@ void lb_launch_reset(const IpmDev& D, hipStream_t st) {
 void lb_launch_update(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(lb_update_kernel, dim3(1, unsigned(D.B)), dim3(D.n >= 4096 ? 1024 : 256), 0, st, D);
 }
-void lb_launch_column(const IpmDev& D, int j, hipStream_t st) {
-  hipLaunchKernelGGL(lb_column_kernel, dim3(1, unsigned(D.B)), dim3(D.Nt >= 4096 ? 1024 : 256), 0, st, D, j, D.lb_Z + size_t(j) * D.B * D.Nt);
+// Z = K0^-1 E: all 2 x history columns of every running instance in ONE pass of the substitution kernels (the columns of an
+// instance are right-hand sides j * B + bi of the same factors, IpmDev::rhs_mult)
+void lb_launch_columns_and_solve(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(lb_column_kernel, dim3(unsigned(2 * IPM_LB_H), unsigned(D.B)), dim3(D.Nt >= 4096 ? 1024 : 256), 0, st, D);
+  IpmDev Dz = D;
+  Dz.rhs = D.lb_Z;
+  Dz.rhs_mult = 2 * IPM_LB_H;
+  kkt_launch_solve(Dz, 1, st);
 }
 void lb_launch_small(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(lb_small_kernel, dim3(1, unsigned(D.B)), dim3(D.n >= 4096 ? 1024 : 256), 0, st, D);

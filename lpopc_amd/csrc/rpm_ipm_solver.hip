@@ -195,6 +195,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc(h, &D.inst, B)); A_(ipm_alloc(h, &D.cnt, size_t(4)));
   A_(ipm_alloc(h, &D.vR, B * p.nv)); A_(ipm_alloc(h, &D.dr2, B * p.nv));
   A_(ipm_alloc(h, &D.vl0, B * p.nv)); A_(ipm_alloc(h, &D.vu0, B * p.nv));
+  D.rhs_mult = 1;
   D.lb_on = lbfgs ? 1 : 0;
   D.lb_S = D.lb_Y = D.lb_xprev = D.lb_gold = D.lb_small = D.lb_Z = nullptr;
   if (lbfgs) {
@@ -576,15 +577,8 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
     }
     IPM_TRY(h, hipEventRecord(h->ev[2], st));
     if (h->lbfgs && h->lb_iterations > 0) {
-      // Z = K0^-1 E with the factors in place: one substitution per column any instance can hold by now, then C = M - E'Z
-      const int hmax = std::min(IPM_LB_H, h->lb_iterations);
-      for (int a = 0; a < hmax; ++a)
-        for (int j : {a, IPM_LB_H + a}) {
-          lb_launch_column(D, j, st);
-          IpmDev Dj = D;
-          Dj.rhs = D.lb_Z + size_t(j) * D.B * D.Nt;
-          kkt_launch_solve(Dj, 1, st);
-        }
+      // Z = K0^-1 E with the factors in place (all columns of all instances in one pass), then C = M - E'Z
+      lb_launch_columns_and_solve(D, st);
       lb_launch_small(D, st);
     }
     if ((rc = factor_and_solve_launch(h, st, false, true, 1))) return rc;
