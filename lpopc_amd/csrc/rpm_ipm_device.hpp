@@ -32,6 +32,8 @@ struct IpmOpts {
   double mu_max_fact = 1e3, mu_red_fact = 0.9999, mu_init_factor = 0.8;
   double sigma_cap = 0.0;            // experiment: cap z/s in the KKT matrix (0 = off)
   int init_ls_mult = 0;              // 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
+  int ic_hot = 0;                    // 1: an iteration whose predecessor needed delta_w > 0 starts Algorithm IC at kw_dec * delta_w_last instead of 0
+  double ic_hot_min = 1e-10;         //    (not Ipopt: saves the factorisation that fails at 0) as long as that value is at least this
   // Ipopt's unscaled termination thresholds, required beside the scaled E_0 <= tol (resp. acceptable_tol)
   double dual_inf_tol = 1.0, constr_viol_tol = 1e-4, compl_inf_tol = 1e-4;
   double acc_dual_inf_tol = 1e10, acc_constr_viol_tol = 1e-2, acc_compl_inf_tol = 1e-2;
@@ -50,7 +52,7 @@ struct IpmInst {
   double alpha_soc, az_soc, th_old_soc;
   double mu_max, refs[4];            // adaptive barrier update: upper bound of mu, KKT errors of the last accepted iterates
   int fixed_mode, nrefs;             // 0 = free mode (mu from the oracle every iteration), 1 = monotone rule until progress resumes
-  int n_recalc, pad3;                // least-squares multipliers recomputed after a line search that failed at a feasible point (at most 3 times)
+  int n_recalc, ic_hot;               // least-squares multipliers recomputed after a line search that failed at a feasible point (at most 3 times)
   long long dbg[8];   // phase clocks of the factorisation (builds with -DIPM_TIMING only)
 };
 
@@ -111,6 +113,15 @@ struct IpmDev {
   int n_cg_long, n_cg2_long;             // leading corner-gather destinations with >= 32 sources (a wave each)
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
+  // df_on: that kernel builds its interval block from the Jacobian / Hessian / diagonal terms itself instead of reading what
+  // ipm_fill_kernel wrote (which then skips the chunks of the storage that lie inside level-1 blocks, as_skip[c] = 1): the structural
+  // slots of level-1 sub-problem s are df_ki / df_hg [df_ptr[3 s], df_ptr[3 s + 3]) (coded like as_ki / as_hg; Jacobian entries from
+  // df_ptr[3 s], Hessian slots from df_ptr[3 s + 1], slack entries and diagonals from df_ptr[3 s + 2]), and lane l of register tile t
+  // holds the entries numbered df_map[(s * IPM_DENSE_TILES + t) * 64 + l] (four 16-bit numbers, 1-based into that list, 0 = a
+  // structural zero)
+  int df_on;
+  const int *df_ptr, *df_ki, *df_hg, *as_skip;
+  const unsigned long long* df_map;
   // hessian-approximation = limited-memory (rpm_ipm_lbfgs.hip): no Hessian entries, sigma on the diagonal of x, low-rank part by Woodbury
   int rhs_mult;               // kkt_launch_solve: right-hand sides per instance in `rhs` (0 / 1: one; j-th of instance bi at row j * B + bi)
   int lb_on;
@@ -121,6 +132,8 @@ struct IpmDev {
   double *lb_Z;               // 2 IPM_LB_H x B x Nt: K0^-1 E, column-major by column
 };
 
+constexpr int IPM_DENSE_SLOTS = 22, IPM_DENSE_TILE_WAVES = 7, IPM_DENSE_LDS_ROW = 18;   // kkt_factor_dense_kernel: tiles per wave, tile waves, doubles per LDS row
+constexpr int IPM_DENSE_TILES = IPM_DENSE_SLOTS * IPM_DENSE_TILE_WAVES;
 constexpr int IPM_FILL_CHUNK = 2048;   // doubles of KKT storage one workgroup of ipm_fill_kernel zeroes and fills at a time
 constexpr int IPM_VEC_BLOCKS = 64;   // most workgroups per instance of a vector kernel
 constexpr int IPM_VEC_PART = 24;     // doubles of partial results per workgroup

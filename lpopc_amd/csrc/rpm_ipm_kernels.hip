@@ -387,6 +387,7 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   S.phi = S.f - mu * ln;
   S.refactor = 1;
   S.delta_w = 0.0;
+  if (o.ic_hot && S.ic_hot && o.kw_dec * S.delta_w_last >= o.ic_hot_min) S.delta_w = o.kw_dec * S.delta_w_last;
   atomicAdd(&D.cnt[0], 1);
 }
 
@@ -461,27 +462,28 @@ __global__ void ipm_assemble_kernel(IpmDev D) {
   }
 }
 
-// ipm_zero_kernel + ipm_assemble_kernel in one pass over the storage, by destination: a workgroup builds a chunk of the
-// storage in LDS (zeros, then the chunk's structural slots, as_* tables in ascending order) and writes it out in full lines,
-// so every line of the storage leaves the chip once per refactorisation instead of being zeroed, fetched again for a
-// scattered read-modify-write and written a second time (1024-instance quadrotor sweep: 0.59 + 0.72 ms per iteration for the
-// two kernels).  Same values, bit for bit: a slot that took two atomic adds onto zero (Hessian sum, diagonal term) gets their sum.
-__global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
-  __shared__ double buf[IPM_FILL_CHUNK];
-  const int bi = blockIdx.y;
-  const IpmInst& S = D.inst[bi];
-  if (S.status != 0 || !S.refactor) return;
-  double* K = D.K + size_t(bi) * D.kstride;
-  const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
-  const double *zL = D.zL + size_t(bi) * D.nv, *zU = D.zU + size_t(bi) * D.nv;
-  double* rhs = D.rhs + size_t(bi) * D.Nt;
-  const int mode = S.mode;
-  const double mu = mode == 2 ? S.mu_r : S.mu;
-  const double delta_w = S.delta_w, zeta = S.zeta;
-  const int tid = threadIdx.x;
-  // the value of structural slot e (and, for a diagonal slot, the right-hand side entry that goes with it)
-  auto value_of = [&](int e) -> double {
-    const int ki = D.as_ki[e], kind = ki >> 28, idx = ki & 0x0fffffff;
+// The value of a structural slot of instance bi's KKT matrix in its present mode (ki / hg coded as IpmDev::as_ki / as_hg) and, for
+// a diagonal slot, the right-hand side entry that goes with it (written on the way).  Same values as ipm_assemble_kernel's, bit
+// for bit: a slot that took two atomic adds onto zero there (Hessian sum, diagonal term) gets their sum.
+struct SlotValue {
+  const IpmDev& D;
+  int bi, mode;
+  double mu, delta_w, zeta;
+  const double *v, *vl, *vu, *zL, *zU;
+  double* rhs;
+  __device__ SlotValue(const IpmDev& D_, int bi_) : D(D_), bi(bi_) {
+    const IpmInst& S = D.inst[bi];
+    mode = S.mode;
+    mu = mode == 2 ? S.mu_r : S.mu;
+    delta_w = S.delta_w;
+    zeta = S.zeta;
+    v = D.v + size_t(bi) * D.nv; vl = D.vl + size_t(bi) * D.nv; vu = D.vu + size_t(bi) * D.nv;
+    zL = D.zL + size_t(bi) * D.nv; zU = D.zU + size_t(bi) * D.nv;
+    rhs = D.rhs + size_t(bi) * D.Nt;
+  }
+  // entry e of the tables ki_tab / hg_tab (the Hessian slot that shares a diagonal is looked up only for a diagonal)
+  __device__ double operator()(const int* ki_tab, const int* hg_tab, int e) const {
+    const int ki = ki_tab[e], kind = ki >> 28, idx = ki & 0x0fffffff;
     if (kind == 1) return D.jac[size_t(bi) * D.sv + idx];
     if (kind == 2) return -1.0;
     if (kind == 4) {   // diagonal of constraint row idx
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
       return k22;
     }
     // 0: a Hessian slot; 3: the diagonal of variable idx (with the Hessian slot that shares it)
-    const int hgi = kind == 0 ? idx : D.as_hg[e];
+    const int hgi = kind == 0 ? idx : hg_tab[e];
     double acc = 0.0;
     if (mode == 0 && hgi >= 0 && !D.lb_on)
       for (int j = D.hg_ptr[hgi]; j < D.hg_ptr[hgi + 1]; ++j) acc += D.hess[size_t(bi) * D.nnz_h + D.hg_src[j]];
@@ -527,20 +529,37 @@ __global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
     rhs[D.pos[i]] = -r;
     // the two-kernel path adds the two terms onto zero, in either order: acc + diag, exactly
     return (mode == 0 && hgi >= 0) ? acc + diag : diag;
-  };
+  }
+};
+
+// ipm_zero_kernel + ipm_assemble_kernel in one pass over the storage, by destination: a workgroup builds a chunk of the
+// storage in LDS (zeros, then the chunk's structural slots, as_* tables in ascending order) and writes it out in full lines,
+// so every line of the storage leaves the chip once per refactorisation instead of being zeroed, fetched again for a
+// scattered read-modify-write and written a second time (1024-instance quadrotor sweep: 0.59 + 0.72 ms per iteration for the
+// two kernels).  Chunks inside a level-1 block that kkt_factor_dense_kernel assembles itself (IpmDev::df_on) are left out.
+__global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
+  __shared__ double buf[IPM_FILL_CHUNK];
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || !S.refactor) return;
+  double* K = D.K + size_t(bi) * D.kstride;
+  const int tid = threadIdx.x;
+  const SlotValue value(D, bi);
+  const bool skipping = D.df_on && D.l1_dense_lds && D.as_skip;
   for (int c = blockIdx.x; c < D.as_nchunk; c += gridDim.x) {
+    if (skipping && D.as_skip[c]) continue;
     const long long lo = (long long)c * IPM_FILL_CHUNK, hi = min(lo + IPM_FILL_CHUNK, D.kstride);
     const int e0 = D.as_ptr[c], e1 = D.as_ptr[c + 1];
     // this thread's first slot: its loads are under way while the chunk is zeroed
     const int ef = e0 + tid;
     double val_f = 0.0;
     int off_f = -1;
-    if (ef < e1) { off_f = int(D.as_dst[ef] - lo); val_f = value_of(ef); }
+    if (ef < e1) { off_f = int(D.as_dst[ef] - lo); val_f = value(D.as_ki, D.as_hg, ef); }
     double2* b2 = reinterpret_cast<double2*>(buf);
     for (int i = tid; i < IPM_FILL_CHUNK / 2; i += 256) b2[i] = make_double2(0.0, 0.0);
     __syncthreads();
     if (off_f >= 0) buf[off_f] = val_f;
-    for (int e = ef + 256; e < e1; e += 256) buf[D.as_dst[e] - lo] = value_of(e);
+    for (int e = ef + 256; e < e1; e += 256) buf[D.as_dst[e] - lo] = value(D.as_ki, D.as_hg, e);
     __syncthreads();
     const int len = int(hi - lo);
     if ((reinterpret_cast<size_t>(K + lo) & 15) == 0) {
@@ -878,9 +897,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 // block ~12 times from the L2 / Infinity Cache, a 16-column step every 25 us.  Same products in the same order, so the factors
 // are the left-looking kernel's bit for bit.  Partial elimination only (the band part; the border x border corner is handed
 // on as the Schur complement).
-constexpr int IPM_DENSE_SLOTS = 22, IPM_DENSE_TILE_WAVES = 7, IPM_DENSE_LDS_ROW = 18;
 __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
-                                                                  int n_sub, IpmInst* inst, int* piv) {
+                                                                  int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W, NWV = IPM_DENSE_TILE_WAVES, MAXS = IPM_DENSE_SLOTS;
   // the barriers of this kernel order LDS traffic only: __syncthreads() would also wait for the stores of L into the storage
@@ -906,6 +924,36 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = t & 15, lq = (t & 63) >> 4;
   auto row0 = [&](int I) { return I < nbb ? W * I : G.Nb + W * (I - nbb); };
   auto rend = [&](int I) { return I < nbb ? G.Nb : G.Nt; };
+  // assemble: the block is built here, not read — the values of its structural slots (a few per cent of the storage) go to LDS
+  // (the panel's space, free until the first block column is solved), number 0 being a structural zero; every tile lane then picks
+  // its four entries by number (df_map).  The right-hand side entries that go with the diagonal slots are written on the way.
+  double* vals = BL;
+  unsigned long long mp[MAXS];     // a tile wave's lanes: the numbers of the entries they hold, on their way while the values are fetched
+  if (assemble) {
+    if (wv != NWV) {
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) mp[s] = D.df_map[(size_t(sidx) * IPM_DENSE_TILES + wv + NWV * s) * 64 + lane];
+    }
+    const int ea = D.df_ptr[3 * sidx], eb = D.df_ptr[3 * sidx + 1], ec = D.df_ptr[3 * sidx + 2], ed = D.df_ptr[3 * sidx + 3];
+    const SlotValue value(D, bi);
+    if (t == 0) vals[0] = 0.0;
+    const double* jac = D.jac + size_t(bi) * D.sv;
+#pragma unroll 4
+    for (int e = ea + t; e < eb; e += 512) vals[1 + e - ea] = jac[D.df_ki[e] & 0x0fffffff];
+    const bool with_h = value.mode == 0 && !D.lb_on;
+    const double* hess = D.hess + size_t(bi) * D.nnz_h;
+#pragma unroll 2
+    for (int e = eb + t; e < ec; e += 512) {
+      double a = 0.0;
+      if (with_h) {
+        const int hgi = D.df_ki[e] & 0x0fffffff;
+        for (int j = D.hg_ptr[hgi]; j < D.hg_ptr[hgi + 1]; ++j) a += hess[D.hg_src[j]];
+      }
+      vals[1 + e - ea] = 0.0 + a;
+    }
+    for (int e = ec + t; e < ed; e += 512) vals[1 + e - ea] = value(D.df_ki, D.df_hg, e);
+    __syncthreads();
+  }
   if (wv == NWV) {
     // ---------------- the eighth wave holds no tiles: it factors the diagonal blocks (its registers are free for that) ----------------
     __builtin_amdgcn_s_setprio(3);   // the chain of diagonal blocks is the critical path: this wave goes first on its SIMD
@@ -998,6 +1046,11 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     const int I = have ? Kb + (tl - colstart(Kb)) : 0;
     Kb = have ? Kb : 0;
     sIK[s] = __builtin_amdgcn_readfirstlane(I << 8 | Kb);
+    if (assemble) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[s][g] = vals[(mp[s] >> (16 * g)) & 0xffff];
+      continue;
+    }
     const int r = row0(I) + lr;
     const bool rv = have && r < rend(I), border = r >= G.Nb;
 #pragma unroll
@@ -1254,6 +1307,7 @@ __global__ void ipm_inertia_kernel(IpmDev D) {
   if (S.npos == D.nv && S.nbad == 0) {
     S.refactor = 0;
     if (S.delta_w > 0) S.delta_w_last = S.delta_w;
+    if (S.mode == 0) S.ic_hot = S.delta_w > 0;
     return;
   }
   if (S.delta_w == 0.0) S.delta_w = S.delta_w_last == 0.0 ? o.delta_w_first : fmax(o.delta_w_min, o.kw_dec * S.delta_w_last);
@@ -1849,7 +1903,7 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
   };
   if (D.l1_dense_lds)                                                                  // every interval up to its corner
     hipLaunchKernelGGL(kkt_factor_dense_kernel, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
-                       D.n_l1, D.n_sub, D.inst, D.piv);
+                       D.n_l1, D.n_sub, D.inst, D.piv, D, D.df_on && D.df_map ? 1 : 0);
   else
     launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);
   corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg, D.n_cg_long);

@@ -139,9 +139,9 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc_c(h, &D.jt_ent, p.jt_ent)); A_(ipm_alloc_c(h, &D.jt_row, p.jt_row));
   A_(ipm_alloc_c(h, &D.hg_ptr, p.hg_ptr)); A_(ipm_alloc_c(h, &D.hg_src, p.hg_src)); A_(ipm_alloc_c(h, &D.hg_dst, p.hg_dst));
   D.n_hg = int(p.hg_dst.size());
-  {   // the structural slots in ascending order, for the one-pass fill (ipm_fill_kernel)
-    struct Ent { int dst, ki, hg; };
-    std::vector<Ent> ents;
+  struct Ent { int dst, ki, hg; };
+  std::vector<Ent> ents;      // the structural slots in ascending order
+  {   // ... for the one-pass fill (ipm_fill_kernel)
     ents.reserve(p.hg_dst.size() + p.jac_dst.size() + p.slk_dst.size() + p.diag_dst.size());
     std::unordered_map<int, int> var_of_slot;
     for (int i = 0; i < p.nv; ++i) var_of_slot.emplace(p.diag_dst[size_t(i)], i);
@@ -237,6 +237,56 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
       }
       if (!(std::getenv("RPM_IPM_DENSE") && std::atoi(std::getenv("RPM_IPM_DENSE")) == 0)) D.l1_dense_lds = h->l1_dense_lds;   // option "level1_dense"
     }
+    // level 1 assembled by kkt_factor_dense_kernel itself (IpmDev::df_on): per interval block the list of its structural slots and,
+    // per register tile lane, which of them it holds; the fill leaves out the chunks that lie inside such a block
+    D.df_on = 0;
+    D.df_ptr = D.df_ki = D.df_hg = D.as_skip = nullptr;
+    D.df_map = nullptr;
+    if (h->l1_dense_lds && D.as_nchunk > 0 && !(std::getenv("RPM_IPM_FUSED_FILL") && std::atoi(std::getenv("RPM_IPM_FUSED_FILL")) == 0)) {
+      // per block the Jacobian entries first, then the Hessian slots, then the rest (slack entries, diagonals): three plain loops in the kernel
+      std::vector<int> f_ptr(3 * size_t(D.n_l1) + 1, 0), f_ki, f_hg, skip(size_t(D.as_nchunk), 0);
+      std::vector<unsigned long long> f_map(size_t(D.n_l1) * IPM_DENSE_TILES * 64, 0ull);
+      bool ok = true;
+      size_t e2 = 0;
+      for (int si = 0; si < D.n_l1 && ok; ++si) {
+        const KktGeom g = subs[size_t(si)].g;
+        const long long k0 = subs[size_t(si)].koff, k1 = k0 + (long long)g.Nt * g.CS;
+        const int nbb = (g.Nb + IPM_W - 1) / IPM_W, nbr = (g.nb + IPM_W - 1) / IPM_W, NTB = nbb + nbr;
+        while (e2 < ents.size() && ents[e2].dst < k0) ++e2;     // (level-1 blocks come first in the storage, in order)
+        size_t e3 = e2;
+        while (e3 < ents.size() && ents[e3].dst < k1) ++e3;
+        int number = 0;
+        for (int cls = 0; cls < 3 && ok; ++cls) {
+          f_ptr[3 * size_t(si) + size_t(cls)] = int(f_ki.size());
+          for (size_t q = e2; q < e3; ++q) {
+            const int kind = ents[q].ki >> 28;
+            if ((kind == 1 ? 0 : (kind == 0 ? 1 : 2)) != cls) continue;
+            const long long o = ents[q].dst - k0;
+            const int j = int(o / g.CS), slot = int(o % g.CS);
+            const int i = (j < g.Nb && slot <= g.b) ? j + slot : g.Nb + slot - (g.b + 1);
+            const bool band = i < g.Nb;
+            if (i < j || i >= g.Nt || (band && (j >= g.Nb || i - j > g.b)) || (long long)j * g.CS + (band ? i - j : g.b + 1 + i - g.Nb) != o) { ok = false; break; }
+            const int I = band ? i / IPM_W : nbb + (i - g.Nb) / IPM_W, Kb = j < g.Nb ? j / IPM_W : nbb + (j - g.Nb) / IPM_W;
+            const int lr = i - (I < nbb ? IPM_W * I : g.Nb + IPM_W * (I - nbb)), cc = j - (Kb < nbb ? IPM_W * Kb : g.Nb + IPM_W * (Kb - nbb));
+            const int tile = Kb * NTB - Kb * (Kb - 1) / 2 + I - Kb;
+            if (tile >= IPM_DENSE_TILES || ++number > 0xffff) { ok = false; break; }
+            f_map[(size_t(si) * IPM_DENSE_TILES + tile) * 64 + size_t((cc & 3) * 16 + lr)] |= (unsigned long long)number << (16 * (cc >> 2));
+            f_ki.push_back(ents[q].ki);
+            f_hg.push_back(ents[q].hg);
+          }
+        }
+        e2 = e3;
+        // the values wait in the panel's LDS space (2 x block rows x 16 rows of IPM_DENSE_LDS_ROW doubles), slot 0 is the zero
+        ok = ok && size_t(number) + 1 <= 2 * size_t(NTB) * IPM_W * IPM_DENSE_LDS_ROW;
+        for (long long c = (k0 + IPM_FILL_CHUNK - 1) / IPM_FILL_CHUNK; ok && (c + 1) * IPM_FILL_CHUNK <= k1; ++c) skip[size_t(c)] = 1;
+      }
+      f_ptr[3 * size_t(D.n_l1)] = int(f_ki.size());
+      if (ok) {
+        A_(ipm_alloc_c(h, &D.df_ptr, f_ptr)); A_(ipm_alloc_c(h, &D.df_ki, f_ki)); A_(ipm_alloc_c(h, &D.df_hg, f_hg));
+        A_(ipm_alloc_c(h, &D.as_skip, skip)); A_(ipm_alloc_c(h, &D.df_map, f_map));
+        D.df_on = 1;
+      }
+    }
     A_(ipm_alloc_c(h, &D.subs, subs));
     A_(ipm_alloc(h, &D.piv, B * subs.size() * 3));
     A_(ipm_alloc_c(h, &D.cg_ptr, p.cg_ptr)); A_(ipm_alloc_c(h, &D.cg_src, p.cg_src)); A_(ipm_alloc_c(h, &D.cg_dst, p.cg_dst));
@@ -302,6 +352,8 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "max_soc") o.max_soc = std::max(0, int(value));
   else if (k == "sigma_cap") o.sigma_cap = value;      // experiment
   else if (k == "init_ls_multipliers") o.init_ls_mult = value != 0.0;
+  else if (k == "ic_hot_start") o.ic_hot = value != 0.0;
+  else if (k == "ic_hot_min") o.ic_hot_min = value;
   else if (k == "mu_strategy") {       // 0 monotone (default), 1 adaptive: LOQO oracle + kkt-error globalisation
     if (value != 0.0 && value != 1.0) { h->err = "mu_strategy: 0 (monotone) or 1 (adaptive)"; return RPM_E_INVALID; }
     o.mu_adaptive = int(value);
@@ -310,6 +362,10 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "level1_dense") {   // level 1 of the nested dissection on kkt_factor_dense_kernel (default where the interval blocks fit it)
     if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 17 block rows"; return RPM_E_UNSUPPORTED; }
     h->D.l1_dense_lds = value != 0.0 ? h->l1_dense_lds : 0;
+  }
+  else if (k == "fused_fill") {     // level-1 blocks assembled inside kkt_factor_dense_kernel (default where that kernel runs and the tables exist)
+    if (value != 0.0 && !h->D.df_map) { h->err = "fused_fill: level 1 does not run on kkt_factor_dense_kernel"; return RPM_E_UNSUPPORTED; }
+    h->D.df_on = value != 0.0;
   }
   else if (k == "trace") {          // keep the first `value` iterations of every instance (rpm_ipm_get_trace)
     const int cap = int(value);
@@ -488,7 +544,10 @@ int rpm_ipm_debug_solve_dense(rpm_ipm* h, const double* k_dense, const double* r
   IPM_TRY(h, hipMemcpy(D.inst, inst.data(), inst.size() * sizeof(IpmInst), hipMemcpyHostToDevice));
   IPM_TRY(h, hipMemcpy(D.K, store.data(), store.size() * sizeof(double), hipMemcpyHostToDevice));
   IPM_TRY(h, hipMemcpy(D.rhs, r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice));
+  const int df_keep = D.df_on;
+  D.df_on = 0;                 // factor what is in the storage, not the solver's own matrix
   int rc = factor_and_solve_launch(h, st, true, true, 0);
+  D.df_on = df_keep;
   if (rc) return rc;
   ipm_launch_inertia(D, st);
   IPM_TRY(h, hipStreamSynchronize(st));

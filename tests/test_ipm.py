@@ -231,6 +231,53 @@ def test_register_resident_level_1_equals_the_left_looking_kernel(built, name, m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hessian", ["exact", "limited-memory"])
+def test_level_1_assembled_in_the_factor_kernel_changes_nothing(built, hessian):
+    """Option fused_fill (default where kkt_factor_dense_kernel runs): the interval blocks are built from the Jacobian, Hessian
+    and diagonal terms inside the factorisation kernel and the fill leaves their storage alone.  Same matrix entries, same products:
+    every instance of a sweep (regular iterations, inertia corrections, second-order corrections, per-instance bounds) takes the
+    same path and ends at the same point, bit for bit, as with the fill kernel writing the whole storage."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine, RpmError
+    from lpopc_amd.problem import Options
+    B = 5
+    prob = problems.quadrotor(8, 8)
+    o = Options()
+    o.SetStringValue("hessian-approximation", hessian)
+    out = []
+    for fused in (1, 0):
+        eng = NLPEngine(prob, o, n_instances=B, device=0)
+        eng.set_option("ipm_nested", 1)
+        ipm = BatchedIPM(eng, max_iter=300, trace=300)
+        ipm.set_option("fused_fill", fused)        # 1 is the default here; it must be accepted
+        xl, xu, _, _ = eng.get_bounds_info()
+        rng = np.random.RandomState(11)
+        N1 = 8 * 8 + 1
+        for bi in range(B):
+            l, u = xl.copy(), xu.copy()
+            l[[i * N1 for i in range(12)]] = u[[i * N1 for i in range(12)]] = rng.uniform(-0.4, 0.4, 12)
+            ipm.set_bounds(bi, l, u)
+        x0 = np.tile(eng.get_starting_point(), (B, 1))
+        r = ipm.solve(x0)
+        out.append((r, [ipm.trace(bi).copy() for bi in range(B)], ipm.stats()))
+        ipm.close()
+        eng.close()
+    (a, ta, sa), (b, tb, sb) = out
+    if hessian == "exact":                         # (the limited-memory runs of this sweep end at the acceptable level or in a failed
+        assert (a["status"] == 0).all()            #  line search: paths long enough to show any difference all the same)
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iterations"], b["iterations"])
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["obj"], b["obj"])
+    assert all(np.array_equal(p, q) for p, q in zip(ta, tb))
+    assert sa["factorizations"] == sb["factorizations"]
+    band = NLPEngine(problems.quadrotor(2, 4), o, n_instances=1, device=0)
+    band.set_option("ipm_nested", 0)
+    ipm = BatchedIPM(band)
+    with pytest.raises(RpmError):
+        ipm.set_option("fused_fill", 1)            # no level 1, no register-resident kernel
+    ipm.close()
+    band.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,make,B,pert", [("bryson_denham", lambda: problems.bryson_denham(2, 8), 2, 0.0),
                                              ("hypersensitive", lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0), 2, 0.0),
                                              ("quadrotor_3x6", lambda: problems.quadrotor(3, 6, pref=(0.4, 0.8, -0.6)), 3, 2e-2),
