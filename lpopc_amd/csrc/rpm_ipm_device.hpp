@@ -169,6 +169,8 @@ hipError_t kkt_factor_dense_prepare(size_t lds_bytes);
 // corner gather -> level 2 and forward -> gather -> level 2 -> scatter -> backward with nested dissection
 void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hipStream_t st);
 // check_status: 0 every instance, 1 the running ones, 2 the running ones that asked for a second-order correction
-void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st);
+// forward_done: D.rhs is the right-hand side the factorisation just ran over (kkt_level1_fused: its level-1 forward sweep is done)
+void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st, int forward_done = 0);
+int kkt_level1_fused(const IpmDev& D);
 
 }  // namespace rpm

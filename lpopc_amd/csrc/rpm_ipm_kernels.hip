@@ -898,7 +898,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 // are the left-looking kernel's bit for bit.  Partial elimination only (the band part; the border x border corner is handed
 // on as the Schur complement).
 __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
-                                                                  int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble) {
+                                                                  int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble, int forward) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W, NWV = IPM_DENSE_TILE_WAVES, MAXS = IPM_DENSE_SLOTS;
   // the barriers of this kernel order LDS traffic only: __syncthreads() would also wait for the stores of L into the storage
@@ -921,6 +921,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   double* dv = invd + W;                   // W: the pivots d (what the storage holds on the diagonal)
   double* BL = dv + W;                     // NTB x 16 x BS: L of the current block column, by block row
   double* BY = BL + size_t(NTB) * W * BS;  // the same for L D
+  double* rsh = BY + size_t(NTB) * W * BS; // forward: this block's right-hand side, NTB x 16
+  double* ysh = rsh + size_t(NTB) * W;     // forward: y of the current block column
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = t & 15, lq = (t & 63) >> 4;
   auto row0 = [&](int I) { return I < nbb ? W * I : G.Nb + W * (I - nbb); };
   auto rend = [&](int I) { return I < nbb ? G.Nb : G.Nt; };
@@ -953,6 +955,16 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     }
     for (int e = ec + t; e < ed; e += 512) vals[1 + e - ea] = value(D.df_ki, D.df_hg, e);
     __syncthreads();
+  }
+  // forward: the first half of the substitution that follows an accepted factorisation (kkt_solve_kernel's phase 1: L y = r over the
+  // band blocks, the border work space takes -L_border y) runs along with the elimination — the panel of a block column is in
+  // LDS anyway, and the factor is not streamed from HBM a second time for it.  Same sums in the same order as that kernel's.
+  double* rg = D.rhs + size_t(bi) * D.Nt + sub.roff;
+  if (forward) {
+    for (int i = t; i < G.Nt; i += 512) {
+      const int I = i < G.Nb ? i / W : nbb + (i - G.Nb) / W;
+      rsh[I * W + (i - row0(I))] = rg[i];
+    }
   }
   if (wv == NWV) {
     // ---------------- the eighth wave holds no tiles: it factors the diagonal blocks (its registers are free for that) ----------------
@@ -1004,6 +1016,18 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       }
       IPM_DTICK(1);
       IPM_LDS_BARRIER();          // B2: Dg, Mi, invd are there
+      if (forward) {              // y = L11^-1 r of this block's unknowns (r is final: the tile waves added the last panel's share before B2),
+        double y = lr < w ? rsh[J * W + lr] : 0.0;   // while they solve the panel
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          const double zk = k < w ? rsh[J * W + k] : 0.0;
+          if (k < lr && lr < w) y = __builtin_fma(inv[k], zk, y);
+        }
+        if (lq == 0) {
+          ysh[lr] = y;
+          if (lr < w) rg[J0 + lr] = y;
+        }
+      }
       // the diagonal block is stored as d on the diagonal and L11^-1 below it (what the solves use)
       for (int idx = lane; idx < W * W; idx += 64) {
         const int di = idx / W, dj = idx % W;
@@ -1080,6 +1104,18 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #else
 #define IPM_TTICK(i)
 #endif
+  // forward: r(row) -= L(row, J) y for every row below block column J, thread p owns row p of the tile rows.  Off the chain of
+  // diagonal blocks: after the next diagonal tile has been handed over (the panel and y stay in LDS until the next B2)
+  auto forward_share = [&](int J) {
+    const int I = t >> 4;
+    if (I > J && I < NTB && row0(I) + lr < rend(I)) {
+      const double* bl = BL + (size_t(I) * W + lr) * BS;
+      double a = 0.0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) a = __builtin_fma(bl[c], ysh[c], a);
+      rsh[I * W + lr] -= a;
+    }
+  };
   for (int J = 0; J < nbb; ++J) {
     const int J0 = W * J, w = min(W, G.Nb - J0);
     const int cs = colstart(J), cs1 = colstart(J + 1);
@@ -1130,6 +1166,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       IPM_LDS_BARRIER();          // B1 of block column J + 1
       IPM_TTICK(2);             // next diagonal tile + B1
     }
+    if (forward) forward_share(J);
     switch (s0) {
 #define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);   /* two tiles' loads and products may interleave, not all 22 (registers) */
       IPM_REP22(IPM_UPD)
@@ -1146,6 +1183,10 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #endif
 #undef IPM_UPD_BODY
 #undef IPM_PUT_BODY
+  if (forward) {   // the border work space (each row by the thread that kept it)
+    const int I = t >> 4;
+    if (I >= nbb && I < NTB && row0(I) + lr < rend(I)) rg[row0(I) + lr] = rsh[I * W + lr];
+  }
   // the Schur complement of the corner, unfactored, back into the corner's storage
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
@@ -1162,7 +1203,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_LDS_BARRIER
 }
 size_t kkt_factor_dense_lds_bytes(int block_rows) {
-  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + 2 * IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW) * sizeof(double);
+  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + 2 * IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW +
+          size_t(block_rows) * IPM_W + IPM_W) * sizeof(double);
 }
 int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of this many block rows
   int n = 1;
@@ -1863,11 +1905,13 @@ __global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int
 __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __restrict__ dst, const int* __restrict__ src, int n, int mode,
                                const IpmInst* inst, int check_status, int kmod) {
   const int bi = blockIdx.y, bk = bi % kmod;
-  if (check_status && (inst[bk].status != 0 || (check_status == 2 && !inst[bk].soc_req))) return;
+  if (check_status && (inst[bk].status != 0 || (check_status == 2 && !inst[bk].soc_req) || (check_status == 3 && !inst[bk].refactor))) return;
   double* v = vall + size_t(bi) * vstride;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[dst[i]] = mode ? v[src[i]] : 0.0;
 }
 
+// level 1 assembled and forward-substituted inside kkt_factor_dense_kernel
+int kkt_level1_fused(const IpmDev& D) { return (D.n_l1 > 0 && D.l1_dense_lds && D.df_on && D.df_map) ? 1 : 0; }
 static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partial, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
   const dim3 grid(unsigned(D.B) * unsigned(n_here));
   if (tiles_per_wave == 28)
@@ -1901,9 +1945,14 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
     const unsigned blocks = unsigned(std::max(1, std::min(1024, (n + 255) / 256)));
     hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.K, D.kstride, ptr, src, dst, n, D.inst, 1, n_long, D.B);
   };
+  const int fused = kkt_level1_fused(D);
+  if (fused && D.n_gap) {                                                              // the forward sweep runs inside the kernel: border work spaces start at zero
+    const unsigned blocks = unsigned(std::max(1, std::min(256, (D.n_gap + 255) / 256)));
+    hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, D.gap_pos, nullptr, D.n_gap, 0, D.inst, 3, D.B);
+  }
   if (D.l1_dense_lds)                                                                  // every interval up to its corner
     hipLaunchKernelGGL(kkt_factor_dense_kernel, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
-                       D.n_l1, D.n_sub, D.inst, D.piv, D, D.df_on && D.df_map ? 1 : 0);
+                       D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused);
   else
     launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);
   corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg, D.n_cg_long);
@@ -1913,7 +1962,7 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
   }
   launch_factor_subs(D, D.n_l1 + D.n_l2, 1, 0, tiles_per_wave, lds_bytes, st);        // last level: (group) separators + border
 }
-void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
+void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st, int forward_done) {
   const unsigned VB = unsigned(D.B) * unsigned(D.rhs_mult > 1 ? D.rhs_mult : 1);   // right-hand sides in D.rhs (rhs_mult per instance)
   if (D.n_l1 == 0) {
     launch_solve_subs(D, 0, 1, 0, check_status, st);
@@ -1930,8 +1979,10 @@ void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st) {
     const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
     hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, VB), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0, 0, D.B);
   };
-  vec(D.gap_pos, nullptr, D.n_gap, 0);                                                 // border work spaces start at zero
-  launch_solve_subs(D, 0, D.n_l1, 1, check_status, st);                                // forward, every interval
+  if (!(forward_done && kkt_level1_fused(D))) {                                        // (else kkt_factor_dense_kernel did both for this right-hand side)
+    vec(D.gap_pos, nullptr, D.n_gap, 0);                                               // border work spaces start at zero
+    launch_solve_subs(D, 0, D.n_l1, 1, check_status, st);                              // forward, every interval
+  }
   gather(D.rg_ptr, D.rg_src, D.rg_dst, D.n_rg);
   if (D.n_l2) {
     launch_solve_subs(D, D.n_l1, D.n_l2, 1, check_status, st);                         // forward, every group

@@ -82,9 +82,9 @@ int launch_check(rpm_ipm* h, const char* what) {
   }
   return RPM_OK;
 }
-int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve, int check_status) {
+int factor_and_solve_launch(rpm_ipm* h, hipStream_t st, bool factor, bool solve, int check_status, int forward_done = 0) {
   if (factor) kkt_launch_factor(h->D, h->factor_mt, h->factor_lds, st);
-  if (solve) kkt_launch_solve(h->D, check_status, st);
+  if (solve) kkt_launch_solve(h->D, check_status, st, forward_done);
   return launch_check(h, "kkt kernels");
 }
 }  // namespace
@@ -640,7 +640,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       lb_launch_columns_and_solve(D, st);
       lb_launch_small(D, st);
     }
-    if ((rc = factor_and_solve_launch(h, st, false, true, 1))) return rc;
+    if ((rc = factor_and_solve_launch(h, st, false, true, 1, 1))) return rc;   // (the right-hand side the factorisation was given)
     if (h->lbfgs) lb_launch_correct(D, 1, st);
     IPM_TRY(h, hipEventRecord(h->ev[3], st));
     h->solve_pending = true;
