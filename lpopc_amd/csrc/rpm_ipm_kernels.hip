@@ -42,6 +42,47 @@ __device__ inline double readlane_d(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
+// value of `v` in the lane whose number is byte_addr / 4 (any lane per lane): a ds_bpermute pair
+__device__ inline double bperm_d(int byte_addr, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// value of `v` in lane K of the reader's own row of 16 lanes (DPP row_newbcast)
+template <int K>
+__device__ inline double row_bcast_d(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, false), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// One step of the 16 x 16 LDL^T + inverse of kkt_factor_dense_kernel's diagonal wave with the block's COLUMNS dealt to the four
+// rows of 16 lanes: lane (q, r) = 16 q + r keeps, of matrix row r, the columns 4 g + q (R[g]: the block, V[g]: L11^-1 so far).
+// Step K: the pivot column sits in group K & 3 — every lane fetches its own row's entry of it (the multiplier's numerator) and
+// the entries of the rows that are its columns (ds_bpermute, 10 a step), row K of the inverse comes by row_newbcast, and a lane
+// is left with 4 or 5 of the 16 products of a step.  Every entry sees the same operations in the same order as with a whole
+// row per lane (a wave-uniform v_readlane per operand, 34 a step, 16 dependent products).
+template <int K>
+struct DiagStep {
+  static __device__ __forceinline__ void run(double (&R)[4], double (&V)[4], int q, int r, int a_own, const int (&a_col)[4]) {
+    constexpr int QK = K & 3, GK = K >> 2;
+    const double dk = readlane_d(R[GK], QK * 16 + K);
+    const double ar = bperm_d(a_own + QK * 64, R[GK]);
+    double aj[4] = {0.0, 0.0, 0.0, 0.0}, mk[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (4 * g + 3 > K) aj[g] = bperm_d(a_col[g] + QK * 64, R[GK]);     // a(4 g + q, K) before scaling
+      if (4 * g <= K) mk[g] = row_bcast_d<K>(V[g]);                       // row K of the inverse so far
+    }
+    const double lik = r > K ? ar / dk : 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (4 * g > K) R[g] = __builtin_fma(-lik, aj[g], R[g]);             // columns right of the pivot
+      else if (4 * g + 3 > K) { const double u = __builtin_fma(-lik, aj[g], R[g]); R[g] = q > K - 4 * g ? u : R[g]; }
+      if (4 * g + 3 <= K) V[g] = __builtin_fma(-lik, mk[g], V[g]);        // columns up to the pivot
+      else if (4 * g <= K) { const double u = __builtin_fma(-lik, mk[g], V[g]); V[g] = q <= K - 4 * g ? u : V[g]; }
+    }
+    if (q == QK && r > K) R[GK] = lik;
+    if constexpr (K + 1 < IPM_W) DiagStep<K + 1>::run(R, V, q, r, a_own, a_col);
+  }
+};
 __device__ inline bool has_lo(double l, double u) { return l > -IPM_INF && l != u; }
 __device__ inline bool has_up(double l, double u) { return u < IPM_INF && l != u; }
 
@@ -603,6 +644,9 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
 // matrix product, Y^T = L11^-1 A^T, with the accumulators fed back as the B operand.  The border x border corner lives
 // in LDS, is updated right-looking and factored there.  Operand maps (cdna_hip_programming.md §3): A: lane l holds
 // A[l&15][l>>4], B: B[l>>4][l&15], C/D: row (l>>4) + 4 reg, column l&15.
+#ifndef IPM_DIAG_SPLIT
+#define IPM_DIAG_SPLIT 1   // kkt_factor_dense_kernel's diagonal blocks over all 64 lanes of their wave (0: a whole row per lane, four copies)
+#endif
 #ifndef IPM_LB
 #define IPM_LB 2   // waves per SIMD the 4-tile factorisation is compiled for (3: 168 VGPRs, 52 of them spilled since the pivots moved to v_readlane)
 #endif
@@ -980,6 +1024,30 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       const int J0 = W * J, w = min(W, G.Nb - J0);
       IPM_LDS_BARRIER();          // B1: the owner of tile (J, J) has put it into Dg
       IPM_DTICK(0);
+#if IPM_DIAG_SPLIT
+      {   // kkt_factor_kernel's elimination, entry for entry, over all 64 lanes (DiagStep)
+        double R[4], V[4];
+        int a_col[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = 4 * g + lq;
+          R[g] = (lr < w && j <= lr) ? Dg[lr * (W + 1) + j] : (j == lr ? 1.0 : 0.0);
+          V[g] = j == lr ? 1.0 : 0.0;
+          a_col[g] = j << 2;
+        }
+        DiagStep<0>::run(R, V, lq, lr, lr << 2, a_col);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = 4 * g + lq;
+          if (lr < w && j <= lr) Dg[lr * (W + 1) + j] = R[g];
+          Mi[lr * IPM_DENSE_LDS_ROW + j] = V[g];
+          if (j == lr) {
+            invd[lr] = lr < w ? 1.0 / R[g] : 0.0;
+            dv[lr] = lr < w ? R[g] : 0.0;
+          }
+        }
+      }
+#else
       double row[W], inv[W];    // lane (l & 15) = row of the block and of L11^-1 (kkt_factor_kernel's elimination, word for word)
 #pragma unroll
       for (int c = 0; c < W; ++c) {
@@ -1014,6 +1082,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
         dv[lr] = lr < w ? row[lr] : 0.0;
       }
+#endif
       IPM_DTICK(1);
       IPM_LDS_BARRIER();          // B2: Dg, Mi, invd are there
       if (forward) {              // y = L11^-1 r of this block's unknowns (r is final: the tile waves added the last panel's share before B2),
@@ -1021,7 +1090,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #pragma unroll
         for (int k = 0; k < W; ++k) {
           const double zk = k < w ? rsh[J * W + k] : 0.0;
-          if (k < lr && lr < w) y = __builtin_fma(inv[k], zk, y);
+          if (k < lr && lr < w) y = __builtin_fma(Mi[lr * IPM_DENSE_LDS_ROW + k], zk, y);
         }
         if (lq == 0) {
           ysh[lr] = y;
