@@ -250,7 +250,14 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start),
  *                       "level1_dense" (1 where it applies: the interval blocks of the nested dissection are factored out of
  *                       registers, kkt_factor_dense_kernel, when each has at most 17 block rows of 16; 0 = the left-looking
- *                       kernel for every level; 1 on a layout it does not fit: RPM_E_UNSUPPORTED)
+ *                       kernel for every level; 1 on a layout it does not fit: RPM_E_UNSUPPORTED),
+ *                       "fused_fill" (1 where level1_dense runs: that kernel assembles its interval block from the Jacobian,
+ *                       Hessian and diagonal terms itself and carries the level-1 forward substitution of the iteration's
+ *                       right-hand side along, the fill kernel leaves level-1 storage alone; 0 = separate kernels; same
+ *                       results bit for bit; 1 where level 1 does not run on that kernel: RPM_E_UNSUPPORTED),
+ *                       "ic_hot_start" (0; 1 = an iteration whose predecessor needed delta_w > 0 starts the inertia correction
+ *                       at kappa_w^- * delta_w_last instead of 0 while that is >= "ic_hot_min" (1e-10): not Ipopt's rule, an
+ *                       experiment)
  *   rpm_ipm_set_bounds: variable bounds of one instance (default: the engine's); the fixed/free pattern is shared
  *   rpm_ipm_solve[_dev]: x (n_instances x n, in: starting points, out: solutions; host resp. device pointer),
  *                       lambda (n_instances x m, may be NULL); per instance on the host, any may be NULL: objective,
