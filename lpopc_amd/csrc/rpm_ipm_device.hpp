@@ -114,13 +114,14 @@ struct IpmDev {
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
   // df_on: that kernel builds its interval block from the Jacobian / Hessian / diagonal terms itself instead of reading what
-  // ipm_fill_kernel wrote (which then skips the chunks of the storage that lie inside level-1 blocks, as_skip[c] = 1): the structural
+  // ipm_fill_kernel wrote (which then fills only the as_nlive chunks as_live[] of the storage that do not lie inside a level-1 block): the structural
   // slots of level-1 sub-problem s are df_ki / df_hg [df_ptr[3 s], df_ptr[3 s + 3]) (coded like as_ki / as_hg; Jacobian entries from
   // df_ptr[3 s], Hessian slots from df_ptr[3 s + 1], slack entries and diagonals from df_ptr[3 s + 2]), and lane l of register tile t
   // holds the entries numbered df_map[(s * IPM_DENSE_TILES + t) * 64 + l] (four 16-bit numbers, 1-based into that list, 0 = a
   // structural zero)
   int df_on;
-  const int *df_ptr, *df_ki, *df_hg, *as_skip;
+  const int *df_ptr, *df_ki, *df_hg, *as_live;
+  int as_nlive;
   const unsigned long long* df_map;
   // hessian-approximation = limited-memory (rpm_ipm_lbfgs.hip): no Hessian entries, sigma on the diagonal of x, low-rank part by Woodbury
   int rhs_mult;               // kkt_launch_solve: right-hand sides per instance in `rhs` (0 / 1: one; j-th of instance bi at row j * B + bi)

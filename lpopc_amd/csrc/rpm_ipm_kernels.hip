@@ -586,9 +586,10 @@ __global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
   double* K = D.K + size_t(bi) * D.kstride;
   const int tid = threadIdx.x;
   const SlotValue value(D, bi);
-  const bool skipping = D.df_on && D.l1_dense_lds && D.as_skip;
-  for (int c = blockIdx.x; c < D.as_nchunk; c += gridDim.x) {
-    if (skipping && D.as_skip[c]) continue;
+  const bool some = D.df_on && D.l1_dense_lds && D.as_live;     // only the chunks not inside a level-1 block (kkt_level1_fused)
+  const int n_here = some ? D.as_nlive : D.as_nchunk;
+  for (int ci = blockIdx.x; ci < n_here; ci += gridDim.x) {
+    const int c = some ? D.as_live[ci] : ci;
     const long long lo = (long long)c * IPM_FILL_CHUNK, hi = min(lo + IPM_FILL_CHUNK, D.kstride);
     const int e0 = D.as_ptr[c], e1 = D.as_ptr[c + 1];
     // this thread's first slot: its loads are under way while the chunk is zeroed
@@ -1903,7 +1904,8 @@ void ipm_launch_jt_lambda_into(const IpmDev& D, double* out, hipStream_t st) {
 }
 void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
   if (D.as_nchunk > 0) {
-    hipLaunchKernelGGL(ipm_fill_kernel, dim3(unsigned(std::min(D.as_nchunk, 65535)), unsigned(D.B)), dim3(256), 0, st, D);
+    const int chunks = kkt_level1_fused(D) ? D.as_nlive : D.as_nchunk;
+    hipLaunchKernelGGL(ipm_fill_kernel, dim3(unsigned(std::max(1, std::min(chunks, 65535))), unsigned(D.B)), dim3(256), 0, st, D);
     return;
   }
   const int assemble_blocks = std::max(1, std::min(D.B <= 32 ? 2048 : 64, (nnz_max + 255) / 256));   // a few large instances: the whole chip

@@ -240,7 +240,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     // level 1 assembled by kkt_factor_dense_kernel itself (IpmDev::df_on): per interval block the list of its structural slots and,
     // per register tile lane, which of them it holds; the fill leaves out the chunks that lie inside such a block
     D.df_on = 0;
-    D.df_ptr = D.df_ki = D.df_hg = D.as_skip = nullptr;
+    D.df_ptr = D.df_ki = D.df_hg = D.as_live = nullptr;
+    D.as_nlive = 0;
     D.df_map = nullptr;
     if (h->l1_dense_lds && D.as_nchunk > 0 && !(std::getenv("RPM_IPM_FUSED_FILL") && std::atoi(std::getenv("RPM_IPM_FUSED_FILL")) == 0)) {
       // per block the Jacobian entries first, then the Hessian slots, then the rest (slack entries, diagonals): three plain loops in the kernel
@@ -283,7 +284,11 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
       f_ptr[3 * size_t(D.n_l1)] = int(f_ki.size());
       if (ok) {
         A_(ipm_alloc_c(h, &D.df_ptr, f_ptr)); A_(ipm_alloc_c(h, &D.df_ki, f_ki)); A_(ipm_alloc_c(h, &D.df_hg, f_hg));
-        A_(ipm_alloc_c(h, &D.as_skip, skip)); A_(ipm_alloc_c(h, &D.df_map, f_map));
+        std::vector<int> live;
+        for (int c = 0; c < D.as_nchunk; ++c)
+          if (!skip[size_t(c)]) live.push_back(c);
+        D.as_nlive = int(live.size());
+        A_(ipm_alloc_c(h, &D.as_live, live)); A_(ipm_alloc_c(h, &D.df_map, f_map));
         D.df_on = 1;
       }
     }
