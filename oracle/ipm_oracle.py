@@ -61,6 +61,8 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 mu_strategy="adaptive", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
                 adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3,
                 init_ls_multipliers=0,                # 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
+                ic_hot_start=0, ic_hot_min=1e-10,     # 1: Algorithm IC starts at kw_dec * delta_w_last when the previous iteration needed delta_w > 0
+                                                      #    and that value is >= ic_hot_min (NOT Ipopt's rule, which always tries 0 first: an experiment)
                 hessian_approximation="exact", limited_memory_max_history=6, limited_memory_max_skipping=2,
                 limited_memory_init_val_min=1e-8, limited_memory_init_val_max=1e8,
                 dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,                      # Ipopt's unscaled termination thresholds
@@ -134,6 +136,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
     zL, zU = lo.astype(float), up.astype(float)
     lam = np.zeros(m)
     mu, it, dw_last = o["mu_init"], 0, 0.0
+    ic_hot = False                # the last regular iteration's factorisation needed delta_w > 0
     filt, trace = [], []
     theta_max = theta_min = None
 
@@ -428,6 +431,8 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         sigma = np.where(lo, zL / dl, 0.0) + np.where(up, zU / du, 0.0)
         rd = glag - np.where(lo, mu / dl, 0.0) + np.where(up, mu / du, 0.0)
         dw = 0.0
+        if o["ic_hot_start"] and ic_hot and o["kw_dec"] * dw_last >= o["ic_hot_min"]:
+            dw = o["kw_dec"] * dw_last
         Ksp = None
         if o["linear_solver"] == "sparse-lu-no-inertia":
             # timing variant for bench cpu_baseline legs ONLY: sparse LU of the same matrix, inertia taken on trust (valid on
@@ -445,6 +450,7 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
             if _n_positive(K) == nv:
                 if dw > 0:
                     dw_last = dw
+                ic_hot = dw > 0
                 break
             if dw == 0.0:
                 dw = o["delta_w_first"] if dw_last == 0.0 else max(o["delta_w_min"], o["kw_dec"] * dw_last)

@@ -379,6 +379,37 @@ def test_device_solve_against_restatement(built, name, make, B, pert, same_path)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,make", [("bryson_denham", lambda: problems.bryson_denham(2, 8)), ("brachistochrone", lambda: problems.brachistochrone(2, 10))],
+                         ids=["bryson_denham", "brachistochrone"])
+def test_inertia_correction_hot_start_against_restatement(built, name, make):
+    """Option ic_hot_start (an experiment, not Ipopt's rule; off by default): an iteration whose predecessor needed delta_w > 0
+    starts Algorithm IC at kappa_w^- delta_w_last instead of 0.  Device and restatement take the same perturbations step by step
+    and reach the same optimum; nearly every iteration is then factored with delta_w > 0, against a minority without the option."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = make()
+    eng = NLPEngine(prob, _exact(), n_instances=1, device=0)
+    o = orc.Oracle(prob, _exact())
+    x0 = o.starting_point()[None, :]
+    ipm = BatchedIPM(eng, max_iter=400, trace=400, ic_hot_start=1)
+    r = ipm.solve(x0)
+    ref = ipm_oracle.solve(o, x0[0], max_iter=400, ic_hot_start=1)
+    plain = ipm_oracle.solve(o, x0[0], max_iter=400)
+    assert r["status"][0] == ref["status"] == 0
+    assert abs(int(r["iterations"][0]) - ref["iterations"]) <= 1
+    assert abs(r["obj"][0] - ref["obj"]) <= 1e-8 * max(1.0, abs(ref["obj"])) and abs(ref["obj"] - plain["obj"]) <= 1e-7 * max(1.0, abs(plain["obj"]))
+    tr = ipm.trace(0)
+    same = min(len(tr), len(ref["trace"]), 8)
+    for k in range(same):
+        dw = ref["trace"][k]["delta_w"]
+        assert abs(tr[k, 5] - dw) <= 1e-12 * dw, (k, tr[k], ref["trace"][k])
+    hot = sum(1 for e in ref["trace"] if e["delta_w"] > 0)
+    assert hot > 2 * sum(1 for e in plain["trace"] if e["delta_w"] > 0) and hot >= 0.8 * len(ref["trace"])
+    assert ipm.stats()["factorizations"] < 1.3 * int(r["iterations"][0]) + 3      # the failed trial at delta_w = 0 is gone
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_sweep_with_per_instance_bounds(built):
     """An MPC sweep: the same transcription from different initial states (per-instance variable bounds)."""
     from lpopc_amd.engine import BatchedIPM, NLPEngine
