@@ -12,6 +12,7 @@ constexpr int IPM_FMAX = 1024;   // filter entries kept per instance (the filter
 constexpr int IPM_TRACE = 8;     // doubles per trace record: f, theta, mu, alpha, alpha_z, delta_w, E_0, backtracks
 constexpr double IPM_INF = 1e19; // Ipopt's nlp_lower_bound_inf / nlp_upper_bound_inf
 constexpr int IPM_LB_H = 6;      // limited-memory BFGS: Ipopt's limited_memory_max_history
+constexpr int IPM_LB_PART = 80 * 16;   // doubles per instance for the partial sums of the limited-memory kernels: 80 sums x 16 waves
 constexpr int IPM_LB_SMALL = 8 + 2 * (2 * IPM_LB_H) * (2 * IPM_LB_H) + 2 * (2 * IPM_LB_H);   // doubles of an instance's small record (rpm_ipm_lbfgs.hip)
 
 struct IpmOpts {
@@ -130,6 +131,7 @@ struct IpmDev {
   double *lb_xprev;           // B x n: the iterate the stored gradient / Jacobian belong to
   double *lb_gold;            // B x nv: grad_x L(x_prev, lambda) with the CURRENT multipliers (first n of every row)
   double *lb_small;           // B x IPM_LB_SMALL
+  double *lb_part;            // B x IPM_LB_PART: the waves' shares of the sums of one phase (rpm_ipm_lbfgs.hip)
   double *lb_Z;               // 2 IPM_LB_H x B x Nt: K0^-1 E, column-major by column
 };
 

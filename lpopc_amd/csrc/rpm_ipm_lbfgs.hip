@@ -22,15 +22,32 @@ constexpr int LB_TH = 2 * IPM_LB_H;
 constexpr int LB_M = 8, LB_C = LB_M + LB_TH * LB_TH, LB_PIV = LB_C + LB_TH * LB_TH, LB_T = LB_PIV + LB_TH;
 static_assert(LB_T + LB_TH <= IPM_LB_SMALL, "record of the limited-memory update");
 
-__device__ inline double lb_sum(double v, double* sh) {   // sum over the workgroup (fixed order), result in every thread
+// A sum over the variables is formed as a single workgroup of nt threads would form it — thread t adds its terms i = t, t + nt, ...
+// in order, the 64 threads of a wave are folded by shuffles, the nt / 64 waves' sums are added in order — but every wave of that
+// layout is a task of its own (task = sum * NW + wave; 4 tasks per workgroup of 256), so that the 144 sums of C = M - E'Z over
+// 40 000 variables run on all CUs instead of one (metric problem: 2.0 ms -> tens of microseconds per iteration, same bits).  The
+// waves' sums wait in lb_part (per instance LB_PART doubles: sum k at [k * 16, k * 16 + NW)); lb_fold adds them.
+constexpr int LB_TASKS = IPM_LB_PART / 16, LB_PART = IPM_LB_PART;
+static_assert(LB_TH * (LB_TH + 1) / 2 <= LB_TASKS, "sums of one phase");
+template <class F>
+__device__ inline void lb_wave_sum(int w, int nt, int n, F term, double* out) {
+  const int l = threadIdx.x & 63;
+  double v = 0.0;
+  for (int i = 64 * w + l; i < n; i += nt) v += term(i);
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();
-  if (l == 0) sh[w] = v;
-  __syncthreads();
+  if (l == 0) *out = v;
+}
+__device__ inline double lb_fold(const double* part, int nw) {
   double s = 0.0;
-  for (int q = 0; q < nw; ++q) s += sh[q];
+  for (int q = 0; q < nw; ++q) s += part[q];
   return s;
+}
+// task of this wave: sum k, wave w of the layout; false beyond the n_sums sums of the phase
+__device__ inline bool lb_task(int n_sums, int nw, int* k, int* w) {
+  const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  *k = task / nw;
+  *w = task % nw;
+  return *k < n_sums;
 }
 
 // column `a` (0 .. TH-1) of Q at variable i
@@ -39,87 +56,124 @@ __device__ inline double lb_q(const IpmDev& D, int bi, int a, int i, double sigm
   return a < IPM_LB_H ? sigma * D.lb_S[base] : D.lb_Y[base];
 }
 
-// one pair per accepted step, then the small matrix M; the current iterate becomes the previous one
-__global__ __launch_bounds__(1024) void lb_update_kernel(IpmDev D) {
-  __shared__ double sh[16];
-  const int bi = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+// ---- one pair per accepted step, then the small matrix M; the current iterate becomes the previous one ----
+// record entries 6, 7: what the decision asks of the kernels behind it (6: 1 = store the pair in column rec[7] (after shifting the
+// columns down when rec[7] = H - 1 and the memory was full: rec[7] + 16), 2 = memory emptied; 0 = nothing)
+__global__ __launch_bounds__(256) void lb_stats_kernel(IpmDev D, int nw) {        // s's, s'y, y'y of the step just taken
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || S.mode != 0) return;
+  const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  if (rec[3] == 0.0) return;
+  int k, w;
+  if (!lb_task(3, nw, &k, &w)) return;
+  const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
+  const double *glag = D.glag + size_t(bi) * D.nv, *gold = D.lb_gold + size_t(bi) * D.nv, *xprev = D.lb_xprev + size_t(bi) * D.n;
+  double* out = D.lb_part + size_t(bi) * LB_PART + k * 16 + w;
+  const int nt = 64 * nw;
+  if (k == 0) lb_wave_sum(w, nt, D.n, [&](int i) { const double s = v[i] - xprev[i]; return s * s; }, out);
+  else if (k == 1) lb_wave_sum(w, nt, D.n, [&](int i) { const double s = v[i] - xprev[i]; const double y = vl[i] != vu[i] ? glag[i] - gold[i] : 0.0; return s * y; }, out);
+  else lb_wave_sum(w, nt, D.n, [&](int i) { const double y = vl[i] != vu[i] ? glag[i] - gold[i] : 0.0; return y * y; }, out);
+}
+__global__ void lb_decide_kernel(IpmDev D, int nw) {
+  const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bi >= D.B) return;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
   double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  rec[6] = 0.0;
   if (S.mode != 0) {   // restoration phase / its multiplier pass: the point moves by another problem's steps -> empty memory
-    if (t == 0) { rec[0] = 1.0; rec[1] = 0.0; rec[2] = 0.0; rec[3] = 0.0; }
+    rec[0] = 1.0; rec[1] = 0.0; rec[2] = 0.0; rec[3] = 0.0;
     return;
   }
+  int c = int(rec[1]);
+  const double skipped = rec[2];
+  if (rec[3] != 0.0) {
+    const double* part = D.lb_part + size_t(bi) * LB_PART;
+    const double sts = lb_fold(part, nw), sty = lb_fold(part + 16, nw), yty = lb_fold(part + 32, nw);
+    if (sts > 0.0) {   // (a pass that only replaced lambda has s = 0: nothing to learn)
+      if (sty > 1.4901161193847656e-08 * sqrt(sts) * sqrt(yty)) {
+        double col = double(c);
+        if (c == IPM_LB_H) { c = IPM_LB_H - 1; col = double(c) + 16.0; }
+        rec[6] = 1.0; rec[7] = col;
+        c += 1;
+        rec[0] = fmin(1e8, fmax(1e-8, sty / sts)); rec[1] = double(c); rec[2] = 0.0; rec[4] += 1.0;
+      } else {
+        const double sk = skipped + 1.0;
+        rec[5] += 1.0;
+        rec[2] = sk >= 2.0 ? 0.0 : sk;
+        if (sk >= 2.0) { rec[0] = 1.0; rec[1] = 0.0; rec[6] = 2.0; }
+      }
+    }
+  }
+  rec[3] = 1.0;
+}
+__global__ __launch_bounds__(256) void lb_store_kernel(IpmDev D) {      // the pair into its column; x becomes the previous iterate
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || S.mode != 0) return;
+  const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
   const int n = D.n;
   const double *v = D.v + size_t(bi) * D.nv, *vl = D.vl + size_t(bi) * D.nv, *vu = D.vu + size_t(bi) * D.nv;
   const double *glag = D.glag + size_t(bi) * D.nv, *gold = D.lb_gold + size_t(bi) * D.nv;
   double* xprev = D.lb_xprev + size_t(bi) * n;
   double* Sm = D.lb_S + size_t(bi) * IPM_LB_H * n;
   double* Ym = D.lb_Y + size_t(bi) * IPM_LB_H * n;
-  int c = int(rec[1]);
-  double sigma = rec[0];
-  const double skipped = rec[2];
-  const bool has_prev = rec[3] != 0.0;
-  __syncthreads();   // every thread has read the record before thread 0 changes it
-  bool changed = false;
-  if (has_prev) {
-    double sts = 0, sty = 0, yty = 0;
-    for (int i = t; i < n; i += nt) {
-      const double s = v[i] - xprev[i];
-      const double y = vl[i] != vu[i] ? glag[i] - gold[i] : 0.0;
-      sts += s * s; sty += s * y; yty += y * y;
+  const bool store = rec[6] == 1.0;
+  const bool shift = store && rec[7] >= 16.0;
+  const int col = store ? int(rec[7]) & 15 : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (shift)
+      for (int k = 0; k + 1 < IPM_LB_H; ++k) { Sm[size_t(k) * n + i] = Sm[size_t(k + 1) * n + i]; Ym[size_t(k) * n + i] = Ym[size_t(k + 1) * n + i]; }
+    if (store) {
+      Sm[size_t(col) * n + i] = v[i] - xprev[i];
+      Ym[size_t(col) * n + i] = vl[i] != vu[i] ? glag[i] - gold[i] : 0.0;
     }
-    sts = lb_sum(sts, sh); sty = lb_sum(sty, sh); yty = lb_sum(yty, sh);
-    if (sts > 0.0) {   // (a pass that only replaced lambda has s = 0: nothing to learn)
-      if (sty > 1.4901161193847656e-08 * sqrt(sts) * sqrt(yty)) {
-        if (c == IPM_LB_H) {
-          for (int i = t; i < n; i += nt)
-            for (int k = 0; k + 1 < IPM_LB_H; ++k) { Sm[size_t(k) * n + i] = Sm[size_t(k + 1) * n + i]; Ym[size_t(k) * n + i] = Ym[size_t(k + 1) * n + i]; }
-          c = IPM_LB_H - 1;
-        }
-        for (int i = t; i < n; i += nt) {
-          Sm[size_t(c) * n + i] = v[i] - xprev[i];
-          Ym[size_t(c) * n + i] = vl[i] != vu[i] ? glag[i] - gold[i] : 0.0;
-        }
-        c += 1;
-        sigma = fmin(1e8, fmax(1e-8, sty / sts));
-        if (t == 0) { rec[0] = sigma; rec[1] = double(c); rec[2] = 0.0; rec[4] += 1.0; }
-        changed = true;
-      } else {
-        const double sk = skipped + 1.0;
-        if (sk >= 2.0) { c = 0; sigma = 1.0; changed = true; }
-        if (t == 0) { rec[5] += 1.0; rec[2] = sk >= 2.0 ? 0.0 : sk; if (sk >= 2.0) { rec[0] = 1.0; rec[1] = 0.0; } }
+    xprev[i] = v[i];
+  }
+}
+// M = [[sigma S'S, L], [L', -D]]: s_a's_b and s_a'y_b for b <= a < pairs held (sum 2 (a (a + 1) / 2 + b) + {0, 1})
+__global__ __launch_bounds__(256) void lb_mdots_kernel(IpmDev D, int nw) {
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || S.mode != 0) return;
+  const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  if (rec[6] == 0.0) return;
+  const int c = int(rec[1]);
+  int k, w;
+  if (!lb_task(c * (c + 1), nw, &k, &w)) return;
+  int a = 0;
+  while ((a + 1) * (a + 2) / 2 <= k / 2) ++a;
+  const int b = k / 2 - a * (a + 1) / 2;
+  const int n = D.n;
+  const double* sa = D.lb_S + (size_t(bi) * IPM_LB_H + a) * n;
+  const double* other = (k & 1) ? D.lb_Y + (size_t(bi) * IPM_LB_H + b) * n : D.lb_S + (size_t(bi) * IPM_LB_H + b) * n;
+  lb_wave_sum(w, 64 * nw, n, [&](int i) { return sa[i] * other[i]; }, D.lb_part + size_t(bi) * LB_PART + k * 16 + w);
+}
+__global__ void lb_mfinish_kernel(IpmDev D, int nw) {
+  const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bi >= D.B) return;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || S.mode != 0) return;
+  double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  if (rec[6] == 0.0) return;
+  const int c = int(rec[1]);
+  const double sigma = rec[0];
+  double* M = rec + LB_M;
+  const double* part = D.lb_part + size_t(bi) * LB_PART;
+  for (int q = 0; q < LB_TH * LB_TH; ++q) M[q] = (q / LB_TH == q % LB_TH) ? 1.0 : 0.0;     // identity on the unused indices
+  for (int a = 0; a < c; ++a)
+    for (int b = 0; b <= a; ++b) {
+      const int k = 2 * (a * (a + 1) / 2 + b);
+      const double ss = lb_fold(part + k * 16, nw), sy = lb_fold(part + (k + 1) * 16, nw);
+      M[a * LB_TH + b] = M[b * LB_TH + a] = sigma * ss;
+      if (a == b) {
+        M[(IPM_LB_H + a) * LB_TH + IPM_LB_H + a] = -sy;                  // -D
+      } else {                                                            // L(a, b) = s_a'y_b for a > b (strictly lower)
+        M[a * LB_TH + IPM_LB_H + b] = M[(IPM_LB_H + b) * LB_TH + a] = sy;
+        M[b * LB_TH + IPM_LB_H + a] = M[(IPM_LB_H + a) * LB_TH + b] = 0.0;
       }
     }
-  }
-  __syncthreads();
-  if (changed) {   // M = [[sigma S'S, L], [L', -D]] in the fixed layout, identity on the unused indices
-    double* M = rec + LB_M;
-    for (int q = t; q < LB_TH * LB_TH; q += nt) M[q] = (q / LB_TH == q % LB_TH) ? 1.0 : 0.0;
-    __syncthreads();
-    for (int a = 0; a < c; ++a)
-      for (int b = 0; b <= a; ++b) {
-        double ss = 0, sy = 0, ys = 0;
-        for (int i = t; i < n; i += nt) {
-          const double sa = Sm[size_t(a) * n + i], sb = Sm[size_t(b) * n + i];
-          ss += sa * sb; sy += sa * Ym[size_t(b) * n + i]; ys += Ym[size_t(a) * n + i] * sb;
-        }
-        ss = lb_sum(ss, sh); sy = lb_sum(sy, sh); ys = lb_sum(ys, sh);
-        if (t == 0) {
-          M[a * LB_TH + b] = M[b * LB_TH + a] = sigma * ss;
-          if (a == b) {
-            M[(IPM_LB_H + a) * LB_TH + IPM_LB_H + a] = -sy;                  // -D
-          } else {                                                            // L(a, b) = s_a'y_b for a > b (strictly lower)
-            M[a * LB_TH + IPM_LB_H + b] = M[(IPM_LB_H + b) * LB_TH + a] = sy;
-            M[b * LB_TH + IPM_LB_H + a] = M[(IPM_LB_H + a) * LB_TH + b] = 0.0;
-            (void)ys;
-          }
-        }
-      }
-  }
-  __syncthreads();
-  for (int i = t; i < n; i += nt) xprev[i] = v[i];
-  if (t == 0) rec[3] = 1.0;
 }
 
 // Z_j <- column j of E (Q at the positions of x, zero elsewhere), to be solved in place; blockIdx.x = column
@@ -137,75 +191,97 @@ __global__ __launch_bounds__(1024) void lb_column_kernel(IpmDev D) {
   for (int i = t; i < D.n; i += nt) z[D.pos[i]] = lb_q(D, bi, j, i, sigma);
 }
 
-// C = M - E'Z and its LU factorisation (partial pivoting; 2 x history rows)
-__global__ __launch_bounds__(1024) void lb_small_kernel(IpmDev D) {
-  __shared__ double sh[16];
-  const int bi = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+// C = M - E'Z and its LU factorisation (partial pivoting; 2 x history rows): the sums q_a'z_b, a <= b (sum ia (2 TH - ia + 1) / 2 + ib - ia
+// in the packed numbering of the live columns), then one thread per instance
+__device__ inline void lb_pair_of(int k, int m, int* ia, int* ib) {   // k-th pair (ia <= ib < m), rows first
+  int r = 0;
+  while (k >= m - r) { k -= m - r; ++r; }
+  *ia = r;
+  *ib = r + k;
+}
+__global__ __launch_bounds__(256) void lb_cdots_kernel(IpmDev D, int nw) {
+  const int bi = blockIdx.y;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || S.mode != 0) return;
+  const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  const int c = int(rec[1]);
+  if (c == 0) return;
+  int k, w;
+  if (!lb_task(c * (2 * c + 1), nw, &k, &w)) return;
+  int ia, ib;
+  lb_pair_of(k, 2 * c, &ia, &ib);
+  const int a = ia < c ? ia : IPM_LB_H + ia - c, b = ib < c ? ib : IPM_LB_H + ib - c;
+  const double sigma = rec[0];
+  const double* zb = D.lb_Z + (size_t(b) * D.B + bi) * D.Nt;
+  lb_wave_sum(w, 64 * nw, D.n, [&](int i) { return lb_q(D, bi, a, i, sigma) * zb[D.pos[i]]; }, D.lb_part + size_t(bi) * LB_PART + k * 16 + w);
+}
+__global__ void lb_cfinish_kernel(IpmDev D, int nw) {
+  const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bi >= D.B) return;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0 || S.mode != 0) return;
   double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
   const int c = int(rec[1]);
   if (c == 0) return;
-  const double sigma = rec[0];
   double* C = rec + LB_C;
   const double* M = rec + LB_M;
-  for (int q = t; q < LB_TH * LB_TH; q += nt) C[q] = M[q];
-  __syncthreads();
+  const double* part = D.lb_part + size_t(bi) * LB_PART;
+  for (int q = 0; q < LB_TH * LB_TH; ++q) C[q] = M[q];
+  int k = 0;
   for (int ia = 0; ia < 2 * c; ++ia)
-    for (int ib = ia; ib < 2 * c; ++ib) {
+    for (int ib = ia; ib < 2 * c; ++ib, ++k) {
       const int a = ia < c ? ia : IPM_LB_H + ia - c, b = ib < c ? ib : IPM_LB_H + ib - c;
-      const double* zb = D.lb_Z + (size_t(b) * D.B + bi) * D.Nt;
-      double acc = 0.0;
-      for (int i = t; i < D.n; i += nt) acc += lb_q(D, bi, a, i, sigma) * zb[D.pos[i]];
-      acc = lb_sum(acc, sh);
-      if (t == 0) {
-        C[a * LB_TH + b] -= acc;
-        if (a != b) C[b * LB_TH + a] -= acc;    // K0 is symmetric: E'K0^-1E is
-      }
+      const double acc = lb_fold(part + k * 16, nw);
+      C[a * LB_TH + b] -= acc;
+      if (a != b) C[b * LB_TH + a] -= acc;    // K0 is symmetric: E'K0^-1E is
     }
-  __syncthreads();
-  if (t == 0) {
-    double* piv = rec + LB_PIV;
-    for (int k = 0; k < LB_TH; ++k) {
-      int p = k;
-      for (int r = k + 1; r < LB_TH; ++r)
-        if (fabs(C[r * LB_TH + k]) > fabs(C[p * LB_TH + k])) p = r;
-      piv[k] = double(p);
-      if (p != k)
-        for (int q = 0; q < LB_TH; ++q) { const double w = C[k * LB_TH + q]; C[k * LB_TH + q] = C[p * LB_TH + q]; C[p * LB_TH + q] = w; }
-      const double d = C[k * LB_TH + k];
-      for (int r = k + 1; r < LB_TH; ++r) {
-        const double f = C[r * LB_TH + k] / d;
-        C[r * LB_TH + k] = f;
-        for (int q = k + 1; q < LB_TH; ++q) C[r * LB_TH + q] -= f * C[k * LB_TH + q];
-      }
+  double* piv = rec + LB_PIV;
+  for (int k2 = 0; k2 < LB_TH; ++k2) {
+    int p = k2;
+    for (int r = k2 + 1; r < LB_TH; ++r)
+      if (fabs(C[r * LB_TH + k2]) > fabs(C[p * LB_TH + k2])) p = r;
+    piv[k2] = double(p);
+    if (p != k2)
+      for (int q = 0; q < LB_TH; ++q) { const double w = C[k2 * LB_TH + q]; C[k2 * LB_TH + q] = C[p * LB_TH + q]; C[p * LB_TH + q] = w; }
+    const double d = C[k2 * LB_TH + k2];
+    for (int r = k2 + 1; r < LB_TH; ++r) {
+      const double f = C[r * LB_TH + k2] / d;
+      C[r * LB_TH + k2] = f;
+      for (int q = k2 + 1; q < LB_TH; ++q) C[r * LB_TH + q] -= f * C[k2 * LB_TH + q];
     }
   }
 }
 
-// d <- d + Z (M - E'Z)^-1 E'd for the solution d of K0 d = r that sits in rhs
-__global__ __launch_bounds__(1024) void lb_correct_kernel(IpmDev D, double* rhs_all, int check_status) {
-  __shared__ double sh[16];
-  __shared__ double w[LB_TH];
-  const int bi = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+// d <- d + Z (M - E'Z)^-1 E'd for the solution d of K0 d = r that sits in rhs: the sums q_a'd first ...
+__global__ __launch_bounds__(256) void lb_wdots_kernel(IpmDev D, const double* rhs_all, int check_status, int nw) {
+  const int bi = blockIdx.y;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0 || S.mode != 0 || (check_status == 2 && !S.soc_req)) return;
-  double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
   const int c = int(rec[1]);
   if (c == 0) return;
+  int ia, w;
+  if (!lb_task(2 * c, nw, &ia, &w)) return;
+  const int a = ia < c ? ia : IPM_LB_H + ia - c;
   const double sigma = rec[0];
+  const double* d = rhs_all + size_t(bi) * D.Nt;
+  lb_wave_sum(w, 64 * nw, D.n, [&](int i) { return lb_q(D, bi, a, i, sigma) * d[D.pos[i]]; }, D.lb_part + size_t(bi) * LB_PART + ia * 16 + w);
+}
+// ... then every workgroup solves the 12 x 12 system for itself (the same operations in each) and corrects its slice of d
+__global__ __launch_bounds__(256) void lb_apply_kernel(IpmDev D, double* rhs_all, int check_status, int nw) {
+  __shared__ double w[LB_TH];
+  const int bi = blockIdx.y, t = threadIdx.x;
+  const IpmInst& S = D.inst[bi];
+  if (S.status != 0 || S.mode != 0 || (check_status == 2 && !S.soc_req)) return;
+  const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
+  const int c = int(rec[1]);
+  if (c == 0) return;
   double* d = rhs_all + size_t(bi) * D.Nt;
-  if (t < LB_TH) w[t] = 0.0;
-  __syncthreads();
-  for (int ia = 0; ia < 2 * c; ++ia) {
-    const int a = ia < c ? ia : IPM_LB_H + ia - c;
-    double acc = 0.0;
-    for (int i = t; i < D.n; i += nt) acc += lb_q(D, bi, a, i, sigma) * d[D.pos[i]];
-    acc = lb_sum(acc, sh);
-    if (t == 0) w[a] = acc;
-  }
-  __syncthreads();
-  if (t == 0) {   // w <- C^-1 w with the LU factors
+  if (t == 0) {
+    const double* part = D.lb_part + size_t(bi) * LB_PART;
+    for (int q = 0; q < LB_TH; ++q) w[q] = 0.0;
+    for (int ia = 0; ia < 2 * c; ++ia) w[ia < c ? ia : IPM_LB_H + ia - c] = lb_fold(part + ia * 16, nw);
+    // w <- C^-1 w with the LU factors
     const double *C = rec + LB_C, *piv = rec + LB_PIV;
     for (int k = 0; k < LB_TH; ++k) {   // the row interchanges first (whole rows were swapped, multipliers included), then L, then U
       const int p = int(piv[k]);
@@ -220,7 +296,7 @@ __global__ __launch_bounds__(1024) void lb_correct_kernel(IpmDev D, double* rhs_
     }
   }
   __syncthreads();
-  for (int p = t; p < D.Nt; p += nt) {
+  for (int p = blockIdx.x * blockDim.x + t; p < D.Nt; p += gridDim.x * blockDim.x) {
     double acc = 0.0;
     for (int ia = 0; ia < 2 * c; ++ia) {
       const int a = ia < c ? ia : IPM_LB_H + ia - c;
@@ -241,8 +317,16 @@ __global__ void lb_reset_kernel(IpmDev D) {
 void lb_launch_reset(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(lb_reset_kernel, dim3(unsigned((D.B + 255) / 256)), dim3(256), 0, st, D);
 }
+static unsigned lb_task_blocks(int n_sums, int nw) { return unsigned((n_sums * nw + 3) / 4); }
+static int lb_waves(int len) { return len >= 4096 ? 16 : 4; }    // the layout the sums are defined on: 1024 resp. 256 threads
 void lb_launch_update(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(lb_update_kernel, dim3(1, unsigned(D.B)), dim3(D.n >= 4096 ? 1024 : 256), 0, st, D);
+  const int nw = lb_waves(D.n);
+  const unsigned B = unsigned(D.B), ib = unsigned((D.B + 63) / 64), vb = unsigned(std::max(1, std::min(1024, (D.n + 255) / 256)));
+  hipLaunchKernelGGL(lb_stats_kernel, dim3(lb_task_blocks(3, nw), B), dim3(256), 0, st, D, nw);
+  hipLaunchKernelGGL(lb_decide_kernel, dim3(ib), dim3(64), 0, st, D, nw);
+  hipLaunchKernelGGL(lb_store_kernel, dim3(vb, B), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(lb_mdots_kernel, dim3(lb_task_blocks(IPM_LB_H * (IPM_LB_H + 1), nw), B), dim3(256), 0, st, D, nw);
+  hipLaunchKernelGGL(lb_mfinish_kernel, dim3(ib), dim3(64), 0, st, D, nw);
 }
 // Z = K0^-1 E: all 2 x history columns of every running instance in ONE pass of the substitution kernels (the columns of an
 // instance are right-hand sides j * B + bi of the same factors, IpmDev::rhs_mult)
@@ -254,10 +338,15 @@ void lb_launch_columns_and_solve(const IpmDev& D, hipStream_t st) {
   kkt_launch_solve(Dz, 1, st);
 }
 void lb_launch_small(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(lb_small_kernel, dim3(1, unsigned(D.B)), dim3(D.n >= 4096 ? 1024 : 256), 0, st, D);
+  const int nw = lb_waves(D.n);
+  hipLaunchKernelGGL(lb_cdots_kernel, dim3(lb_task_blocks(LB_TH * (LB_TH + 1) / 2, nw), unsigned(D.B)), dim3(256), 0, st, D, nw);
+  hipLaunchKernelGGL(lb_cfinish_kernel, dim3(unsigned((D.B + 63) / 64)), dim3(64), 0, st, D, nw);
 }
 void lb_launch_correct(const IpmDev& D, int check_status, hipStream_t st) {
-  hipLaunchKernelGGL(lb_correct_kernel, dim3(1, unsigned(D.B)), dim3(D.Nt >= 4096 ? 1024 : 256), 0, st, D, D.rhs, check_status);
+  const int nw = lb_waves(D.Nt);
+  const unsigned vb = unsigned(std::max(1, std::min(1024, (D.Nt + 255) / 256)));
+  hipLaunchKernelGGL(lb_wdots_kernel, dim3(lb_task_blocks(LB_TH, nw), unsigned(D.B)), dim3(256), 0, st, D, D.rhs, check_status, nw);
+  hipLaunchKernelGGL(lb_apply_kernel, dim3(vb, unsigned(D.B)), dim3(256), 0, st, D, D.rhs, check_status, nw);
 }
 
 }  // namespace rpm

@@ -197,11 +197,11 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
   A_(ipm_alloc(h, &D.vl0, B * p.nv)); A_(ipm_alloc(h, &D.vu0, B * p.nv));
   D.rhs_mult = 1;
   D.lb_on = lbfgs ? 1 : 0;
-  D.lb_S = D.lb_Y = D.lb_xprev = D.lb_gold = D.lb_small = D.lb_Z = nullptr;
+  D.lb_S = D.lb_Y = D.lb_xprev = D.lb_gold = D.lb_small = D.lb_Z = D.lb_part = nullptr;
   if (lbfgs) {
     A_(ipm_alloc(h, &D.lb_S, B * IPM_LB_H * p.n)); A_(ipm_alloc(h, &D.lb_Y, B * IPM_LB_H * p.n));
     A_(ipm_alloc(h, &D.lb_xprev, B * p.n)); A_(ipm_alloc(h, &D.lb_gold, B * p.nv));
-    A_(ipm_alloc(h, &D.lb_small, B * IPM_LB_SMALL));
+    A_(ipm_alloc(h, &D.lb_small, B * IPM_LB_SMALL)); A_(ipm_alloc(h, &D.lb_part, B * IPM_LB_PART));
     A_(ipm_alloc(h, &D.lb_Z, size_t(2 * IPM_LB_H) * B * size_t(p.Nt_alloc)));
   }
   {   // restoration phase and second-order correction work space (m >= 1 keeps the allocations non-empty)
