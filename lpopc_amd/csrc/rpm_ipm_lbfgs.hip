@@ -150,9 +150,8 @@ __global__ __launch_bounds__(256) void lb_mdots_kernel(IpmDev D, int nw) {
   const double* other = (k & 1) ? D.lb_Y + (size_t(bi) * IPM_LB_H + b) * n : D.lb_S + (size_t(bi) * IPM_LB_H + b) * n;
   lb_wave_sum(w, 64 * nw, n, [&](int i) { return sa[i] * other[i]; }, D.lb_part + size_t(bi) * LB_PART + k * 16 + w);
 }
-__global__ void lb_mfinish_kernel(IpmDev D, int nw) {
-  const int bi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bi >= D.B) return;
+__global__ __launch_bounds__(64) void lb_mfinish_kernel(IpmDev D, int nw) {      // one wave per instance: a lane per sum
+  const int bi = blockIdx.x, t = threadIdx.x;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0 || S.mode != 0) return;
   double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
@@ -161,19 +160,21 @@ __global__ void lb_mfinish_kernel(IpmDev D, int nw) {
   const double sigma = rec[0];
   double* M = rec + LB_M;
   const double* part = D.lb_part + size_t(bi) * LB_PART;
-  for (int q = 0; q < LB_TH * LB_TH; ++q) M[q] = (q / LB_TH == q % LB_TH) ? 1.0 : 0.0;     // identity on the unused indices
-  for (int a = 0; a < c; ++a)
-    for (int b = 0; b <= a; ++b) {
-      const int k = 2 * (a * (a + 1) / 2 + b);
-      const double ss = lb_fold(part + k * 16, nw), sy = lb_fold(part + (k + 1) * 16, nw);
-      M[a * LB_TH + b] = M[b * LB_TH + a] = sigma * ss;
-      if (a == b) {
-        M[(IPM_LB_H + a) * LB_TH + IPM_LB_H + a] = -sy;                  // -D
-      } else {                                                            // L(a, b) = s_a'y_b for a > b (strictly lower)
-        M[a * LB_TH + IPM_LB_H + b] = M[(IPM_LB_H + b) * LB_TH + a] = sy;
-        M[b * LB_TH + IPM_LB_H + a] = M[(IPM_LB_H + a) * LB_TH + b] = 0.0;
-      }
+  for (int q = t; q < LB_TH * LB_TH; q += 64) M[q] = (q / LB_TH == q % LB_TH) ? 1.0 : 0.0;     // identity on the unused indices
+  __syncthreads();
+  if (t < c * (c + 1) / 2) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    const int b = t - a * (a + 1) / 2, k = 2 * t;
+    const double ss = lb_fold(part + k * 16, nw), sy = lb_fold(part + (k + 1) * 16, nw);
+    M[a * LB_TH + b] = M[b * LB_TH + a] = sigma * ss;
+    if (a == b) {
+      M[(IPM_LB_H + a) * LB_TH + IPM_LB_H + a] = -sy;                  // -D
+    } else {                                                            // L(a, b) = s_a'y_b for a > b (strictly lower)
+      M[a * LB_TH + IPM_LB_H + b] = M[(IPM_LB_H + b) * LB_TH + a] = sy;
+      M[b * LB_TH + IPM_LB_H + a] = M[(IPM_LB_H + a) * LB_TH + b] = 0.0;
     }
+  }
 }
 
 // Z_j <- column j of E (Q at the positions of x, zero elsewhere), to be solved in place; blockIdx.x = column
@@ -215,41 +216,56 @@ __global__ __launch_bounds__(256) void lb_cdots_kernel(IpmDev D, int nw) {
   const double* zb = D.lb_Z + (size_t(b) * D.B + bi) * D.Nt;
   lb_wave_sum(w, 64 * nw, D.n, [&](int i) { return lb_q(D, bi, a, i, sigma) * zb[D.pos[i]]; }, D.lb_part + size_t(bi) * LB_PART + k * 16 + w);
 }
-__global__ void lb_cfinish_kernel(IpmDev D, int nw) {
-  const int bi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bi >= D.B) return;
+__global__ __launch_bounds__(LB_TH * LB_TH) void lb_cfinish_kernel(IpmDev D, int nw) {   // one workgroup per instance: a thread per entry of C
+  __shared__ double Cs[LB_TH * LB_TH];
+  __shared__ int pv;
+  const int bi = blockIdx.x, t = threadIdx.x, r = t / LB_TH, q = t % LB_TH;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0 || S.mode != 0) return;
   double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
   const int c = int(rec[1]);
   if (c == 0) return;
-  double* C = rec + LB_C;
-  const double* M = rec + LB_M;
   const double* part = D.lb_part + size_t(bi) * LB_PART;
-  for (int q = 0; q < LB_TH * LB_TH; ++q) C[q] = M[q];
-  int k = 0;
-  for (int ia = 0; ia < 2 * c; ++ia)
-    for (int ib = ia; ib < 2 * c; ++ib, ++k) {
-      const int a = ia < c ? ia : IPM_LB_H + ia - c, b = ib < c ? ib : IPM_LB_H + ib - c;
-      const double acc = lb_fold(part + k * 16, nw);
-      C[a * LB_TH + b] -= acc;
-      if (a != b) C[b * LB_TH + a] -= acc;    // K0 is symmetric: E'K0^-1E is
-    }
-  double* piv = rec + LB_PIV;
-  for (int k2 = 0; k2 < LB_TH; ++k2) {
-    int p = k2;
-    for (int r = k2 + 1; r < LB_TH; ++r)
-      if (fabs(C[r * LB_TH + k2]) > fabs(C[p * LB_TH + k2])) p = r;
-    piv[k2] = double(p);
-    if (p != k2)
-      for (int q = 0; q < LB_TH; ++q) { const double w = C[k2 * LB_TH + q]; C[k2 * LB_TH + q] = C[p * LB_TH + q]; C[p * LB_TH + q] = w; }
-    const double d = C[k2 * LB_TH + k2];
-    for (int r = k2 + 1; r < LB_TH; ++r) {
-      const double f = C[r * LB_TH + k2] / d;
-      C[r * LB_TH + k2] = f;
-      for (int q = k2 + 1; q < LB_TH; ++q) C[r * LB_TH + q] -= f * C[k2 * LB_TH + q];
-    }
+  Cs[t] = rec[LB_M + t];
+  __syncthreads();
+  if (t < c * (2 * c + 1)) {
+    int ia, ib;
+    lb_pair_of(t, 2 * c, &ia, &ib);
+    const int a = ia < c ? ia : IPM_LB_H + ia - c, b = ib < c ? ib : IPM_LB_H + ib - c;
+    const double acc = lb_fold(part + t * 16, nw);
+    Cs[a * LB_TH + b] -= acc;
+    if (a != b) Cs[b * LB_TH + a] -= acc;    // K0 is symmetric: E'K0^-1E is
   }
+  __syncthreads();
+  // LU with partial pivoting, the first largest entry of a column as the pivot; every entry sees the operations of the
+  // one-thread elimination in the same order
+  for (int k = 0; k < LB_TH; ++k) {
+    if (t == 0) {
+      int p = k;
+      for (int r2 = k + 1; r2 < LB_TH; ++r2)
+        if (fabs(Cs[r2 * LB_TH + k]) > fabs(Cs[p * LB_TH + k])) p = r2;
+      pv = p;
+      rec[LB_PIV + k] = double(p);
+    }
+    __syncthreads();
+    const int p = pv;
+    const bool swap = p != k && (r == k || r == p);      // whole rows change places
+    double other = 0.0;
+    if (swap) other = Cs[(r == k ? p : k) * LB_TH + q];
+    __syncthreads();
+    if (swap) Cs[t] = other;
+    __syncthreads();
+    const double d = Cs[k * LB_TH + k];
+    double f = 0.0;
+    if (r > k) f = Cs[r * LB_TH + k] / d;
+    __syncthreads();
+    if (r > k) {
+      if (q == k) Cs[t] = f;
+      else if (q > k) Cs[t] -= f * Cs[k * LB_TH + q];
+    }
+    __syncthreads();
+  }
+  rec[LB_C + t] = Cs[t];
 }
 
 // d <- d + Z (M - E'Z)^-1 E'd for the solution d of K0 d = r that sits in rhs: the sums q_a'd first ...
@@ -326,7 +342,7 @@ void lb_launch_update(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(lb_decide_kernel, dim3(ib), dim3(64), 0, st, D, nw);
   hipLaunchKernelGGL(lb_store_kernel, dim3(vb, B), dim3(256), 0, st, D);
   hipLaunchKernelGGL(lb_mdots_kernel, dim3(lb_task_blocks(IPM_LB_H * (IPM_LB_H + 1), nw), B), dim3(256), 0, st, D, nw);
-  hipLaunchKernelGGL(lb_mfinish_kernel, dim3(ib), dim3(64), 0, st, D, nw);
+  hipLaunchKernelGGL(lb_mfinish_kernel, dim3(B), dim3(64), 0, st, D, nw);
 }
 // Z = K0^-1 E: all 2 x history columns of every running instance in ONE pass of the substitution kernels (the columns of an
 // instance are right-hand sides j * B + bi of the same factors, IpmDev::rhs_mult)
@@ -340,7 +356,7 @@ void lb_launch_columns_and_solve(const IpmDev& D, hipStream_t st) {
 void lb_launch_small(const IpmDev& D, hipStream_t st) {
   const int nw = lb_waves(D.n);
   hipLaunchKernelGGL(lb_cdots_kernel, dim3(lb_task_blocks(LB_TH * (LB_TH + 1) / 2, nw), unsigned(D.B)), dim3(256), 0, st, D, nw);
-  hipLaunchKernelGGL(lb_cfinish_kernel, dim3(unsigned((D.B + 63) / 64)), dim3(64), 0, st, D, nw);
+  hipLaunchKernelGGL(lb_cfinish_kernel, dim3(unsigned(D.B)), dim3(LB_TH * LB_TH), 0, st, D, nw);
 }
 void lb_launch_correct(const IpmDev& D, int check_status, hipStream_t st) {
   const int nw = lb_waves(D.Nt);
