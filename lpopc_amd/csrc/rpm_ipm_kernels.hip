@@ -1972,6 +1972,27 @@ __global__ void kkt_gather_add_kernel(double* Kall, long long kstride, const int
     K[dst[i]] = acc;
   }
 }
+// v[dst[i]] += v[src[ptr[i]]] + v[src[ptr[i] + 1]] + ... in list order, a WAVE per destination: 64 sources are fetched at a time, then
+// every lane adds them up in order through shuffles (lane 0 stores).  The right-hand-side gather of the nested dissection: the
+// global border's rows collect one term from every interval — 256 on the metric problem, 88 us as 256 dependent loads of one
+// thread, a few microseconds this way — with the sums' order, and so their bits, unchanged.
+__global__ __launch_bounds__(256) void kkt_gather_seq_kernel(double* vall, long long vstride, const int* __restrict__ ptr, const int* __restrict__ src,
+                                                             const int* __restrict__ dst, int n, const IpmInst* inst, int check_status, int kmod) {
+  const int bi = blockIdx.y, bk = bi % kmod;
+  if (check_status && (inst[bk].status != 0 || (check_status == 2 && !inst[bk].soc_req))) return;
+  double* v = vall + size_t(bi) * vstride;
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n; i += n_waves) {
+    const int j0 = ptr[i], j1 = ptr[i + 1];
+    double acc = v[dst[i]];
+    for (int j = j0; j < j1; j += 64) {
+      const double mine = j + lane < j1 ? v[src[j + lane]] : 0.0;
+      const int m = min(64, j1 - j);
+      for (int k = 0; k < m; ++k) acc += __shfl(mine, k, 64);
+    }
+    if (lane == 0) v[dst[i]] = acc;
+  }
+}
 // mode 0: v[pos[i]] = 0;  mode 1: v[dst[i]] = v[src[i]]
 __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __restrict__ dst, const int* __restrict__ src, int n, int mode,
                                const IpmInst* inst, int check_status, int kmod) {
@@ -2047,8 +2068,8 @@ void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st, int for
   };
   auto gather = [&](const int* ptr, const int* src, const int* dst, int n) {
     if (!n) return;
-    const unsigned blocks = unsigned(std::max(1, std::min(256, (n + 255) / 256)));
-    hipLaunchKernelGGL(kkt_gather_add_kernel, dim3(blocks, VB), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, 0, 0, D.B);
+    const unsigned blocks = unsigned(std::max(1, std::min(4096, (n + 3) / 4)));           // a wave per destination
+    hipLaunchKernelGGL(kkt_gather_seq_kernel, dim3(blocks, VB), dim3(256), 0, st, D.rhs, (long long)D.Nt, ptr, src, dst, n, D.inst, check_status, D.B);
   };
   if (!(forward_done && kkt_level1_fused(D))) {                                        // (else kkt_factor_dense_kernel did both for this right-hand side)
     vec(D.gap_pos, nullptr, D.n_gap, 0);                                               // border work spaces start at zero

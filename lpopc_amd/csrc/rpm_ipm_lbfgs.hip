@@ -177,19 +177,18 @@ __global__ __launch_bounds__(64) void lb_mfinish_kernel(IpmDev D, int nw) {     
   }
 }
 
-// Z_j <- column j of E (Q at the positions of x, zero elsewhere), to be solved in place; blockIdx.x = column
-__global__ __launch_bounds__(1024) void lb_column_kernel(IpmDev D) {
-  const int bi = blockIdx.y, t = threadIdx.x, nt = blockDim.x, j = blockIdx.x;
+// Z_j <- column j of E (Q at the positions of x, zero elsewhere — the launcher has zeroed Z), to be solved in place;
+// blockIdx.x = column + 2 H x slice of the variables
+__global__ __launch_bounds__(256) void lb_column_kernel(IpmDev D) {
+  const int bi = blockIdx.y, j = blockIdx.x % LB_TH, slice = blockIdx.x / LB_TH, n_slices = gridDim.x / LB_TH;
   const IpmInst& S = D.inst[bi];
   if (S.status != 0) return;
-  double* z = D.lb_Z + (size_t(j) * D.B + bi) * D.Nt;
-  for (int p = t; p < D.Nt; p += nt) z[p] = 0.0;
   const double* rec = D.lb_small + size_t(bi) * IPM_LB_SMALL;
   const int c = int(rec[1]), a = j < IPM_LB_H ? j : j - IPM_LB_H;
   if (S.mode != 0 || a >= c) return;
-  __syncthreads();
+  double* z = D.lb_Z + (size_t(j) * D.B + bi) * D.Nt;
   const double sigma = rec[0];
-  for (int i = t; i < D.n; i += nt) z[D.pos[i]] = lb_q(D, bi, j, i, sigma);
+  for (int i = slice * blockDim.x + threadIdx.x; i < D.n; i += n_slices * blockDim.x) z[D.pos[i]] = lb_q(D, bi, j, i, sigma);
 }
 
 // C = M - E'Z and its LU factorisation (partial pivoting; 2 x history rows): the sums q_a'z_b, a <= b (sum ia (2 TH - ia + 1) / 2 + ib - ia
@@ -347,7 +346,9 @@ void lb_launch_update(const IpmDev& D, hipStream_t st) {
 // Z = K0^-1 E: all 2 x history columns of every running instance in ONE pass of the substitution kernels (the columns of an
 // instance are right-hand sides j * B + bi of the same factors, IpmDev::rhs_mult)
 void lb_launch_columns_and_solve(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(lb_column_kernel, dim3(unsigned(2 * IPM_LB_H), unsigned(D.B)), dim3(D.Nt >= 4096 ? 1024 : 256), 0, st, D);
+  (void)hipMemsetAsync(D.lb_Z, 0, size_t(2 * IPM_LB_H) * D.B * D.Nt * sizeof(double), st);
+  const int slices = std::max(1, std::min(64, (D.n + 1023) / 1024));
+  hipLaunchKernelGGL(lb_column_kernel, dim3(unsigned(2 * IPM_LB_H * slices), unsigned(D.B)), dim3(256), 0, st, D);
   IpmDev Dz = D;
   Dz.rhs = D.lb_Z;
   Dz.rhs_mult = 2 * IPM_LB_H;
