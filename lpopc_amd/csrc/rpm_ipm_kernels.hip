@@ -761,7 +761,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
       }
     }
     IPM_TICK(1);
-    if (wv == 0) {              // tile 0 holds the diagonal block (rows q < w): its LDL^T in the registers of 16 lanes
+    if (wv == 0) {              // tile 0 holds the diagonal block (rows q < w): its LDL^T and the inverse of L11 by this wave
+#if IPM_DIAG_SPLIT
+      // the accumulator tile is DiagStep's layout already: lane (lq, lr) holds columns lq + 4 g of row lr
+      double R[4], V[4];
+      int a_col[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = 4 * g + lq;
+        R[g] = (lr < w && j <= lr) ? acc[0][g] : (j == lr ? 1.0 : 0.0);
+        V[g] = j == lr ? 1.0 : 0.0;
+        a_col[g] = j << 2;
+      }
+      DiagStep<0>::run(R, V, lq, lr, lr << 2, a_col);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = 4 * g + lq;
+        if (lr < w && j <= lr) Dg[lr * (W + 1) + j] = R[g];
+        Mi[lr * W + j] = V[g];
+        if (j == lr) invd[lr] = lr < w ? 1.0 / R[g] : 0.0;
+      }
+#else
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = lq + 4 * g;
@@ -802,6 +822,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
         }
         invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
       }
+#endif
     }
     __syncthreads();
     IPM_TICK(2);
