@@ -1399,11 +1399,23 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       }
     }
     fetch(blk - 1, dg, l);      // in flight across the reduction and the diagonal solve
+    {   // the 16 sums over the wave, each by the same tree as `for (o = 32; o; o >>= 1) v += shfl_down(v, o)` (lane l + lane l + o:
+        // the same pairs, a + b for b + a at most), but the columns are dealt out while the lanes fold: 8 + 4 + 2 + 1 + 1 + 1
+        // exchanges instead of 16 x 6 — column c's sum ends in lane 4 c.  (The LDS pipe, which carries the exchanges, bounded the
+        // backward pass when 12 right-hand sides of the limited-memory update run side by side.)
+      const int ln = t & 63;
+      double q8[8], q4[4], q2[2], u;
+      const bool h32 = ln & 32, h16 = ln & 16, h8 = ln & 8, h4 = ln & 4;
 #pragma unroll
-    for (int c = 0; c < W; ++c) {
-      double sacc = p[c];
-      for (int o = 32; o; o >>= 1) sacc += __shfl_down(sacc, o);
-      if ((t & 63) == 0) red[t >> 6][c] = sacc;
+      for (int i = 0; i < 8; ++i) q8[i] = (h32 ? p[i + 8] : p[i]) + __shfl_xor(h32 ? p[i] : p[i + 8], 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q4[i] = (h16 ? q8[i + 4] : q8[i]) + __shfl_xor(h16 ? q8[i] : q8[i + 4], 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) q2[i] = (h8 ? q4[i + 2] : q4[i]) + __shfl_xor(h8 ? q4[i] : q4[i + 2], 8);
+      u = (h4 ? q2[1] : q2[0]) + __shfl_xor(h4 ? q2[0] : q2[1], 4);
+      u += __shfl_xor(u, 2);
+      u += __shfl_xor(u, 1);
+      if ((ln & 3) == 0) red[t >> 6][ln >> 2] = u;
     }
     __syncthreads();
     if (t < W) zs[t] = t < B.w ? r[B.J0 + t] / Dg[t * (W + 1) + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]) : 0.0;
