@@ -108,10 +108,15 @@ __device__ inline bool vec_combine(const IpmDev& D, int bi, double (&vals)[N], c
   __syncthreads();
   if (!last_arrival) return false;
   __threadfence();
+  // the partial results into LDS side by side (as G x N dependent loads of every thread they took 20 us of a 30 us kernel on the
+  // metric problem), then added up in workgroup order as before
+  __shared__ double staged[IPM_VEC_BLOCKS * N];
+  for (int idx = threadIdx.x; idx < G * N; idx += blockDim.x) staged[idx] = P[size_t(idx / N) * IPM_VEC_PART + idx % N];
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < N; ++k) vals[k] = kind[k] == 0 ? 0.0 : (kind[k] == 1 ? -1e300 : 1e300);
   for (int b = 0; b < G; ++b) {
-    const double* q = P + size_t(b) * IPM_VEC_PART;
+    const double* q = staged + b * N;
 #pragma unroll
     for (int k = 0; k < N; ++k) vals[k] = kind[k] == 0 ? vals[k] + q[k] : (kind[k] == 1 ? fmax(vals[k], q[k]) : fmin(vals[k], q[k]));
   }
@@ -1435,20 +1440,20 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
 
 // ------------------------------------------------------------------------------------------------ inertia correction
 // Algorithm IC: the factorisation is accepted when D has exactly nv positive entries (and no zero / NaN pivot)
-__global__ void ipm_inertia_kernel(IpmDev D) {
-  const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void ipm_inertia_kernel(IpmDev D) {   // a wave per instance: its lanes add up the sub-problems' pivot counts
+  const int bi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (bi >= D.B) return;
   IpmInst& S = D.inst[bi];
   if (S.status != 0 || !S.refactor) return;
   const IpmOpts& o = D.o;
-  {   // pivot signs of all the sub-problems of this instance (one without dissection)
-    int np = 0, nn = 0, nz = 0;
-    for (int s2 = 0; s2 < D.n_sub; ++s2) {
-      const int* q = D.piv + (size_t(bi) * D.n_sub + s2) * 3;
-      np += q[0]; nn += q[1]; nz += q[2];
-    }
-    S.npos = np; S.nneg = nn; S.nbad = nz;
+  int np = 0, nn = 0, nz = 0;
+  for (int s2 = lane; s2 < D.n_sub; s2 += 64) {   // pivot signs of all the sub-problems of this instance (one without dissection)
+    const int* q = D.piv + (size_t(bi) * D.n_sub + s2) * 3;
+    np += q[0]; nn += q[1]; nz += q[2];
   }
+  for (int w = 32; w; w >>= 1) { np += __shfl_xor(np, w); nn += __shfl_xor(nn, w); nz += __shfl_xor(nz, w); }
+  if (lane != 0) return;
+  S.npos = np; S.nneg = nn; S.nbad = nz;
   if (S.npos == D.nv && S.nbad == 0) {
     S.refactor = 0;
     if (S.delta_w > 0) S.delta_w_last = S.delta_w;
@@ -1947,7 +1952,7 @@ void ipm_launch_assemble(const IpmDev& D, int nnz_max, hipStream_t st) {
   hipLaunchKernelGGL(ipm_assemble_kernel, dim3(unsigned(assemble_blocks), unsigned(D.B)), dim3(256), 0, st, D);
 }
 void ipm_launch_inertia(const IpmDev& D, hipStream_t st) {
-  hipLaunchKernelGGL(ipm_inertia_kernel, dim3(unsigned((D.B + 255) / 256)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_inertia_kernel, dim3(unsigned((D.B + 3) / 4)), dim3(256), 0, st, D);
 }
 void ipm_launch_direction(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_direction_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);

@@ -562,6 +562,9 @@ int rpm_ipm_debug_solve_dense(rpm_ipm* h, const double* k_dense, const double* r
   // kkt_factor_dense_kernel (build with -DIPM_TIMING_SUB=<out of range>): tile wave 0 and the diagonal wave of interval block 0
   fprintf(stderr, "level-1 phases of instance 0 [100 MHz ticks]: panel %lld  wait B3 %lld  next diagonal tile + B1 %lld  update %lld  wait B2 %lld | diagonal wave: waiting %lld  factoring %lld\n",
           inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[6], inst[0].dbg[7]);
+  // kkt_factor_kernel (-DIPM_TIMING_SUB=<sub-problem>): the same record read as the left-looking kernel's phases
+  fprintf(stderr, "left-looking phases of instance 0 [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld\n",
+          inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[5]);
 #endif
   for (size_t bi = 0; bi < B; ++bi) {
     for (size_t a = 0; a < Nt; ++a) sol[bi * Nt + a] = r[bi * p.Nt_alloc + p.pos[a]];
