@@ -41,17 +41,30 @@ __global__ __launch_bounds__(256) void rpm_delta_copy_kernel(const RunDev* __res
   const int t = threadIdx.x;
   const unsigned long long* f = reinterpret_cast<const unsigned long long*>(fresh) + r.off;
   unsigned long long* mi = mirror + r.off;
-  const bool in0 = t < r.len, in1 = t + 256 < r.len;
-  const unsigned long long a0 = in0 ? f[t] : 0ull, a1 = in1 ? f[t + 256] : 0ull;
+  unsigned long long* h = reinterpret_cast<unsigned long long*>(host) + r.off;
+  // a thread takes two neighbouring entries: 16-byte stores over PCIe (1 KB per wave instruction) where the run starts on a
+  // 16-byte boundary of all three arrays, else the entries t and t + 256
+  const bool wide = ((reinterpret_cast<size_t>(f) | reinterpret_cast<size_t>(mi) | reinterpret_cast<size_t>(h)) & 15) == 0;
+  const int i0 = wide ? 2 * t : t, i1 = wide ? 2 * t + 1 : t + 256;
+  const bool in0 = i0 < r.len, in1 = i1 < r.len;
+  unsigned long long a0 = 0ull, a1 = 0ull;
+  if (wide && in1) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(f + i0); a0 = v.x; a1 = v.y; }
+  else { a0 = in0 ? f[i0] : 0ull; a1 = in1 ? f[i1] : 0ull; }
   int differ = force;
   if (!force) {
-    const unsigned long long m0 = in0 ? mi[t] : 0ull, m1 = in1 ? mi[t + 256] : 0ull;
+    unsigned long long m0 = 0ull, m1 = 0ull;
+    if (wide && in1) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(mi + i0); m0 = v.x; m1 = v.y; }
+    else { m0 = in0 ? mi[i0] : 0ull; m1 = in1 ? mi[i1] : 0ull; }
     differ = (a0 != m0) || (a1 != m1);
   }
   if (!__syncthreads_or(differ)) return;
-  unsigned long long* h = reinterpret_cast<unsigned long long*>(host) + r.off;
-  if (in0) { h[t] = a0; mi[t] = a0; }
-  if (in1) { h[t + 256] = a1; mi[t + 256] = a1; }
+  if (wide && in1) {
+    *reinterpret_cast<ulonglong2*>(h + i0) = make_ulonglong2(a0, a1);
+    *reinterpret_cast<ulonglong2*>(mi + i0) = make_ulonglong2(a0, a1);
+  } else {
+    if (in0) { h[i0] = a0; mi[i0] = a0; }
+    if (in1) { h[i1] = a1; mi[i1] = a1; }
+  }
   if (sent_runs && t == 0) atomicAdd(sent_runs, 1u);
 }
 
