@@ -730,6 +730,7 @@ def main():
             },
         }
     xs_main = xs
+    stored_bytes_per_launch = B * (eng.m + eng.nnz_jac) * 8
     eng.close()
     del d_x, d_g, d_v
     ctx.torch.cuda.empty_cache()
@@ -737,7 +738,12 @@ def main():
         try:   # normalise by what this box's write path delivers to the same store pattern, measured now
             sc = store_ceiling(ctx)
             out["roofline"]["measured_store_ceiling"] = sc
-            out["roofline"]["frac_of_measured_store_ceiling"] = out["roofline"]["achieved"] / sc["pattern_512B_runs_GBs"]
+            # like with like: the bytes the kernel STORES per launch (g and the Jacobian values of every resident iterate: what
+            # rocprofv3's WRITE_SIZE counts, profiles/pmc_traffic.json) over its launch time, against the pure store stream;
+            # `achieved` above also counts the algorithmic reads of SURVEY 8(d), most of which the caches serve
+            out["roofline"]["stored_bytes_per_launch"] = stored_bytes_per_launch
+            out["roofline"]["store_rate_GBs"] = stored_bytes_per_launch / (out["roofline"]["avg_launch_us"] * 1e-6) / 1e9
+            out["roofline"]["frac_of_measured_store_ceiling"] = out["roofline"]["store_rate_GBs"] / sc["pattern_512B_runs_GBs"]
         except Exception as ex:
             errors["store_ceiling"] = repr(ex)
 
