@@ -361,7 +361,10 @@ struct QuadrotorProblem {
     const double tx = c[2] * (f4[1] - f4[3]);
     const double ty = c[2] * (f4[2] - f4[0]);
     const double tz = c[6] * (((f4[0] - f4[1]) + f4[2]) - f4[3]);
-    const double sph = sin(ph), cph = cos(ph), sth = sin(th), cth = cos(th), sps = sin(ps), cps = cos(ps);
+    double sph, cph, sth, cth, sps, cps;     // (one argument reduction for the pair: sincos)
+    sincos(ph, &sph, &cph);
+    sincos(th, &sth, &cth);
+    sincos(ps, &sps, &cps);
     const double b3x = cph * sth * cps + sph * sps;
     const double b3y = cph * sth * sps - sph * cps;
     const double b3z = cph * cth;
