@@ -734,7 +734,7 @@ def main():
     eng.close()
     del d_x, d_g, d_v
     ctx.torch.cuda.empty_cache()
-    if rank == 0 and not args.profile:
+    if rank == 0 and not args.profile and not args.persistent:
         try:   # normalise by what this box's write path delivers to the same store pattern, measured now
             sc = store_ceiling(ctx)
             out["roofline"]["measured_store_ceiling"] = sc

@@ -338,6 +338,11 @@ int rpm_synchronize(rpm_engine* e);
  *                    persistent pipelined kernel (4 compute waves + 1 DMA wave per workgroup; inputs of the next tile
  *                    prefetched, constant block written by the DMA wave); automatic = every resident workgroup has
  *                    at least two tiles.  get-only "pipeline_active": 1 if the next launch uses it
+ * "stage_roles"      -1 (default) | 0 | 1: in the pipelined kernel, problem functors that offer their dynamics in stages
+ *                    (csrc/problems/problems.hpp `has_stage`: the launch vehicle, the quadrotor) are evaluated in full once per
+ *                    node and per perturbation role only in what the perturbed variable enters — the same operations, the
+ *                    same bits; -1: where the launch skips the constant block ("persistent_values"), which is bound by the
+ *                    dynamics; with all stores the extra registers cost more than the arithmetic saves
  * "instance_align"   1 (default) or any power of two up to 65536 doubles: in the device-resident calls with n_instances > 1 the g /
  *                    values arrays of consecutive instances are rpm_get_option "stride_g" / "stride_values" doubles
  *                    apart (m, nnz_jac rounded up to this multiple) instead of packed back to back, so that every

@@ -19,6 +19,7 @@
 // vectorised expressions so that results agree with lpopc's CPU path to rounding of libm.
 // Paths below are relative to /root/reference/Lpopc.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "../../../include/rpm_hip.h"
@@ -37,6 +38,21 @@ RPM_DEV void pf_dae(int ph, double t, const double* x, const double* u, const do
   if constexpr (prob_nq<P>::value > 0) P::dae(ph, t, x, u, p, c, f, cp);
   else P::dae(ph, t, x, u, c, f, cp);
 }
+// Optional, for the finite-difference kernels that walk several perturbation roles of one node in one thread: a functor may
+// offer  struct Stage,  stage(ph, t, x, u, c, Stage&)  — the sub-expressions of dae() at the unperturbed point — and
+// dae_from(ph, t, x, u, c, const Stage& base, int var, f, p)  = dae() at a point that differs from the base in variable `var`
+// ONLY ([x.., u.., t]; -1: the base itself), which recomputes just what depends on that variable.  Same operations on the same
+// operands, so the same bits as dae(): of the metric problem's 13 evaluations per node only 4 need the exponential, the
+// cube and the first square root again.  (Problems without static parameters.)
+template <class P, class = void>
+struct has_stage : std::false_type {};
+template <class P>
+struct has_stage<P, std::void_t<typename P::Stage>> : std::true_type {};
+template <class P, bool = has_stage<P>::value>
+struct stage_of { struct type {}; };
+template <class P>
+struct stage_of<P, true> { using type = typename P::Stage; };
+
 template <class P, class CP>
 RPM_DEV void pf_dae_jac_col(int ph, int v, double t, const double* x, const double* u, const double* p, CP c, double* df, double* dc) {
   if constexpr (prob_nq<P>::value > 0) P::dae_jac_col(ph, v, t, x, u, p, c, df, dc);
@@ -152,6 +168,82 @@ struct LaunchProblem {
       f[3 + j] = (Toverm * u[j] + drag) + grav;                        // :733
     }
     f[6] = mdot;
+  }
+
+  // The same in stages (has_stage): what depends on the position only, on position and velocity, on the mass.
+  struct Stage { double ocr[3], vrel[3], rho, mu3, speedrel, bc, T_tot, mdot; };
+  template <class CP = const double*>
+  RPM_DEV static void stage_r(const double* x, CP c, Stage& s) {        // position: rad, density, gravity factor, omega x r
+    const double r0 = x[0], r1 = x[1], r2 = x[2];
+    const double rad = sqrt((r0 * r0 + r1 * r1) + r2 * r2);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      double ocr = 0.0;
+      ocr += r0 * c[cc + 0];
+      ocr += r1 * c[cc + 3];
+      ocr += r2 * c[cc + 6];
+      s.ocr[cc] = ocr;
+    }
+    const double altitude = rad - c[14];
+    s.rho = exp(-altitude / c[13]) * c[12];
+    s.mu3 = (1.0 * c[9]) / cube_rn(rad);
+  }
+  RPM_DEV static void stage_v(const double* x, Stage& s) {              // velocity (after stage_r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) s.vrel[cc] = x[3 + cc] - s.ocr[cc];
+    s.speedrel = sqrt((s.vrel[0] * s.vrel[0] + s.vrel[1] * s.vrel[1]) + s.vrel[2] * s.vrel[2]);
+  }
+  template <class CP = const double*>
+  RPM_DEV static void stage_m(const double* x, CP c, Stage& s) {        // mass (after stage_r)
+    s.bc = s.rho / (x[6] * 2) * (c[11] * c[10]);
+  }
+  template <class CP = const double*>
+  RPM_DEV static void stage_ph(int ph, CP c, Stage& s) {                // the phase's thrust and mass flow
+    double T_tot, mdot;
+    if (ph == 1 || ph == 2) {
+      const double T_srb = 1.0 * ((ph == 1 ? 6 : 3) * c[16]);
+      const double T_first = 1.0 * c[17];
+      T_tot = T_srb + T_first;
+      double m1dot = 0.0, m2dot = 0.0;
+      m1dot -= T_srb / (c[15] * c[19]);
+      m2dot -= T_first / (c[15] * c[20]);
+      mdot = m1dot + m2dot;
+    } else if (ph == 3) {
+      T_tot = 1.0 * c[17];
+      mdot = 0.0;
+      mdot -= T_tot / (c[15] * c[20]);
+    } else {
+      T_tot = 1.0 * c[18];
+      mdot = 0.0;
+      mdot -= T_tot / (c[15] * c[21]);
+    }
+    s.T_tot = T_tot;
+    s.mdot = mdot;
+  }
+  template <class CP = const double*>
+  RPM_DEV static void stage(int ph, double, const double* x, const double*, CP c, Stage& s) {
+    stage_r(x, c, s);
+    stage_v(x, s);
+    stage_m(x, c, s);
+    stage_ph(ph, c, s);
+  }
+  template <class CP = const double*>
+  RPM_DEV static void dae_from(int, double, const double* x, const double* u, CP c, const Stage& base, int var, double* f, double* p) {
+    Stage s = base;
+    if (var >= 0 && var < 3) { stage_r(x, c, s); stage_v(x, s); stage_m(x, c, s); }
+    else if (var >= 3 && var < 6) stage_v(x, s);
+    else if (var == 6) stage_m(x, c, s);
+    const double bcspeed = s.bc * s.speedrel;
+    p[0] = (u[0] * u[0] + u[1] * u[1]) + u[2] * u[2];
+    const double Toverm = s.T_tot / x[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double drag = (bcspeed * (-1.0)) * s.vrel[j];
+      const double grav = (-s.mu3) * x[j];
+      f[j] = x[3 + j];
+      f[3 + j] = (Toverm * u[j] + drag) + grav;
+    }
+    f[6] = s.mdot;
   }
 
   // Armadillo 5.300.4 dot() on 3-vectors: (a0 b0 + a2 b2) + a1 b1
@@ -365,6 +457,44 @@ struct QuadrotorProblem {
     sincos(ph, &sph, &cph);
     sincos(th, &sth, &cth);
     sincos(ps, &sps, &cps);
+    const double b3x = cph * sth * cps + sph * sps;
+    const double b3y = cph * sth * sps - sph * cps;
+    const double b3z = cph * cth;
+    const double Fm = F / c[0];
+    f[0] = x[3];
+    f[1] = x[4];
+    f[2] = x[5];
+    f[3] = Fm * b3x;
+    f[4] = Fm * b3y;
+    f[5] = Fm * b3z - c[1];
+    const double w = q * sph + r * cph;
+    f[6] = p + w * (sth / cth);
+    f[7] = q * cph - r * sph;
+    f[8] = w / cth;
+    f[9] = (tx - (c[5] - c[4]) * q * r) / c[3];
+    f[10] = (ty - (c[3] - c[5]) * p * r) / c[4];
+    f[11] = (tz - (c[4] - c[3]) * p * q) / c[5];
+  }
+  // In stages (has_stage): the three sine / cosine pairs are all that is worth keeping
+  struct Stage { double sph, cph, sth, cth, sps, cps; };
+  template <class CP = const double*>
+  RPM_DEV static void stage(int, double, const double* x, const double*, CP, Stage& s) {
+    sincos(x[6], &s.sph, &s.cph);
+    sincos(x[7], &s.sth, &s.cth);
+    sincos(x[8], &s.sps, &s.cps);
+  }
+  template <class CP = const double*>
+  RPM_DEV static void dae_from(int, double, const double* x, const double* f4, CP c, const Stage& base, int var, double* f, double*) {
+    Stage s = base;
+    if (var == 6) sincos(x[6], &s.sph, &s.cph);
+    else if (var == 7) sincos(x[7], &s.sth, &s.cth);
+    else if (var == 8) sincos(x[8], &s.sps, &s.cps);
+    const double p = x[9], q = x[10], r = x[11];
+    const double F = ((f4[0] + f4[1]) + f4[2]) + f4[3];
+    const double tx = c[2] * (f4[1] - f4[3]);
+    const double ty = c[2] * (f4[2] - f4[0]);
+    const double tz = c[6] * (((f4[0] - f4[1]) + f4[2]) - f4[3]);
+    const double sph = s.sph, cph = s.cph, sth = s.sth, cth = s.cth, sps = s.sps, cps = s.cps;
     const double b3x = cph * sth * cps + sph * sps;
     const double b3y = cph * sth * sps - sph * cps;
     const double b3z = cph * cth;

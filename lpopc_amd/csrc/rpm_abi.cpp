@@ -571,6 +571,9 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
   } else if (k == "pipeline") {
     if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "pipeline must be -1 (auto), 0 or 1");
     e.opt_pipeline = value;
+  } else if (k == "stage_roles") {
+    if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "stage_roles must be -1 (auto), 0 or 1");
+    e.opt_stage_roles = value;
   } else if (k == "role_loop") {
     if (value < -1 || value > 1) return fail(e, RPM_E_INVALID, "role_loop must be -1 (auto), 0 or 1");
     if (e.dev) return fail(e, RPM_E_INVALID, "role_loop must be set before the device is initialised");
@@ -599,6 +602,7 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "n_tiles") *value = int(e.tiles.size());
   else if (k == "role_loop") *value = e.role_looped ? 1 : 0;
   else if (k == "pipeline") *value = e.opt_pipeline;
+  else if (k == "stage_roles") *value = e.opt_stage_roles;
   else if (k == "const_once") *value = e.opt_const_once;
   else if (k == "instance_align") *value = e.opt_instance_align;
   else if (k == "delta_values") *value = e.opt_delta_values;

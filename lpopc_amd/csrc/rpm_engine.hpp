@@ -167,6 +167,7 @@ struct Engine {
   int opt_instance_align = 1;    // device-resident batched calls: every instance's g / values array starts on a multiple of this many doubles
   long long stride_g() const { return (long long)(m + opt_instance_align - 1) / opt_instance_align * opt_instance_align; }
   long long stride_values() const { return (long long)(nnz_jac + opt_instance_align - 1) / opt_instance_align * opt_instance_align; }
+  int opt_stage_roles = -1;      // pipelined kernel: functors with a staged dae (problems.hpp has_stage) recompute per role only what the perturbed variable enters; -1: when the constant block is skipped
   int opt_pipeline = -1;         // rpm_tile_pl_kernel: -1 automatic (>= 2 tiles per resident workgroup), 0 never, 1 whenever the mesh fits
   int jac_nonfinite = -1;                 // verdict on the cached Jacobian of the fused pair launch (-1: not checked)
   const double* const_filled = nullptr;   // host `values` buffer whose LIN/CONST tail this engine wrote last (const_once)

@@ -17,6 +17,7 @@
 // dynamics, role 1+v the dynamics with variable v perturbed (v = states, controls, time) — the
 // reference's (2+nx+nu) whole-vector user calls become (2+nx+nu) roles evaluated concurrently.
 // State roles also compute their state's D.X row from the LDS-staged D rows and X tile.
+#include <cstdlib>
 #include "rpm_device_internal.hpp"
 
 namespace rpm {
@@ -780,7 +781,7 @@ constexpr PlShape pl_shape(int R) { return R <= 12 ? PlShape{2, 4, 2} : PlShape{
 // (Tried for the one-half shape, R > 12 roles: __launch_bounds__(..., 6) so that two 11-wave workgroups share a CU and one's
 // store phases overlap the other's dynamics.  The quadrotor kernel needs ~156 VGPRs; at 80 it spills 76 of them and the
 // 1024-instance sweep takes 89.9 us instead of 51 — DESIGN.md §4.)
-template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN, bool DXM = false>
+template <class Prob, int NH, int RG, int NDMA, bool WG, bool WJ, bool AN, bool DXM = false, bool STG = false>
 __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
     const KParams K, int n_inst, const double* __restrict__ xall, double* __restrict__ gall,
     double* __restrict__ vall) {
@@ -989,6 +990,19 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
     const int k = k0 + kc;
     const bool node_ok = kk < cnt;
     bool first = true;
+    // STG (has_stage functors): the sub-expressions of the dynamics at the node's unperturbed point, once per wave and tile; a
+    // role then recomputes only what its one perturbed variable enters (same operations, same bits as the whole dae())
+    typename stage_of<Prob>::type base_stage;
+    if constexpr (STG) {
+      static_assert(NQ == 0 && !AN, "staged evaluation: finite differences, no static parameters");
+      double xs0[NXs], us0[NUs];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xs0[i] = Xs[i * K.max_span + (k - span0)];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) us0[j] = Us[j * T + kc];
+      const double tau0 = cur[S_TAU + kc], t00 = cur[S_TT], tf0 = cur[S_TT + 1];
+      Prob::stage(phase_num, (tau0 + 1) * ((tf0 - t00) / 2.0) + t00, xs0, us0, c4, base_stage);
+    }
     // per-pass scalars (tau, t0, tf, the node record, the diagonal of D) are re-read from LDS where they are used
     // instead of living in registers across the dynamics call: the 10-wave workgroup has 168 VGPRs per lane
     for (int role = grp; role < R || first; role += RG) {
@@ -1051,7 +1065,9 @@ __global__ __launch_bounds__(NH * 64 * (RG + NDMA), 1) void rpm_tile_pl_kernel(
         for (int j = 0; j < NQ; ++j) us[NU + j] = (v == NX + NU + 1 + j) ? pp : us[NU + j];
       }
       double f[NXs], cp[NCs];
-      if (!AN || role == 0) {
+      if constexpr (STG) {
+        Prob::dae_from(phase_num, tk, xs, us, c4, base_stage, (WJ && role >= 1) ? v : -1, f, cp);
+      } else if (!AN || role == 0) {
         pf_dae<Prob>(phase_num, tk, xs, us, us + NU, c4, f, cp);
       } else if constexpr (AN) {
         pf_dae_jac_col<Prob>(phase_num, v, tk, xs, us, us + NU, c4, f, cp);
@@ -1214,11 +1230,20 @@ static bool pl_dxm_ok(const Engine& e) {
   return e.first_derive != RPM_DERIVE_ANALYTIC && e.dev->pl_lds + pl_dxm_extra(e) <= 160 * 1024;
 }
 
-template <class Prob, bool WG, bool WJ, bool AN, bool DXM = false>
+template <class Prob, bool WG, bool WJ, bool AN, bool DXM = false, bool STG = false>
 static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const double* dx, double* dg, double* dv, hipStream_t st) {
+  if constexpr (!STG && !AN && has_stage<Prob>::value) {
+    // engine option "stage_roles": 1 the functor's staged dynamics, 0 whole-function evaluations, -1 (default) staged when the
+    // launch is bound by the dynamics and not by its stores — persistent `values` (kp.skip_const).  Measured on the metric
+    // problem, 64 iterates per launch: 75.3 -> 69.5 us with the constant block skipped, but 99.2 -> 106.6 us with all stores (21
+    // more registers in a kernel that waits for its stores); same bits either way
+    static const bool env_off = std::getenv("RPM_STAGE_ROLES") && std::atoi(std::getenv("RPM_STAGE_ROLES")) == 0;   // measurements
+    if (!env_off && (e.opt_stage_roles == 1 || (e.opt_stage_roles < 0 && kp.skip_const)))
+      return launch_tile_pl<Prob, WG, WJ, AN, DXM, true>(e, kp, dx, dg, dv, st);
+  }
   const Device& d = *e.dev;
   constexpr PlShape S = pl_shape(Prob::NX + Prob::NU + 2 + prob_nq<Prob>::value);
-  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN, DXM>;
+  auto kern = rpm_tile_pl_kernel<Prob, S.NH, S.RG, S.NDMA, WG, WJ, AN, DXM, STG>;
   const size_t lds = d.pl_lds + (DXM ? size_t(S.NH) * Prob::NX * 64 * sizeof(double) : 0);
   if (lds > 64 * 1024) {
     hipError_t s = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

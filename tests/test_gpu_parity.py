@@ -279,6 +279,46 @@ def test_mfma_dx_mode_in_the_pipelined_kernel(built, name, make, mode, B):
     assert not np.array_equal(g1, g0) or name == "bryson_denham"   # the matrix cores really were used (different rounding)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,mode,B", [("launch_metric", lambda: problems.config("launch"), "perturb", 18), ("launch_ragged", _launch_ragged, "perturb", 150),
+                                              ("quadrotor_8x8", lambda: problems.quadrotor(8, 8), "perturb", 300)],
+                         ids=["launch_metric", "launch_ragged", "quadrotor_8x8"])
+def test_staged_dynamics_in_the_pipelined_kernel(built, name, make, mode, B):
+    """Option stage_roles (default -1: where the launch skips the constant block, persistent_values): functors that offer their dynamics in stages (problems.hpp has_stage: the launch vehicle,
+    the quadrotor) are evaluated once per node in full and per perturbation role only in what the perturbed variable enters.
+    Same operations on the same operands: g and every Jacobian value equal the whole-function evaluation's bit for bit, also
+    with only g or only the Jacobian asked for."""
+    import torch
+    prob = make()
+    orc = oracle_for(prob)
+    xl, xu, _, _ = orc.bounds()
+    xs = np.stack([problems.seeded_iterate(orc.starting_point(), xl, xu, 90 + i, mode) for i in range(B)])
+    dx = torch.from_numpy(xs).cuda()
+    out = []
+    for staged in (1, 0):
+        eng = NLPEngine(prob, n_instances=B, device=0, role_loop=1)
+        eng.set_option("pipeline", 1)
+        assert eng.get_option("stage_roles") == -1         # the default: staged only where the launch is bound by the dynamics
+        eng.set_option("stage_roles", staged)
+        dg = torch.full((B, eng.m), np.nan, dtype=torch.float64, device="cuda")
+        dv = torch.full((B, eng.nnz_jac), np.nan, dtype=torch.float64, device="cuda")
+        eng.eval_pair_dev(dx, dg, dv)
+        dg2 = torch.full((B, eng.m), np.nan, dtype=torch.float64, device="cuda")
+        dv2 = torch.full((B, eng.nnz_jac), np.nan, dtype=torch.float64, device="cuda")
+        eng.eval_g_dev(dx, dg2)
+        eng.eval_jac_g_dev(dx, dv2)
+        torch.cuda.synchronize()
+        assert eng.get_option("pipeline_active") == 1
+        assert torch.equal(dg, dg2) and torch.equal(dv, dv2)
+        out.append((dg.cpu().numpy(), dv.cpu().numpy()))
+        eng.close()
+    (g1, v1), (g0, v0) = out
+    assert not np.isnan(g1).any() and not np.isnan(v1).any()
+    assert np.array_equal(g1, g0) and np.array_equal(v1, v0)
+    for b in (0, B - 1):
+        assert np.max(np.abs(g1[b] - orc.eval_g(xs[b])) / np.maximum(1.0, np.abs(g0[b]))) <= 1e-12
+
+
 # ---- exact Hessian (hessian-approximation=exact): forward second differences, LpHessian.cpp ------------------
 def _exact():
     o = Options()
