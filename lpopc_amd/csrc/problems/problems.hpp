@@ -245,6 +245,18 @@ struct LaunchProblem {
     }
     f[6] = s.mdot;
   }
+  // ... and at a point that differs from the base in variables va and vb (second differences, rpm_hess_kernel)
+  template <class CP = const double*>
+  RPM_DEV static void dae_from2(int ph, double t, const double* x, const double* u, CP c, const Stage& base, int va, int vb, double* f, double* p) {
+    Stage s = base;
+    const bool r = (va >= 0 && va < 3) || (vb >= 0 && vb < 3), v = (va >= 3 && va < 6) || (vb >= 3 && vb < 6), m = va == 6 || vb == 6;
+    if (r) { stage_r(x, c, s); stage_v(x, s); stage_m(x, c, s); }
+    else {
+      if (v) stage_v(x, s);
+      if (m) stage_m(x, c, s);
+    }
+    dae_from(ph, t, x, u, c, s, -1, f, p);
+  }
 
   // Armadillo 5.300.4 dot() on 3-vectors: (a0 b0 + a2 b2) + a1 b1
   RPM_DEV static double dot3(const double* a, const double* b) {
@@ -512,6 +524,14 @@ struct QuadrotorProblem {
     f[9] = (tx - (c[5] - c[4]) * q * r) / c[3];
     f[10] = (ty - (c[3] - c[5]) * p * r) / c[4];
     f[11] = (tz - (c[4] - c[3]) * p * q) / c[5];
+  }
+  template <class CP = const double*>
+  RPM_DEV static void dae_from2(int ph, double t, const double* x, const double* f4, CP c, const Stage& base, int va, int vb, double* f, double* p) {
+    Stage s = base;
+    if (va == 6 || vb == 6) sincos(x[6], &s.sph, &s.cph);
+    if (va == 7 || vb == 7) sincos(x[7], &s.sth, &s.cth);
+    if (va == 8 || vb == 8) sincos(x[8], &s.sps, &s.cps);
+    dae_from(ph, t, x, f4, c, s, -1, f, p);
   }
   RPM_DEV static void event(int, double, const double*, double, const double*, const double*, double*) {}
   RPM_DEV static void link(int, int, const double*, const double*, const double*, int, double*) {}

@@ -90,7 +90,28 @@ __global__ void rpm_hess_kernel(const KParams K, const HParams Hp, const double*
     if (b == NX + NU) { hb = ht; tk += ht; }
   }
   double F[NF];
-  {
+  if constexpr (has_stage<Prob>::value) {
+    // functors with staged dynamics (problems.hpp): role 0 of a node leaves the sub-expressions of the unperturbed point in LDS,
+    // every perturbed evaluation recomputes only what its one or two variables enter — same operations, same bits
+    using Stage = typename stage_of<Prob>::type;
+    constexpr int SD = int(sizeof(Stage) / sizeof(double));
+    __shared__ double stg[SD * 64];
+    if (role == 0) {             // (unperturbed: a = b = -1)
+      Stage s0;
+      Prob::stage(ph.phase_num, tk, xs, us, c, s0);
+#pragma unroll
+      for (int i = 0; i < SD; ++i) stg[i * 64 + kk] = reinterpret_cast<const double*>(&s0)[i];
+    }
+    __syncthreads();
+    Stage sb;
+#pragma unroll
+    for (int i = 0; i < SD; ++i) reinterpret_cast<double*>(&sb)[i] = stg[i * 64 + kk];
+    double cp[NCs];
+    Prob::dae_from2(ph.phase_num, tk, xs, us, c, sb, a, b, F, cp);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) F[NX + j] = cp[j];
+    F[NX + NC] = pf_lagrange<Prob>(ph.phase_num, tk, xs, us, x + ph.x_t0 + 2, c);
+  } else {
     double cp[NCs];
     pf_dae<Prob>(ph.phase_num, tk, xs, us, x + ph.x_t0 + 2, c, F, cp);
 #pragma unroll
