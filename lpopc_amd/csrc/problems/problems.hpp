@@ -48,6 +48,10 @@ template <class P, class = void>
 struct has_stage : std::false_type {};
 template <class P>
 struct has_stage<P, std::void_t<typename P::Stage>> : std::true_type {};
+template <class P, class = void>
+struct stage_always : std::false_type {};     // P::STAGE_ALWAYS = true: the staged form also pays when the launch stores everything
+template <class P>
+struct stage_always<P, std::enable_if_t<P::STAGE_ALWAYS>> : std::true_type {};
 template <class P, bool = has_stage<P>::value>
 struct stage_of { struct type {}; };
 template <class P>
@@ -489,6 +493,7 @@ struct QuadrotorProblem {
   }
   // In stages (has_stage): the three sine / cosine pairs are all that is worth keeping
   struct Stage { double sph, cph, sth, cth, sps, cps; };
+  static constexpr bool STAGE_ALWAYS = true;    // 1024-instance sweep, all stores: 44.2 -> 42.9 us per launch
   template <class CP = const double*>
   RPM_DEV static void stage(int, double, const double* x, const double*, CP, Stage& s) {
     sincos(x[6], &s.sph, &s.cph);

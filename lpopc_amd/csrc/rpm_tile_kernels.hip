@@ -1238,7 +1238,7 @@ static hipError_t launch_tile_pl(const Engine& e, const KParams& kp, const doubl
     // problem, 64 iterates per launch: 75.3 -> 69.5 us with the constant block skipped, but 99.2 -> 106.6 us with all stores (21
     // more registers in a kernel that waits for its stores); same bits either way
     static const bool env_off = std::getenv("RPM_STAGE_ROLES") && std::atoi(std::getenv("RPM_STAGE_ROLES")) == 0;   // measurements
-    if (!env_off && (e.opt_stage_roles == 1 || (e.opt_stage_roles < 0 && kp.skip_const)))
+    if (!env_off && (e.opt_stage_roles == 1 || (e.opt_stage_roles < 0 && (kp.skip_const || stage_always<Prob>::value))))
       return launch_tile_pl<Prob, WG, WJ, AN, DXM, true>(e, kp, dx, dg, dv, st);
   }
   const Device& d = *e.dev;
