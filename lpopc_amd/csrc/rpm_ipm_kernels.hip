@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void ipm_fill_kernel(IpmDev D) {
     const int len = int(hi - lo);
     if ((reinterpret_cast<size_t>(K + lo) & 15) == 0) {
       double2* K2 = reinterpret_cast<double2*>(K + lo);
-      for (int i = tid; i < (len >> 1); i += 256) K2[i] = b2[i];
+      typedef double d2v __attribute__((ext_vector_type(2)));   // streaming stores: the storage is next read by the factorisation, from HBM either way
+      for (int i = tid; i < (len >> 1); i += 256) __builtin_nontemporal_store(d2v{b2[i].x, b2[i].y}, reinterpret_cast<d2v*>(K2 + i));
       if ((len & 1) && tid == 0) K[hi - 1] = buf[len - 1];
     } else {
       for (int i = tid; i < len; i += 256) K[lo + i] = buf[i];
