@@ -255,6 +255,9 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       Hessian and diagonal terms itself and carries the level-1 forward substitution of the iteration's
  *                       right-hand side along, the fill kernel leaves level-1 storage alone; 0 = separate kernels; same
  *                       results bit for bit; 1 where level 1 does not run on that kernel: RPM_E_UNSUPPORTED),
+ *                       "nlp_scaling" (0; 1 = Ipopt's gradient-based NLP scaling, ITS default: objective and constraint rows
+ *                       scaled so that no gradient entry at the starting point exceeds "nlp_scaling_max_gradient" (100); the
+ *                       multipliers and the objective come back unscaled; DESIGN.md f-2 on why it is off here),
  *                       "ic_hot_start" (0; 1 = an iteration whose predecessor needed delta_w > 0 starts the inertia correction
  *                       at kappa_w^- * delta_w_last instead of 0 while that is >= "ic_hot_min" (1e-10): not Ipopt's rule, an
  *                       experiment)

@@ -5,8 +5,8 @@
 // independent instances of one transcription — the MPC sweep of BASELINE config 5 — with every iterate, multiplier,
 // KKT matrix and factor resident in HBM.  Restated beyond the basic iteration: bound_relax_factor, the second-order correction,
 // the restoration phase (paper section 3.3, with a Gauss-Newton model of the constraint curvature) and least-squares
-// multipliers on leaving it, and Ipopt's adaptive barrier update with the LOQO oracle (option "mu_strategy", default 1; 0 = monotone).  Not restated:
-// the quality-function oracle, scaling, the watchdog.  See DESIGN.md §f-2.
+// multipliers on leaving it, Ipopt's adaptive barrier update with the LOQO oracle (option "mu_strategy", default 1; 0 = monotone) and its
+// gradient-based NLP scaling (option "nlp_scaling", off by default).  Not restated: the quality-function oracle, the watchdog.  See DESIGN.md §f-2.
 //
 // The KKT matrix of a collocation NLP is banded once the unknowns are ordered along time: node k's states, controls,
 // slacks and multipliers sit together, a defect row reaches the nodes of its own mesh interval only.  What does not

@@ -33,6 +33,8 @@ struct IpmOpts {
   double mu_max_fact = 1e3, mu_red_fact = 0.9999, mu_init_factor = 0.8;
   double sigma_cap = 0.0;            // experiment: cap z/s in the KKT matrix (0 = off)
   int init_ls_mult = 0;              // 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
+  int nlp_scaling = 0;               // 1: Ipopt's gradient-based NLP scaling (its default; this solver's is off)
+  double scal_gmax = 100.0, scal_min = 1e-8;   // nlp_scaling_max_gradient, nlp_scaling_min_value
   int ic_hot = 0;                    // 1: an iteration whose predecessor needed delta_w > 0 starts Algorithm IC at kw_dec * delta_w_last instead of 0
   double ic_hot_min = 1e-10;         //    (not Ipopt: saves the factorisation that fails at 0) as long as that value is at least this
   // Ipopt's unscaled termination thresholds, required beside the scaled E_0 <= tol (resp. acceptable_tol)
@@ -130,6 +132,11 @@ struct IpmDev {
   double *lb_S, *lb_Y;        // B x IPM_LB_H x n pairs, oldest first
   double *lb_xprev;           // B x n: the iterate the stored gradient / Jacobian belong to
   double *lb_gold;            // B x nv: grad_x L(x_prev, lambda) with the CURRENT multipliers (first n of every row)
+  // nlp_scaling: per instance the row factors sc (B x m), the objective factor sf (B), lambda o sc / sf for the Hessian call (B x m)
+  int scal_on;
+  double *sc, *sf, *lam_h;
+  const int* jac_row;         // row of every Jacobian entry
+  int nnz_var;                // entries of `jac` a later evaluation of the solve rewrites ([NL | LIN]; the constant block is written once)
   double *lb_small;           // B x IPM_LB_SMALL
   double *lb_part;            // B x IPM_LB_PART: the waves' shares of the sums of one phase (rpm_ipm_lbfgs.hip)
   double *lb_Z;               // 2 IPM_LB_H x B x Nt: K0^-1 E, column-major by column
@@ -155,6 +162,12 @@ void ipm_launch_accept(const IpmDev& D, hipStream_t st);
 void ipm_launch_update(const IpmDev& D, hipStream_t st);
 void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st);          // right-hand side of the second-order correction
 void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st);    // its step and step lengths
+// Ipopt's gradient-based NLP scaling (option nlp_scaling)
+void ipm_launch_scaling_factors(const IpmDev& D, hipStream_t st);   // sc, sf from D.grad / D.jac at the starting point (unscaled)
+void ipm_launch_scale(const IpmDev& D, double* g, double* jac, int jac0, int jac1, double* obj, double* grad, hipStream_t st);   // in place; null = leave
+void ipm_launch_scale_lambda(const IpmDev& D, hipStream_t st);       // lam_h = lam o sc / sf
+void ipm_launch_scale_hessian(const IpmDev& D, hipStream_t st);      // hess *= sf
+void ipm_launch_unscale_lambda(const IpmDev& D, double* out, hipStream_t st);   // out = lam o sc / sf
 // limited-memory BFGS (rpm_ipm_lbfgs.hip)
 void lb_launch_reset(const IpmDev& D, hipStream_t st);
 void lb_launch_update(const IpmDev& D, hipStream_t st);               // after the residual kernel of an iteration

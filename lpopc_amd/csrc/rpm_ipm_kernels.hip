@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void ipm_init_slack_kernel(IpmDev D) {
     const int r = D.slack_row[s];
     double l = D.gl[r], u = D.gu[r];
     const bool lo = l > -IPM_INF, up = u < IPM_INF;
+    if (D.scal_on) {           // the rows are scaled (nlp_scaling): so are their bounds
+      const double sr = D.sc[size_t(bi) * D.m + r];
+      if (lo) l *= sr;
+      if (up) u *= sr;
+    }
     if (lo) l -= D.o.bound_relax * fmax(1.0, fabs(l));
     if (up) u += D.o.bound_relax * fmax(1.0, fabs(u));
     const size_t o = size_t(bi) * D.nv + D.n + s;
@@ -240,18 +245,21 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   const double *g = D.g + size_t(bi) * D.sg, *glag = D.glag + size_t(bi) * D.nv;
   double dinf = 0, cinf = 0, th1 = 0, cmax = 0, cmin = 1e300, sl = 0, sz = 0, ln = 0, bad = 0, nzb = 0;
   double csq = 0, dsq = 0, psum = 0, psq = 0, nfree = 0;      // 2-norms for the adaptive barrier update's KKT error
+  double cinf_u = 0;            // nlp_scaling: the constraint violation of the unscaled problem (Ipopt's constr_viol_tol applies to it)
   // pass 1: constraint values and what does not depend on the multipliers
   #pragma unroll 4
   for (int r = i0; r < D.m; r += stride) {
     const int s = D.row_slack[r];
-    const double cr = s < 0 ? g[r] - D.gl[r] : g[r] - v[D.n + s];
+    const double glr = D.scal_on ? D.sc[size_t(bi) * D.m + r] * D.gl[r] : D.gl[r];
+    const double cr = s < 0 ? g[r] - glr : g[r] - v[D.n + s];
     D.c[size_t(bi) * D.m + r] = cr;
     if (!(fabs(cr) < 1e300)) bad = 1;
     cinf = fmax(cinf, fabs(cr));
+    cinf_u = fmax(cinf_u, D.scal_on ? fabs(cr / D.sc[size_t(bi) * D.m + r]) : fabs(cr));
     th1 += fabs(cr);
     csq += cr * cr;
   }
-  cinf = block_red(cinf, 1, sh); th1 = block_red(th1, 0, sh);
+  cinf = block_red(cinf, 1, sh); th1 = block_red(th1, 0, sh); cinf_u = block_red(cinf_u, 1, sh);
   if (mode_in == 2) {
     // ---- restoration phase (paper section 3.3): min rho sum(p + n) + zeta/2 |D_R (v - v_R)|^2  s.t.  c(v) - p + n = 0, p, n >= 0, bounds
     const IpmOpts& o = D.o;
@@ -371,11 +379,11 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   cmax = block_red(cmax, 1, sh); cmin = block_red(cmin, 2, sh); sl = block_red(sl, 0, sh); sz = block_red(sz, 0, sh);
   ln = block_red(ln, 0, sh); bad = block_red(bad, 1, sh); nzb = block_red(nzb, 0, sh);
   {
-    double vals[15] = {dinf, cmax, cmin, sl, sz, ln, bad, nzb, cinf, th1, csq, dsq, psum, psq, nfree};
-    const int kind[15] = {1, 1, 2, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
+    double vals[16] = {dinf, cmax, cmin, sl, sz, ln, bad, nzb, cinf, th1, csq, dsq, psum, psq, nfree, cinf_u};
+    const int kind[16] = {1, 1, 2, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 1};
     if (!vec_combine(D, bi, vals, kind)) return;
     dinf = vals[0]; cmax = vals[1]; cmin = vals[2]; sl = vals[3]; sz = vals[4]; ln = vals[5]; bad = vals[6]; nzb = vals[7];
-    cinf = vals[8]; th1 = vals[9]; csq = vals[10]; dsq = vals[11]; psum = vals[12]; psq = vals[13]; nfree = vals[14];
+    cinf = vals[8]; th1 = vals[9]; csq = vals[10]; dsq = vals[11]; psum = vals[12]; psq = vals[13]; nfree = vals[14]; cinf_u = vals[15];
   }
   if (t != 0) return;
   const IpmOpts& o = D.o;
@@ -386,9 +394,11 @@ __global__ __launch_bounds__(1024) void ipm_residual_kernel(IpmDev D) {
   const double sc = nzb > 0 ? fmax(o.s_max, sz / nzb) / o.s_max : 1.0;
   S.err0 = fmax(fmax(dinf / sd, cinf), nzb > 0 ? cmax / sc : 0.0);
   if (bad != 0) { S.status = 5; return; }
-  const double cm = nzb > 0 ? cmax : 0.0;
-  if (S.err0 <= o.tol && dinf <= o.dual_inf_tol && cinf <= o.constr_viol_tol && cm <= o.compl_inf_tol) { S.status = 1; return; }
-  S.n_acc = (S.err0 <= o.acceptable_tol && dinf <= o.acc_dual_inf_tol && cinf <= o.acc_constr_viol_tol && cm <= o.acc_compl_inf_tol) ? S.n_acc + 1 : 0;
+  // Ipopt's secondary thresholds apply to the unscaled problem: gradient of the Lagrangian and complementarity / sf, rows / sc
+  const double sfu = D.scal_on ? D.sf[bi] : 1.0;
+  const double cm = (nzb > 0 ? cmax : 0.0) / sfu, dinf_u = dinf / sfu;
+  if (S.err0 <= o.tol && dinf_u <= o.dual_inf_tol && cinf_u <= o.constr_viol_tol && cm <= o.compl_inf_tol) { S.status = 1; return; }
+  S.n_acc = (S.err0 <= o.acceptable_tol && dinf_u <= o.acc_dual_inf_tol && cinf_u <= o.acc_constr_viol_tol && cm <= o.acc_compl_inf_tol) ? S.n_acc + 1 : 0;
   if (o.acceptable_iter > 0 && S.n_acc >= o.acceptable_iter) { S.status = 6; return; }
   if (S.iter >= o.max_iter) { S.status = 2; return; }
   if (S.iter == 0) {
@@ -1689,7 +1699,8 @@ __global__ __launch_bounds__(1024) void ipm_accept_kernel(IpmDev D) {
   for (int r = i0; r < D.m; r += stride) {
     const int s = D.row_slack[r];
     const double gr = D.gt[size_t(bi) * D.sg + r];
-    double cr = s < 0 ? gr - D.gl[r] : gr - (D.v[o + D.n + s] + a * dvp[o + D.n + s]);
+    const double glr = D.scal_on ? D.sc[om + r] * D.gl[r] : D.gl[r];
+    double cr = s < 0 ? gr - glr : gr - (D.v[o + D.n + s] + a * dvp[o + D.n + s]);
     D.ct[om + r] = cr;
     if (resto) {
       const double pt = D.pp[om + r] + a * D.dpp[om + r], nt = D.nn[om + r] + a * D.dnn[om + r];
@@ -1974,6 +1985,78 @@ void ipm_launch_soc_rhs(const IpmDev& D, hipStream_t st) {
 void ipm_launch_soc_direction(const IpmDev& D, hipStream_t st) {
   hipLaunchKernelGGL(ipm_soc_direction_kernel, dim3(vec_blocks(D), unsigned(D.B)), dim3(vec_threads(D)), 0, st, D);
 }
+// ------------------------------------------------------------------------------------------------ NLP scaling
+// Ipopt's GradientScaling (nlp_scaling_method = gradient-based, its default; option nlp_scaling here): at the caller's starting
+// point, sf = min(1, gmax / |grad f|_inf) and sc_i = min(1, gmax / |grad c_i|_inf) over the free variables (floor scal_min); the
+// solver then works on sf f and sc o c — values scaled in place right after every evaluation — and hands back lambda o sc / sf.
+__global__ void ipm_scal_max_kernel(IpmDev D) {      // row maxima into sc, gradient maximum into sf (as bit patterns of non-negative doubles)
+  const int bi = blockIdx.y;
+  unsigned long long* rmax = reinterpret_cast<unsigned long long*>(D.sc + size_t(bi) * D.m);
+  const double* jac = D.jac + size_t(bi) * D.sv;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int k = i0; k < D.nnz_jac; k += stride)
+    if (D.jac_dst[k] >= 0) atomicMax(&rmax[D.jac_row[k]], (unsigned long long)__double_as_longlong(fabs(jac[k])));
+  double gm = 0.0;
+  for (int i = i0; i < D.n; i += stride)
+    if (D.vl[size_t(bi) * D.nv + i] != D.vu[size_t(bi) * D.nv + i]) gm = fmax(gm, fabs(D.grad[size_t(bi) * D.n + i]));
+  if (gm > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(D.sf + bi), (unsigned long long)__double_as_longlong(gm));
+}
+__global__ void ipm_scal_finish_kernel(IpmDev D) {
+  const int bi = blockIdx.y;
+  const double gmax = D.o.scal_gmax, vmin = D.o.scal_min;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < D.m; r += gridDim.x * blockDim.x) {
+    const double v = D.sc[size_t(bi) * D.m + r];
+    D.sc[size_t(bi) * D.m + r] = v > gmax ? fmax(gmax / v, vmin) : 1.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double v = D.sf[bi];
+    D.sf[bi] = v > gmax ? fmax(gmax / v, vmin) : 1.0;
+  }
+}
+__global__ void ipm_scal_apply_kernel(IpmDev D, double* g, double* jac, int jac0, int jac1, double* obj, double* grad) {
+  const int bi = blockIdx.y;
+  if (D.inst[bi].status != 0) return;
+  const double* sc = D.sc + size_t(bi) * D.m;
+  const double sf = D.sf[bi];
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (g) for (int r = i0; r < D.m; r += stride) g[size_t(bi) * D.sg + r] *= sc[r];
+  if (jac) for (int k = jac0 + i0; k < jac1; k += stride) jac[size_t(bi) * D.sv + k] *= sc[D.jac_row[k]];
+  if (grad) for (int i = i0; i < D.n; i += stride) grad[size_t(bi) * D.n + i] *= sf;
+  if (obj && i0 == 0) obj[bi] *= sf;
+}
+__global__ void ipm_scal_lambda_kernel(IpmDev D, double* out) {   // lambda o sc / sf: the multipliers of the unscaled rows over the objective's factor
+  const int bi = blockIdx.y;
+  const double sf = D.sf[bi];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < D.m; r += gridDim.x * blockDim.x)
+    out[size_t(bi) * D.m + r] = D.lam[size_t(bi) * D.m + r] * D.sc[size_t(bi) * D.m + r] / sf;
+}
+__global__ void ipm_scal_hess_kernel(IpmDev D) {
+  const int bi = blockIdx.y;
+  if (D.inst[bi].status != 0) return;
+  const double sf = D.sf[bi];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.nnz_h; k += gridDim.x * blockDim.x) D.hess[size_t(bi) * D.nnz_h + k] *= sf;
+}
+static dim3 scal_grid(const IpmDev& D, int n) { return dim3(unsigned(std::max(1, std::min(D.B <= 32 ? 256 : 16, (n + 255) / 256))), unsigned(D.B)); }
+void ipm_launch_scaling_factors(const IpmDev& D, hipStream_t st) {
+  (void)hipMemsetAsync(D.sc, 0, size_t(D.B) * D.m * sizeof(double), st);
+  (void)hipMemsetAsync(D.sf, 0, size_t(D.B) * sizeof(double), st);
+  hipLaunchKernelGGL(ipm_scal_max_kernel, scal_grid(D, std::max(D.nnz_jac, D.n)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(ipm_scal_finish_kernel, scal_grid(D, D.m), dim3(256), 0, st, D);
+}
+void ipm_launch_scale(const IpmDev& D, double* g, double* jac, int jac0, int jac1, double* obj, double* grad, hipStream_t st) {
+  const int n = std::max(std::max(g ? D.m : 0, jac ? jac1 - jac0 : 0), std::max(grad ? D.n : 0, 1));
+  hipLaunchKernelGGL(ipm_scal_apply_kernel, scal_grid(D, n), dim3(256), 0, st, D, g, jac, jac0, jac1, obj, grad);
+}
+void ipm_launch_scale_lambda(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_scal_lambda_kernel, scal_grid(D, D.m), dim3(256), 0, st, D, D.lam_h);
+}
+void ipm_launch_scale_hessian(const IpmDev& D, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_scal_hess_kernel, scal_grid(D, D.nnz_h), dim3(256), 0, st, D);
+}
+void ipm_launch_unscale_lambda(const IpmDev& D, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(ipm_scal_lambda_kernel, scal_grid(D, D.m), dim3(256), 0, st, D, out);
+}
+
 size_t kkt_factor_lds_bytes(const IpmPlan& p) {
   if (p.nd) return p.max_factor_lds;
   return (size_t(p.b + 24) * IPM_W + size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_W + IPM_W + 2 * size_t(p.nb) * IPM_W +

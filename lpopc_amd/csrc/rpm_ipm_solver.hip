@@ -204,6 +204,15 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     A_(ipm_alloc(h, &D.lb_small, B * IPM_LB_SMALL)); A_(ipm_alloc(h, &D.lb_part, B * IPM_LB_PART));
     A_(ipm_alloc(h, &D.lb_Z, size_t(2 * IPM_LB_H) * B * size_t(p.Nt_alloc)));
   }
+  {   // nlp_scaling (off until the option asks for it; the arrays are small)
+    const size_t Bm = B * size_t(std::max(p.m, 1));
+    D.scal_on = 0;
+    A_(ipm_alloc(h, &D.sc, Bm)); A_(ipm_alloc(h, &D.sf, B)); A_(ipm_alloc(h, &D.lam_h, Bm));
+    std::vector<int> jrow(size_t(e.nnz_jac));
+    for (int k = 0; k < e.nnz_jac; ++k) jrow[size_t(k)] = e.jac_i[size_t(k)];
+    A_(ipm_alloc_c(h, &D.jac_row, jrow));
+    D.nnz_var = e.nnz_nl + e.nnz_lin;
+  }
   {   // restoration phase and second-order correction work space (m >= 1 keeps the allocations non-empty)
     const size_t Bm = B * size_t(std::max(p.m, 1));
     A_(ipm_alloc(h, &D.pp, Bm)); A_(ipm_alloc(h, &D.nn, Bm)); A_(ipm_alloc(h, &D.zp, Bm)); A_(ipm_alloc(h, &D.zn, Bm));
@@ -357,6 +366,8 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "max_soc") o.max_soc = std::max(0, int(value));
   else if (k == "sigma_cap") o.sigma_cap = value;      // experiment
   else if (k == "init_ls_multipliers") o.init_ls_mult = value != 0.0;
+  else if (k == "nlp_scaling") { o.nlp_scaling = value != 0.0; h->D.scal_on = o.nlp_scaling; }
+  else if (k == "nlp_scaling_max_gradient") { if (!(value > 0.0)) { h->err = "nlp_scaling_max_gradient must be > 0"; return RPM_E_INVALID; } o.scal_gmax = value; }
   else if (k == "ic_hot_start") o.ic_hot = value != 0.0;
   else if (k == "ic_hot_min") o.ic_hot_min = value;
   else if (k == "mu_strategy") {       // 0 monotone (default), 1 adaptive: LOQO oracle + kkt-error globalisation
@@ -615,9 +626,19 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
 
   IPM_TRY(h, hipMemcpyAsync(D.xt, d_x, size_t(B) * p.n * sizeof(double), hipMemcpyDeviceToDevice, st));
   ipm_launch_init(D, d_x, st);
+  int rc;
+  const bool scal = D.scal_on != 0;
+  if (scal) {   // Ipopt's gradient-based scaling: factors from the gradients at the caller's starting point (before it is pushed inside its bounds)
+    if ((rc = dev_eval_obj(e, D.xt, D.objt, D.grad, st))) return eng_fail(rc);
+    if ((rc = dev_eval_cons(e, D.xt, D.gt, D.jac, 3 | 4 | 16, st))) return eng_fail(rc);
+    ipm_launch_scaling_factors(D, st);
+    // this evaluation has written D.jac's constant block, which the later ones leave alone: it is scaled here, once
+    if (e.nnz_jac > D.nnz_var) ipm_launch_scale(D, nullptr, D.jac, D.nnz_var, e.nnz_jac, nullptr, nullptr, st);
+  }
   ipm_launch_pack_x(D, st);
-  int rc = dev_eval_cons(e, D.xe, D.g, nullptr, 1 | 4, st);
+  rc = dev_eval_cons(e, D.xe, D.g, nullptr, 1 | 4, st);
   if (rc) return eng_fail(rc);
+  if (scal) ipm_launch_scale(D, D.g, nullptr, 0, 0, nullptr, nullptr, st);
   ipm_launch_init_slack(D, st);
   if ((rc = launch_check(h, "ipm_init"))) return rc;
 
@@ -627,13 +648,19 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
     // D.jac is this solver's own array, written by the tile kernel only: its constant Doffdiag block (55 % of the metric
     // problem's Jacobian) is written by the first evaluation of a solve and left alone afterwards (flag 16)
     if ((rc = dev_eval_cons(e, D.xe, D.g, D.jac, 3 | 4 | 16, st))) return eng_fail(rc);
+    // (without the scaling's own evaluation the first pass of a solve writes the constant block too: then all of D.jac is scaled)
+    if (scal) ipm_launch_scale(D, D.g, D.jac, 0, D.nnz_var, D.obj, D.grad, st);
     IPM_TRY(h, hipMemsetAsync(D.cnt, 0, 4 * sizeof(int), st));
     ipm_launch_residual(D, st);
     if (h->lbfgs) lb_launch_update(D, st);     // the pair of the step just taken (grad_x L at the new point is in D.glag)
     if ((rc = fetch_counts(h, st))) return rc;
     if (h->h_cnt[0] == 0) break;
     h->total_iterations += 1;
-    if (!h->lbfgs && (rc = dev_eval_h(e, D.xe, 1.0, D.lam, D.hess, st))) return eng_fail(rc);
+    if (!h->lbfgs) {
+      if (scal) ipm_launch_scale_lambda(D, st);            // sf (H_f + sum (lambda_i sc_i / sf) H_ci)
+      if ((rc = dev_eval_h(e, D.xe, 1.0, scal ? D.lam_h : D.lam, D.hess, st))) return eng_fail(rc);
+      if (scal) ipm_launch_scale_hessian(D, st);
+    }
     for (int tries = 0; tries < 80; ++tries) {
       IPM_TRY(h, hipMemsetAsync(D.cnt + 1, 0, sizeof(int), st));
       ipm_launch_assemble(D, std::max(e.nnz_jac, e.nnz_h), st);
@@ -673,6 +700,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
       ipm_launch_trial(D, st);
       if ((rc = dev_eval_obj(e, D.xt, D.objt, nullptr, st))) return eng_fail(rc);
       if ((rc = dev_eval_cons(e, D.xt, D.gt, nullptr, 1 | 4, st))) return eng_fail(rc);
+      if (scal) ipm_launch_scale(D, D.gt, nullptr, 0, 0, D.objt, nullptr, st);
       IPM_TRY(h, hipMemsetAsync(D.cnt + 2, 0, 2 * sizeof(int), st));
       ipm_launch_accept(D, st);
       h->total_trials += 1;
@@ -694,7 +722,15 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
   // results: x back into the caller's array, multipliers, per-instance verdicts
   ipm_launch_pack_x(D, st);
   IPM_TRY(h, hipMemcpyAsync(d_x, D.xe, size_t(B) * p.n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  if (d_lambda) IPM_TRY(h, hipMemcpyAsync(d_lambda, D.lam, size_t(B) * p.m * sizeof(double), hipMemcpyDeviceToDevice, st));
+  std::vector<double> sf_host;
+  if (d_lambda) {
+    if (scal) ipm_launch_unscale_lambda(D, d_lambda, st);     // the multipliers of the caller's (unscaled) rows
+    else IPM_TRY(h, hipMemcpyAsync(d_lambda, D.lam, size_t(B) * p.m * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  if (scal) {
+    sf_host.resize(B);
+    IPM_TRY(h, hipMemcpyAsync(sf_host.data(), D.sf, size_t(B) * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   IPM_TRY(h, hipMemcpyAsync(h->h_inst.data(), D.inst, size_t(B) * sizeof(IpmInst), hipMemcpyDeviceToHost, st));
   IPM_TRY(h, hipStreamSynchronize(st));
 #ifdef IPM_TIMING
@@ -703,7 +739,7 @@ int rpm_ipm_solve_dev(rpm_ipm* h, double* d_x, double* d_lambda, double* obj, in
 #endif
   for (unsigned bi = 0; bi < B; ++bi) {
     const IpmInst& S = h->h_inst[bi];
-    if (obj) obj[bi] = S.f;
+    if (obj) obj[bi] = scal ? S.f / sf_host[bi] : S.f;
     if (status) status[bi] = S.status == 1 ? 0 : (S.status == 6 ? 1 : S.status);
     if (iterations) iterations[bi] = S.iter;
     if (kkt_error) kkt_error[bi] = S.err0;

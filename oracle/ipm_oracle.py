@@ -37,7 +37,8 @@ s'y <= sqrt(eps) |s| |y| (two skips in a row empty the memory), initial scaling 
 compact representation B = sigma I - [sigma S  Y] [[sigma S'S, L], [L', -D]]^-1 [sigma S'; Y'] (Byrd, Nocedal, Schnabel 1994) in the
 place of the exact Hessian W.  B is positive definite, so the inertia is right without a correction.  The memory is emptied when
 the restoration phase returns.  Entries of y at fixed variables are dropped (their rows of the KKT matrix are identity rows).
-Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle, NLP scaling,
+Ipopt's gradient-based NLP scaling is restated as an option (nlp_scaling_method = "gradient-based", Ipopt's default; "none" here).
+Deliberately NOT restated (neither here nor on the device; DESIGN.md "f-2"): the quality-function oracle,
 least-squares multipliers at the very first iterate by default (option init_ls_multipliers; lambda_0 = 0 otherwise), watchdog.  One deviation:
 the constraint regularisation delta_c = 1e-9 is always on
 (Ipopt: only for singular Jacobians), which is what makes the pivot-free LDL^T on the device well defined.
@@ -61,6 +62,9 @@ DEFAULTS = dict(tol=1e-8, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.
                 mu_strategy="adaptive", mu_max_fact=1e3, adaptive_mu_kkterror_red_iters=4, adaptive_mu_kkterror_red_fact=0.9999,
                 adaptive_mu_monotone_init_factor=0.8, max_recalc_y=3,
                 init_ls_multipliers=0,                # 1: least-squares multipliers at the very first iterate too (Ipopt's default start)
+                nlp_scaling_method="none",            # "gradient-based": Ipopt's default NLP scaling (GradientScaling, nlp_scaling_max_gradient 100): the
+                nlp_scaling_max_gradient=100.0,       #   objective and every constraint row are scaled down so that no gradient entry at the starting
+                nlp_scaling_min_value=1e-8,           #   point exceeds 100; "none" is this restatement's default
                 ic_hot_start=0, ic_hot_min=1e-10,     # 1: Algorithm IC starts at kw_dec * delta_w_last when the previous iteration needed delta_w > 0
                                                       #    and that value is >= ic_hot_min (NOT Ipopt's rule, which always tries 0 first: an experiment)
                 hessian_approximation="exact", limited_memory_max_history=6, limited_memory_max_skipping=2,
@@ -105,11 +109,58 @@ def _push_body(x, l, u, o, lo, up, both):
     return x
 
 
+class _GradientScaled:
+    """The NLP seen through Ipopt's gradient-based scaling: f -> sf f, c_i -> sc_i c_i with sf = min(1, gmax / |grad f(x0)|_inf),
+    sc_i = min(1, gmax / |grad c_i(x0)|_inf) (columns of fixed variables left out, floor nlp_scaling_min_value), x unscaled."""
+
+    def __init__(self, orc, x0, fixed, gmax, vmin):
+        self.o, self.n, self.m = orc, orc.n, orc.m
+        self.ji, self.jj = orc.jac_structure()
+        g = np.abs(orc.eval_grad_f(x0))[~fixed]
+        gr = g.max() if g.size else 0.0
+        self.sf = max(gmax / gr, vmin) if gr > gmax else 1.0
+        jv = np.abs(orc.eval_jac_g(x0))
+        rmax = np.zeros(orc.m)
+        keep = ~fixed[self.jj]
+        np.maximum.at(rmax, self.ji[keep], jv[keep])
+        self.sc = np.where(rmax > gmax, np.maximum(gmax / np.maximum(rmax, 1e-300), vmin), 1.0)
+
+    def bounds(self):
+        xl, xu, gl, gu = self.o.bounds()
+        return xl, xu, np.where(np.abs(gl) < INF, gl * self.sc, gl), np.where(np.abs(gu) < INF, gu * self.sc, gu)
+
+    def jac_structure(self):
+        return self.ji, self.jj
+
+    def hess_structure(self):
+        return self.o.hess_structure()
+
+    def eval_f(self, x):
+        return self.sf * self.o.eval_f(x)
+
+    def eval_grad_f(self, x):
+        return self.sf * self.o.eval_grad_f(x)
+
+    def eval_g(self, x):
+        return self.sc * self.o.eval_g(x)
+
+    def eval_jac_g(self, x):
+        return self.sc[self.ji] * self.o.eval_jac_g(x)
+
+    def eval_h(self, x, sigma, lam):
+        return self.sf * self.o.eval_h(x, sigma, lam * self.sc / self.sf)     # as the device forms it: one scalar factor outside
+
+
 def solve(orc, x0, x_l=None, x_u=None, **options):
     """-> dict(x, lambda, obj, status, iterations, kkt_error, trace); status codes as rpm_ipm_solve (0 converged, 1 acceptable level, ...)."""
     o = dict(DEFAULTS)
     o.update(options)
     n, m = orc.n, orc.m
+    sf_u, sc_u = 1.0, np.ones(m)
+    if o["nlp_scaling_method"] == "gradient-based":
+        xl0, xu0 = orc.bounds()[:2] if x_l is None else (np.asarray(x_l, float), np.asarray(x_u, float))
+        orc = _GradientScaled(orc, np.asarray(x0, float), xl0 == xu0, o["nlp_scaling_max_gradient"], o["nlp_scaling_min_value"])
+        sf_u, sc_u = orc.sf, orc.sc
     xl, xu, gl, gu = orc.bounds()
     if x_l is not None:
         xl, xu = np.asarray(x_l, float), np.asarray(x_u, float)
@@ -368,11 +419,15 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         ln = lnsum(v)
         if not np.isfinite([f, ln, dinf, cinf]).all():
             status = 5
-        elif err0 <= o["tol"] and dinf <= o["dual_inf_tol"] and cinf <= o["constr_viol_tol"] and (cmax if nzb else 0.0) <= o["compl_inf_tol"]:
+        # Ipopt's secondary thresholds apply to the UNSCALED problem (nlp_scaling_method): gradient and complementarity / sf, rows / sc
+        dinf_u, cinf_u, cm_u = dinf / sf_u, (float(np.max(np.abs(c / sc_u))) if m else 0.0), (cmax / sf_u if nzb else 0.0)
+        if status is not None:
+            pass
+        elif err0 <= o["tol"] and dinf_u <= o["dual_inf_tol"] and cinf_u <= o["constr_viol_tol"] and cm_u <= o["compl_inf_tol"]:
             status = 0
         else:
-            acc_ok = err0 <= o["acceptable_tol"] and dinf <= o["acceptable_dual_inf_tol"] and cinf <= o["acceptable_constr_viol_tol"] and \
-                (cmax if nzb else 0.0) <= o["acceptable_compl_inf_tol"]
+            acc_ok = err0 <= o["acceptable_tol"] and dinf_u <= o["acceptable_dual_inf_tol"] and cinf_u <= o["acceptable_constr_viol_tol"] and \
+                cm_u <= o["acceptable_compl_inf_tol"]
             n_acc = n_acc + 1 if acc_ok else 0            # Ipopt: acceptable_tol 1e-6, acceptable_iter 15
             if o["acceptable_iter"] > 0 and n_acc >= o["acceptable_iter"]:
                 status = 1
@@ -553,5 +608,5 @@ def solve(orc, x0, x_l=None, x_u=None, **options):
         trace.append(dict(it=it, f=f, theta=theta, mu=mu, alpha=a, alpha_z=az, delta_w=dw, err0=err0, ls=ls, soc=n_soc, dinf=dinf, cinf=cinf, comp=cmax,
                           smin=float(min(dl[lo].min(initial=1e300), du[up].min(initial=1e300)))))
         it += 1
-    return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam.copy()}, obj=f, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto,
+    return dict(x=v[:n].copy(), slack=v[n:].copy(), **{"lambda": lam * sc_u / sf_u}, obj=f / sf_u, status=status, iterations=it, kkt_error=err0, trace=trace, restorations=n_resto,
                 multiplier_recalculations=n_recalc, lm_updates=lm["updates"], lm_skips=lm["skips"])

@@ -409,6 +409,70 @@ def test_inertia_correction_hot_start_against_restatement(built, name, make):
     eng.close()
 
 
+SCALED = [("hypersensitive", lambda: problems.hypersensitive(np.linspace(-1, 1, 7).tolist(), [10] * 6, tf=30.0)),
+          ("bryson_denham_8x6", lambda: problems.bryson_denham(8, 6)), ("brachistochrone_6x8", lambda: problems.brachistochrone(6, 8))]
+
+
+@pytest.mark.parametrize("name,make", SCALED, ids=[c[0] for c in SCALED])
+def test_restatement_gradient_based_scaling(name, make):
+    """Ipopt's default NLP scaling (nlp_scaling_method = gradient-based), an option of this restatement: on these meshes some
+    defect rows have differentiation-matrix entries above 100 at the starting point and are scaled down; the scaled solve reaches
+    the optimum of the unscaled one and returns the multipliers of the caller's rows."""
+    prob = make()
+    o = orc.Oracle(prob, _exact())
+    x0 = o.starting_point()
+    plain = ipm_oracle.solve(o, x0, max_iter=400)
+    scaled = ipm_oracle.solve(o, x0, max_iter=400, nlp_scaling_method="gradient-based")
+    assert plain["status"] == scaled["status"] == 0
+    assert abs(plain["obj"] - scaled["obj"]) <= 1e-7 * max(1.0, abs(plain["obj"]))
+    ji, jj = o.jac_structure()
+    rmax = np.zeros(o.m)
+    np.maximum.at(rmax, ji, np.abs(o.eval_jac_g(x0)))
+    assert (rmax > 100).sum() >= 10                               # the scaling is not the identity here
+    xl, xu, gl, gu = o.bounds()
+    g = o.eval_g(scaled["x"])
+    assert max((gl - g).max(), (g - gu).max()) < 1e-6             # feasible for the caller's rows
+    # stationarity with the returned multipliers, in the caller's scaling: grad f + J' lambda vanishes on the variables off their bounds
+    res = o.eval_grad_f(scaled["x"])
+    np.add.at(res, jj, o.eval_jac_g(scaled["x"]) * scaled["lambda"][ji])
+    inner = (scaled["x"] > xl + 1e-5) & (scaled["x"] < xu - 1e-5)
+    assert np.max(np.abs(res[inner])) <= 1e-5 * max(1.0, np.max(np.abs(scaled["lambda"])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", SCALED, ids=[c[0] for c in SCALED])
+def test_device_gradient_based_scaling_against_restatement(built, name, make):
+    """Option nlp_scaling on the device solver: factors from the gradients at the caller's starting point, every evaluation
+    scaled in place (the Jacobian's constant block once), multipliers and objective handed back unscaled — step for step with
+    the restatement."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = make()
+    eng = NLPEngine(prob, _exact(), n_instances=1, device=0)
+    o = orc.Oracle(prob, _exact())
+    x0 = o.starting_point()[None, :]
+    ipm = BatchedIPM(eng, max_iter=400, trace=400, nlp_scaling=1)
+    r = ipm.solve(x0)
+    ref = ipm_oracle.solve(o, x0[0], max_iter=400, nlp_scaling_method="gradient-based")
+    assert r["status"][0] == ref["status"] == 0
+    assert abs(int(r["iterations"][0]) - ref["iterations"]) <= 1
+    assert abs(r["obj"][0] - ref["obj"]) <= 1e-8 * max(1.0, abs(ref["obj"]))
+    assert np.max(np.abs(r["x"][0] - ref["x"])) <= 1e-6 * max(1.0, np.max(np.abs(ref["x"])))
+    tr = ipm.trace(0)
+    for k in range(min(len(tr), len(ref["trace"]), 4)):
+        e = ref["trace"][k]
+        assert abs(tr[k, 0] - e["f"]) <= 1e-2 * max(1.0, abs(e["f"])) and abs(tr[k, 1] - e["theta"]) <= 1e-2 * max(1.0, e["theta"]), (k, tr[k], e)
+        assert abs(tr[k, 5] - e["delta_w"]) <= 1e-12 * e["delta_w"] and int(tr[k, 7]) == e["ls"], (k, tr[k], e)
+    # the multipliers come back for the caller's rows
+    ji, jj = o.jac_structure()
+    xl_, xu_, _, _ = o.bounds()
+    live = np.zeros(o.m, dtype=bool)
+    live[ji[xl_[jj] != xu_[jj]]] = True
+    dl = np.abs(r["lambda"][0] - ref["lambda"])[live]
+    assert dl.size == 0 or np.max(dl) <= 3e-4 * max(1.0, np.max(np.abs(ref["lambda"][live])))
+    ipm.close()
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_sweep_with_per_instance_bounds(built):
     """An MPC sweep: the same transcription from different initial states (per-instance variable bounds)."""
