@@ -471,6 +471,19 @@ def test_device_gradient_based_scaling_against_restatement(built, name, make):
     assert dl.size == 0 or np.max(dl) <= 3e-4 * max(1.0, np.max(np.abs(ref["lambda"][live])))
     ipm.close()
     eng.close()
+    # a batch: every instance has its own factors (its own starting point), and an instance that ends early keeps its values
+    B = 3
+    eng = NLPEngine(prob, _exact(), n_instances=B, device=0)
+    xs = np.tile(o.starting_point(), (B, 1)) * (1 + 2e-2 * np.random.RandomState(3).uniform(-1, 1, size=(B, o.n)))
+    ipm = BatchedIPM(eng, max_iter=400, nlp_scaling=1)
+    rb = ipm.solve(xs)
+    for bi in range(B):
+        refb = ipm_oracle.solve(o, xs[bi], max_iter=400, nlp_scaling_method="gradient-based")
+        assert rb["status"][bi] == refb["status"] == 0
+        assert abs(int(rb["iterations"][bi]) - refb["iterations"]) <= 1
+        assert abs(rb["obj"][bi] - refb["obj"]) <= 1e-8 * max(1.0, abs(refb["obj"]))
+    ipm.close()
+    eng.close()
 
 
 @pytest.mark.gpu
