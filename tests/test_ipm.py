@@ -671,6 +671,31 @@ def test_restatement_restoration_rescues_bryson_denham_on_the_default_mesh():
 
 
 @pytest.mark.gpu
+def test_restoration_and_multiplier_passes_through_the_assembling_factor_kernel(built):
+    """The restoration phase (mode 2: another matrix and right-hand side) and the least-squares-multiplier pass on leaving it
+    (mode 3) with level 1 assembled and forward-substituted inside kkt_factor_dense_kernel: the same iterates, bit for bit, as with
+    the fill kernel and the separate substitution (option fused_fill), and restorations do happen on this run."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    prob = problems.bryson_denham()
+    out = []
+    for fused in (1, 0):
+        eng = NLPEngine(prob, _exact(), n_instances=2, device=0)
+        eng.set_option("ipm_nested", 1)
+        ipm = BatchedIPM(eng, tol=1e-6, trace=300, mu_strategy="monotone")
+        ipm.set_option("fused_fill", fused)
+        x0 = np.tile(eng.get_starting_point(), (2, 1))
+        x0[1] *= 1 + 1e-3 * np.random.RandomState(4).uniform(-1, 1, x0.shape[1])
+        r = ipm.solve(x0)
+        out.append((r, [ipm.trace(bi).copy() for bi in range(2)], ipm.restorations().copy()))
+        ipm.close()
+        eng.close()
+    (a, ta, ra), (b, tb, rb) = out
+    assert (a["status"] == 0).all() and (ra >= 1).all()
+    assert np.array_equal(ra, rb) and np.array_equal(a["iterations"], b["iterations"]) and np.array_equal(a["x"], b["x"])
+    assert all(np.array_equal(p, q) for p, q in zip(ta, tb))
+
+
+@pytest.mark.gpu
 def test_device_restoration_against_restatement(built):
     from lpopc_amd.engine import BatchedIPM, NLPEngine
     prob = problems.bryson_denham()
