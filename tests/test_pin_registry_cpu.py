@@ -9,10 +9,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lpopc_amd", "csrc")
 
 
-def test_registry_bookkeeping_against_a_mock_runtime(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("sanitize", [[], ["-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]], ids=["plain", "asan_ubsan"])
+def test_registry_bookkeeping_against_a_mock_runtime(tmp_path, sanitize):
+    """(the second build runs the same 20 000 random acquisitions / releases under AddressSanitizer and UBSan: CPU only, the pool's
+    GPU boxes do not run sanitizers)"""
     exe = str(tmp_path / "pin_registry_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           os.path.join(ROOT, "tests", "native", "pin_registry_test.cpp"), "-o", exe])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + sanitize +
+                          [os.path.join(ROOT, "tests", "native", "pin_registry_test.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
 
