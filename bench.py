@@ -600,7 +600,45 @@ def group_section(ctx, args, prob, devices):
         grp.close()
         one.close()
         torch.cuda.set_device(ctx.local_rank)
+    try:   # rpm_sweep_*: the device solver's 1024-instance sweep dealt to the same devices (instances, not intervals: nothing crosses)
+        out["sweep_solver_instances_dealt"] = sweep_group_part(devices)
+    except Exception as ex:
+        out["sweep_solver_instances_dealt"] = {"error": repr(ex)}
+    torch.cuda.set_device(ctx.local_rank)
     return out
+
+
+def sweep_group_part(devices, B=1024):
+    import numpy as np
+    from lpopc_amd import problems
+    from lpopc_amd.group import SweepGroup
+    from lpopc_amd.problem import Options
+    o = Options()
+    o.SetStringValue("hessian-approximation", "exact")
+    prob = problems.quadrotor(8, 8)
+    sw = SweepGroup(prob, devices, B, o)
+    try:
+        from lpopc_amd.engine import NLPEngine
+        one = NLPEngine(prob, o)
+        xl, xu, _, _ = one.get_bounds_info()
+        x_start = one.get_starting_point()[:one.n]
+        one.close()
+        rng = np.random.RandomState(5)
+        idx = [i * 65 for i in range(12)]
+        for bi in range(B):
+            l, u = xl.copy(), xu.copy()
+            l[idx] = u[idx] = np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.1, 0.1, 6)])
+            sw.set_bounds(bi, l, u)
+        x0 = np.tile(x_start, (B, 1))
+        sw.solve(x0)
+        t0 = time.perf_counter()
+        r = sw.solve(x0)
+        dt = time.perf_counter() - t0
+        return {"devices": list(devices), "instances": B, "solve_s": dt, "solves_per_s": B / dt, "converged": int((r["status"] == 0).sum()),
+                "max_kkt_error": float(r["kkt_error"].max()), "batched_iterations": sw.stats()["iterations"],
+                "how": "rpm_sweep_solve: one process, an engine and a solver per device, a host thread per share; host arrays in and out"}
+    finally:
+        sw.close()
 
 
 def main():

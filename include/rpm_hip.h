@@ -481,6 +481,26 @@ int rpm_group_eval_pair_dev(rpm_group* g, int home, const double* d_x, double* d
  * places of every peer's arrays, one xGMI link per peer (a direct one-shot all-gather, not a ring).  Blocking. */
 int rpm_group_allgather_pair_dev(rpm_group* g, const double* const* d_x, double* const* d_g, double* const* d_values);
 
+/* ---- one process, several GPUs: the INSTANCES of a sweep dealt to the devices (the device solver of row f-2) ---------------
+ * desc->n_instances independent NLPs of one transcription (the MPC sweep of BASELINE config 5), share r = instances
+ * [B r / N, B (r + 1) / N) on device_ids[r] with an engine and a solver (rpm_ipm_*) of its own; the same device may be listed
+ * more than once.  rpm_sweep_solve runs the shares side by side, a host thread each (the solver's loop blocks on its stream);
+ * nothing crosses between devices, so every instance's result is what one engine holding all of them computes for it.  Options
+ * are rpm_ipm_set_option's and go to every share; per-share objects (traces, kernel times, rpm_set_instance_constants with the
+ * share's own instance numbers) through rpm_sweep_solver / rpm_sweep_engine.  Calls on one sweep are serial. */
+typedef struct rpm_sweep rpm_sweep;
+int rpm_sweep_create(const rpm_problem_desc* desc, int n_devices, const int* device_ids, rpm_sweep** out);
+void rpm_sweep_destroy(rpm_sweep* s);
+const char* rpm_sweep_last_error(const rpm_sweep* s);      /* s == NULL: of the last failed rpm_sweep_create */
+int rpm_sweep_size(const rpm_sweep* s);
+rpm_engine* rpm_sweep_engine(rpm_sweep* s, int share);
+rpm_ipm* rpm_sweep_solver(rpm_sweep* s, int share);
+int rpm_sweep_share(const rpm_sweep* s, int share, int* first_instance, int* n_instances);
+int rpm_sweep_set_option(rpm_sweep* s, const char* key, double value);
+int rpm_sweep_set_bounds(rpm_sweep* s, int instance, const double* x_l, const double* x_u);   /* instance: 0 .. B - 1 */
+int rpm_sweep_solve(rpm_sweep* s, double* x, double* lambda, double* obj, int* status, int* iterations, double* kkt_error);
+int rpm_sweep_get_stats(rpm_sweep* s, int* iterations, int* factorizations, int* trial_points);
+
 #ifdef __cplusplus
 }
 #endif

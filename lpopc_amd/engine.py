@@ -34,6 +34,8 @@ ABI_SYMBOLS = [
     "rpm_group_create", "rpm_group_destroy", "rpm_group_last_error", "rpm_group_size", "rpm_group_engine", "rpm_group_device_init",
     "rpm_group_set_option", "rpm_group_eval_f", "rpm_group_eval_grad_f", "rpm_group_eval_g", "rpm_group_eval_jac_g", "rpm_group_eval_pair",
     "rpm_group_eval_h", "rpm_group_eval_pair_dev", "rpm_group_allgather_pair_dev",
+    "rpm_sweep_create", "rpm_sweep_destroy", "rpm_sweep_last_error", "rpm_sweep_size", "rpm_sweep_engine", "rpm_sweep_solver", "rpm_sweep_share",
+    "rpm_sweep_set_option", "rpm_sweep_set_bounds", "rpm_sweep_solve", "rpm_sweep_get_stats",
     "rpm_ipm_get_stats", "rpm_ipm_get_subproblems", "rpm_ipm_get_trace", "rpm_ipm_get_restorations", "rpm_ipm_get_kernel_times", "rpm_ipm_solve", "rpm_ipm_solve_dev", "rpm_ipm_get_permutation", "rpm_ipm_debug_solve", "rpm_ipm_debug_solve_dense", "rpm_ipm_debug_slot",
 ]
 
@@ -152,6 +154,21 @@ def lib(path=None):
     L.rpm_group_eval_h.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp, C.c_int, C.c_int, ip, ip, dp]
     L.rpm_group_eval_pair_dev.argtypes = [vp, C.c_int, vp, vp, vp]
     L.rpm_group_allgather_pair_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.rpm_sweep_create.argtypes = [vp, C.c_int, ip, C.POINTER(vp)]
+    L.rpm_sweep_destroy.argtypes = [vp]
+    L.rpm_sweep_destroy.restype = None
+    L.rpm_sweep_last_error.argtypes = [vp]
+    L.rpm_sweep_last_error.restype = C.c_char_p
+    L.rpm_sweep_size.argtypes = [vp]
+    L.rpm_sweep_engine.argtypes = [vp, C.c_int]
+    L.rpm_sweep_engine.restype = vp
+    L.rpm_sweep_solver.argtypes = [vp, C.c_int]
+    L.rpm_sweep_solver.restype = vp
+    L.rpm_sweep_share.argtypes = [vp, C.c_int, ip, ip]
+    L.rpm_sweep_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.rpm_sweep_set_bounds.argtypes = [vp, C.c_int, dp, dp]
+    L.rpm_sweep_solve.argtypes = [vp, dp, dp, dp, ip, ip, dp]
+    L.rpm_sweep_get_stats.argtypes = [vp, ip, ip, ip]
     _LIBS[so] = L
     if so == _SO:
         _LIB = L

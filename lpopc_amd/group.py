@@ -114,3 +114,69 @@ class EngineGroup:
         """Lists of per-rank tensors (each on its rank's device); afterwards every rank's g / values are complete.  Blocking."""
         arr = lambda ts: (C.c_void_p * self.size)(*[t.data_ptr() for t in ts])   # noqa: E731
         self._check(self._L.rpm_group_allgather_pair_dev(self._h, arr(d_x), arr(d_g), arr(d_values)))
+
+
+class SweepGroup:
+    """rpm_sweep_*: the batched device solver (BatchedIPM) over several GPUs from one process — the B instances of one
+    transcription dealt to `devices` in contiguous shares, solved side by side (a host thread per share inside the library)."""
+
+    def __init__(self, problem, devices, n_instances, options=None, **solver_options):
+        self._L = lib(getattr(problem.GetOpimalProblemFuns(), "library", None))
+        self._desc, self._keep = _abi.lower(problem, options, n_instances, 0, 0, 1)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._L.rpm_sweep_create(C.byref(self._desc), len(devices), devs, C.byref(h))
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_sweep_last_error(None).decode())
+        self._h = h
+        self.size = self._L.rpm_sweep_size(h)
+        self.n_instances = int(n_instances)
+        e0 = self._L.rpm_sweep_engine(h, 0)
+        n, m, nj, nh, st = (C.c_int() for _ in range(5))
+        self._check(self._L.rpm_get_nlp_info(e0, C.byref(n), C.byref(m), C.byref(nj), C.byref(nh), C.byref(st)))
+        self.n, self.m = n.value, m.value
+        for k, v in solver_options.items():
+            self.set_option(k, v)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rpm_sweep_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != RPM_OK:
+            raise RpmError(rc, self._L.rpm_sweep_last_error(self._h).decode())
+
+    def shares(self):
+        out = []
+        for r in range(self.size):
+            a, b = C.c_int(), C.c_int()
+            self._check(self._L.rpm_sweep_share(self._h, r, C.byref(a), C.byref(b)))
+            out.append((a.value, b.value))
+        return out
+
+    def set_option(self, key, value):
+        if key == "mu_strategy" and isinstance(value, str):
+            value = {"monotone": 0, "adaptive": 1}[value]
+        self._check(self._L.rpm_sweep_set_option(self._h, key.encode(), float(value)))
+
+    def set_bounds(self, instance, x_l, x_u):
+        x_l, x_u = np.ascontiguousarray(x_l, dtype=np.float64), np.ascontiguousarray(x_u, dtype=np.float64)
+        assert x_l.size == self.n and x_u.size == self.n
+        self._check(self._L.rpm_sweep_set_bounds(self._h, int(instance), _dp(x_l), _dp(x_u)))
+
+    def solve(self, x0):
+        B = self.n_instances
+        x = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n).copy()
+        lam = np.zeros((B, max(self.m, 1)))
+        obj, err = np.zeros(B), np.zeros(B)
+        status, its = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._check(self._L.rpm_sweep_solve(self._h, _dp(x), _dp(lam), _dp(obj), _ip(status), _ip(its), _dp(err)))
+        return {"x": x, "lambda": lam[:, :self.m], "obj": obj, "status": status, "iterations": its, "kkt_error": err}
+
+    def stats(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._L.rpm_sweep_get_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"iterations": a.value, "factorizations": b.value, "trial_points": c.value}

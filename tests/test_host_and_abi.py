@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "rpm_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*|rpm_engine\*)\s+(rpm_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*|rpm_engine\*|rpm_ipm\*)\s+(rpm_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
     L = C.CDLL(built)
     for s in declared:

@@ -131,3 +131,48 @@ def test_device_consumer_group_direct_stores_and_peer_push(built, name, make, mo
             assert torch.equal(vs[r][b * sv:b * sv + one.nnz_jac], ref_v[b * sv:b * sv + one.nnz_jac]), r
     grp.close()
     one.close()
+
+
+@pytest.mark.gpu
+def test_sweep_group_equals_one_engine(built):
+    """rpm_sweep_*: the instances of an MPC sweep dealt to three shares (this box's one GPU listed three times: three engines,
+    three solvers, three host threads) — every instance's solution, multipliers, verdict and iteration count are bit for bit
+    what ONE engine holding all of them computes."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    from lpopc_amd.group import SweepGroup
+    from lpopc_amd.problem import Options
+    o = Options()
+    o.SetStringValue("hessian-approximation", "exact")
+    B = 7
+    prob = problems.quadrotor(4, 6)
+    one = NLPEngine(prob, o, n_instances=B, device=0)
+    xl, xu, _, _ = one.get_bounds_info()
+    x0 = np.tile(one.get_starting_point()[:one.n], (B, 1))
+    N1 = 4 * 6 + 1
+    idx = [i * N1 for i in range(12)]
+    rng = np.random.RandomState(2)
+    bounds = []
+    for bi in range(B):
+        l, u = xl.copy(), xu.copy()
+        l[idx] = u[idx] = rng.uniform(-0.3, 0.3, 12)
+        bounds.append((l, u))
+    ipm = BatchedIPM(one, max_iter=200)
+    for bi in range(B):
+        ipm.set_bounds(bi, *bounds[bi])
+    ref = ipm.solve(x0)
+    ipm.close()
+    one.close()
+    sw = SweepGroup(prob, [0, 0, 0], B, o, max_iter=200)
+    assert sw.size == 3 and sw.shares() == [(0, 2), (2, 2), (4, 3)]
+    for bi in range(B):
+        sw.set_bounds(bi, *bounds[bi])
+    r = sw.solve(x0)
+    assert (ref["status"] == 0).all() and np.array_equal(r["status"], ref["status"])
+    assert np.array_equal(r["iterations"], ref["iterations"])
+    assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["lambda"], ref["lambda"]) and np.array_equal(r["obj"], ref["obj"])
+    assert sw.stats()["iterations"] == int(ref["iterations"].max())
+    with pytest.raises(Exception):
+        sw.set_bounds(B, *bounds[0])                     # no such instance
+    sw.close()
+    with pytest.raises(Exception):
+        SweepGroup(prob, [0, 0, 0], 2, o)               # fewer instances than devices
