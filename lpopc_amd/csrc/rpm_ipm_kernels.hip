@@ -1196,8 +1196,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #define IPM_UPD_BODY(s) {                                                                                                    \
     int ik = sIK[s];                                                                                                         \
     asm volatile("" : "+s"(ik));   /* keeps the 44 LDS addresses from being hoisted out of the J loop into registers */      \
-    const double* bl = BL + (size_t(ik >> 8) * W + lr) * BS + lq;                                                            \
-    const double* by = BY + (size_t(ik & 255) * W + lr) * BS + lq;                                                           \
+    const double* bl = BL + ((ik >> 8) * W + lr) * BS + lq;                                                                  \
+    const double* by = BY + ((ik & 255) * W + lr) * BS + lq;                                                                 \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-by[4 * g], bl[4 * g], acc[s], 0, 0, 0); \
   }
   // slot s is a diagonal tile of width wd: its lower triangle goes to Dg for the eighth wave
@@ -1238,15 +1238,20 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
           asm volatile("" : "+s"(ik));                                                                                       \
           const int I = ik >> 8, r = row0(I) + lr;                                                                           \
           const bool rv = r < rend(I), border = r >= G.Nb;                                                                   \
+          /* the four entries of a lane sit 4 columns apart: one 64-bit address (row r, column J0 + lq) and a 32-bit step — a   \
+             per-entry G.at() is a 64-bit vector multiply each, and the stores' address arithmetic was 60 % of the panel's time */ \
+          const int kstep = border ? G.CS : G.CS - 1;                                                                        \
+          double* kp = K + (size_t(J0) * G.CS + (border ? G.b + 1 + r - G.Nb : r - J0)) + lq * kstep;                         \
+          const int lo_ = (I * W + lr) * BS + lq;                                                                            \
           _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
             const int c = lq + 4 * g;                                                                                        \
             const double l = y[g] * invd[c];                                                                                 \
             const bool ok = rv && c < w;                                                                                     \
-            if (ok && (border || r - (J0 + c) <= G.b)) K[G.at(r, J0 + c)] = l;                                               \
-            BL[(size_t(I) * W + lr) * BS + c] = ok ? l : 0.0;                                                                \
+            if (ok && (border || r - (J0 + c) <= G.b)) kp[4 * g * kstep] = l;                                                \
+            BL[lo_ + 4 * g] = ok ? l : 0.0;                                                                                  \
             /* L D as kkt_factor_kernel forms it: the product of the stored l and d for a band row (its T), y itself for a   \
                border row (its BY) — the two differ in the last bit, and Delta-III's path is sensitive to that */            \
-            BY[(size_t(I) * W + lr) * BS + c] = ok ? (border ? y[g] : l * dv[c]) : 0.0;                                        \
+            BY[lo_ + 4 * g] = ok ? (border ? y[g] : l * dv[c]) : 0.0;                                                        \
           }                                                                                                                  \
         }
         IPM_REP22(IPM_PANEL)
