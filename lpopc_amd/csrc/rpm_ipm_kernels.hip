@@ -994,8 +994,10 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   double* K = Kall + size_t(bi) * kstride + sub.koff;
   const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr, ntl = NTB * (NTB + 1) / 2;
   extern __shared__ double lds[];
-  double* Dg = lds;                       // W x (W + 1)
-  double* Mi = Dg + W * (W + 1);          // W x 18: L11^-1, row-major (rows padded like the panel's, see below)
+  double* Dg = lds;                       // 2 x W x (W + 1): the diagonal tile of block column J in copy J & 1 (the next one is handed over
+                                          // while the eighth wave still stores the current one)
+  constexpr int DGN = W * (W + 1);
+  double* Mi = Dg + 2 * DGN;              // W x 18: L11^-1, row-major (rows padded like the panel's, see below)
   double* invd = Mi + W * IPM_DENSE_LDS_ROW;   // W
   // rows of 18 doubles: the 16 lanes that read one column of 16 successive rows then hit 16 different pairs of banks (at 16
   // doubles per row they share two, and the matrix products starve: 18 us per block column instead of 3)
@@ -1006,6 +1008,9 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   double* rsh = BY + size_t(NTB) * W * BS; // forward: this block's right-hand side, NTB x 16
   double* ysh = rsh + size_t(NTB) * W;     // forward: y of the current block column
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lr = t & 15, lq = (t & 63) >> 4;
+  // hand_over: block column J's panel rows of block row J + 1 are in LDS (value J + 1) — all the owner of the next diagonal tile waits for
+  __shared__ int hand_over;
+  if (t == 0) hand_over = 0;
   auto row0 = [&](int I) { return I < nbb ? W * I : G.Nb + W * (I - nbb); };
   auto rend = [&](int I) { return I < nbb ? G.Nb : G.Nt; };
   // assemble: the block is built here, not read — the values of its structural slots (a few per cent of the storage) go to LDS
@@ -1060,7 +1065,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #endif
     for (int J = 0; J < nbb; ++J) {
       const int J0 = W * J, w = min(W, G.Nb - J0);
-      IPM_LDS_BARRIER();          // B1: the owner of tile (J, J) has put it into Dg
+      double* DgJ = Dg + (J & 1) * DGN;
+      IPM_LDS_BARRIER();          // B1: the owner of tile (J, J) has put it into its copy of Dg — and, from J = 1 on, block column J - 1's panel is in LDS
       IPM_DTICK(0);
 #if IPM_DIAG_SPLIT
       {   // kkt_factor_kernel's elimination, entry for entry, over all 64 lanes (DiagStep)
@@ -1069,7 +1075,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int j = 4 * g + lq;
-          R[g] = (lr < w && j <= lr) ? Dg[lr * (W + 1) + j] : (j == lr ? 1.0 : 0.0);
+          R[g] = (lr < w && j <= lr) ? DgJ[lr * (W + 1) + j] : (j == lr ? 1.0 : 0.0);
           V[g] = j == lr ? 1.0 : 0.0;
           a_col[g] = j << 2;
         }
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int j = 4 * g + lq;
-          if (lr < w && j <= lr) Dg[lr * (W + 1) + j] = R[g];
+          if (lr < w && j <= lr) DgJ[lr * (W + 1) + j] = R[g];
           Mi[lr * IPM_DENSE_LDS_ROW + j] = V[g];
           if (j == lr) {
             invd[lr] = lr < w ? 1.0 / R[g] : 0.0;
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       double row[W], inv[W];    // lane (l & 15) = row of the block and of L11^-1 (kkt_factor_kernel's elimination, word for word)
 #pragma unroll
       for (int c = 0; c < W; ++c) {
-        row[c] = (lr < w && c <= lr) ? Dg[lr * (W + 1) + c] : (c == lr ? 1.0 : 0.0);
+        row[c] = (lr < w && c <= lr) ? DgJ[lr * (W + 1) + c] : (c == lr ? 1.0 : 0.0);
         inv[c] = c == lr ? 1.0 : 0.0;
       }
 #pragma unroll
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       if (lq == 0) {
 #pragma unroll
         for (int c = 0; c < W; ++c) {
-          if (lr < w && c <= lr) Dg[lr * (W + 1) + c] = row[c];
+          if (lr < w && c <= lr) DgJ[lr * (W + 1) + c] = row[c];
           Mi[lr * IPM_DENSE_LDS_ROW + c] = inv[c];
         }
         invd[lr] = lr < w ? 1.0 / row[lr] : 0.0;
@@ -1138,16 +1144,16 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       // the diagonal block is stored as d on the diagonal and L11^-1 below it (what the solves use)
       for (int idx = lane; idx < W * W; idx += 64) {
         const int di = idx / W, dj = idx % W;
-        if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = di == dj ? Dg[di * (W + 1) + dj] : Mi[di * IPM_DENSE_LDS_ROW + dj];
+        if (di < w && dj <= di) K[G.at(J0 + di, J0 + dj)] = di == dj ? DgJ[di * (W + 1) + dj] : Mi[di * IPM_DENSE_LDS_ROW + dj];
       }
       if (lane < w) {
-        const double dk = Dg[lane * (W + 1) + lane];
+        const double dk = DgJ[lane * (W + 1) + lane];
         if (dk > 0) ++npos; else if (dk < 0) ++nneg; else ++nbad;
         if (!(fabs(dk) < 1e300)) ++nbad;
       }
-      IPM_LDS_BARRIER();          // B3: (the panel is in LDS)
       IPM_DTICK(2);
     }
+    IPM_LDS_BARRIER();            // the last block column's panel is in LDS (the tile waves' last meeting point)
 #ifdef IPM_TIMING
     if (lane == 0 && sidx == 0) { inst[bi].dbg[6] = tq[0] + tq[2]; inst[bi].dbg[7] = tq[1]; }   // waiting for the tile waves | factoring
 #endif
@@ -1201,8 +1207,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-by[4 * g], bl[4 * g], acc[s], 0, 0, 0); \
   }
   // slot s is a diagonal tile of width wd: its lower triangle goes to Dg for the eighth wave
-#define IPM_PUT_BODY(s, wd) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int c = lq + 4 * g; if (lr < (wd) && c <= lr) Dg[lr * (W + 1) + c] = acc[s][g]; } }
-  if (wv == 0) IPM_PUT_BODY(0, min(W, G.Nb))    // tile (0, 0) is tile number 0: slot 0 of wave 0
+#define IPM_PUT_BODY(s, wd, dg) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int c = lq + 4 * g; if (lr < (wd) && c <= lr) (dg)[lr * (W + 1) + c] = acc[s][g]; } }
+  if (wv == 0) IPM_PUT_BODY(0, min(W, G.Nb), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
   IPM_LDS_BARRIER();              // B1 of block column 0
   IPM_LDS_BARRIER();              // B2: its diagonal block is factored
 #ifdef IPM_TIMING
@@ -1230,6 +1236,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     // the tiles below the diagonal one: Y^T = L11^-1 A^T, L^T = D^-1 Y^T; both go to LDS for the updates, L to the storage
     {
       const int sa = first_slot_at(cs + 1), sb = min(MAXS, first_slot_at(cs1));   // slots [sa, sb)
+      const bool first_owner = (cs + 1) % NWV == wv;   // this wave's first tile of the column is (J + 1, J): the rows the next diagonal tile needs
       switch (sa) {
 #define IPM_PANEL(s) case s: if (s < sb) {                                                                                   \
           d4 y = {0.0, 0.0, 0.0, 0.0};                                                                                       \
@@ -1253,6 +1260,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
                border row (its BY) — the two differ in the last bit, and Delta-III's path is sensitive to that */            \
             BY[lo_ + 4 * g] = ok ? (border ? y[g] : l * dv[c]) : 0.0;                                                        \
           }                                                                                                                  \
+          if (s == sa && first_owner) __hip_atomic_store(&hand_over, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
         }
         IPM_REP22(IPM_PANEL)
 #undef IPM_PANEL
@@ -1260,24 +1268,26 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       }
     }
     IPM_TTICK(0);               // panel
-    IPM_LDS_BARRIER();            // B3: the panel is in LDS
-    IPM_TTICK(1);               // waiting at B3
-    // every tile to the right takes its update; the next diagonal tile first, so that the eighth wave factors it meanwhile
+    // every tile to the right takes its update; the next diagonal tile first and BEFORE the workgroup meets: its owner needs the
+    // panel's rows of block row J + 1 only, which their owner announces (hand_over) after its first tile.  One barrier then says
+    // both "the panel is in LDS" and "the next diagonal tile is in its copy of Dg" (they were two, with this update between them)
     int s0 = first_slot_at(cs1);
-    if (J + 1 < nbb) {
-      if (cs1 % NWV == wv) {
-        const int w1 = min(W, G.Nb - (J0 + W));
-        switch (s0) {
-#define IPM_NEXT(s) case s: IPM_UPD_BODY(s) IPM_PUT_BODY(s, w1) break;
-          IPM_REP22(IPM_NEXT)
+    if (J + 1 < nbb && cs1 % NWV == wv) {
+      const int w1 = min(W, G.Nb - (J0 + W));
+      double* DgN = Dg + ((J + 1) & 1) * DGN;
+      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
+        __builtin_amdgcn_s_sleep(1);
+      switch (s0) {
+#define IPM_NEXT(s) case s: IPM_UPD_BODY(s) IPM_PUT_BODY(s, w1, DgN) break;
+        IPM_REP22(IPM_NEXT)
 #undef IPM_NEXT
-          default: break;
-        }
-        ++s0;
+        default: break;
       }
-      IPM_LDS_BARRIER();          // B1 of block column J + 1
-      IPM_TTICK(2);             // next diagonal tile + B1
+      ++s0;
     }
+    IPM_TTICK(2);               // next diagonal tile
+    IPM_LDS_BARRIER();            // the panel is in LDS; B1 of block column J + 1
+    IPM_TTICK(1);               // waiting there
     if (forward) forward_share(J);
     switch (s0) {
 #define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);   /* two tiles' loads and products may interleave, not all 22 (registers) */
@@ -1315,7 +1325,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_LDS_BARRIER
 }
 size_t kkt_factor_dense_lds_bytes(int block_rows) {
-  return (size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + 2 * IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW +
+  return (2 * size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + 2 * IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW +
           size_t(block_rows) * IPM_W + IPM_W) * sizeof(double);
 }
 int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of this many block rows
