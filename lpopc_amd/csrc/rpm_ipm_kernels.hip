@@ -710,6 +710,35 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
     const int r = idx / nb, c = idx % nb;
     if (r >= c) C[ct(r, c)] = K[G.at(G.Nb + r, G.Nb + c)];
   }
+  // corner -= L_border D L_border^T of a block column: the 16 x 16 tiles of its lower triangle dealt to the waves w0, w0 + 1, ..
+  // (nw of them), four matrix products each (the scalar form — 16 FMAs per entry fed by LDS reads 128 bytes apart, a 16-way bank
+  // conflict — was 73 % of a separator group's factorisation and 23 % of an interval's).  It only needs the column's border rows of
+  // L and L D (BL, BY), which stay in LDS until the NEXT panel is solved: so block column J's update runs on the waves that are
+  // idle while wave 0 factors the diagonal block of J + 1 (it was a phase of its own, 15 % of an interval block of the metric problem).
+  auto corner_update = [&](int w0, int nw) {
+    const int nbt = (nb + 15) >> 4, ntl = nbt * (nbt + 1) / 2;
+    for (int tl = wv - w0; tl < ntl; tl += nw) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+      const int tj = tl - ti * (ti + 1) / 2, ra = ti * 16 + lr, cb = tj * 16 + lr;
+      d4 cacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rr = ti * 16 + lq + 4 * g;
+        cacc[g] = (rr < nb && cb <= rr) ? C[ct(rr, cb)] : 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double a = ra < nb ? -BL[ra * W + 4 * g + lq] : 0.0, bq = cb < nb ? BY[cb * W + 4 * g + lq] : 0.0;
+        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, cacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rr = ti * 16 + lq + 4 * g;
+        if (rr < nb && cb <= rr) C[ct(rr, cb)] = cacc[g];
+      }
+    }
+  };
   for (int J0 = 0; J0 < G.Nb;) {
     const int J1 = min(J0 + W, G.Nb), w = J1 - J0;
     const int kbase = max(J0 - G.b, 0), nk = J0 - kbase, ngrp = (nk + 3) >> 2;
@@ -777,7 +806,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
       }
     }
     IPM_TICK(1);
-    if (wv == 0) {              // tile 0 holds the diagonal block (rows q < w): its LDL^T and the inverse of L11 by this wave
+    if (wv != 0) {
+      if (J0 > 0 && nb > 0) corner_update(1, NW - 1);    // the previous block column's, while wave 0 is busy below
+    } else {                    // tile 0 holds the diagonal block (rows q < w): its LDL^T and the inverse of L11 by this wave
 #if IPM_DIAG_SPLIT
       // the accumulator tile is DiagStep's layout already: lane (lq, lr) holds columns lq + 4 g of row lr
       double R[4], V[4];
@@ -871,35 +902,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
     }
     __syncthreads();
     IPM_TICK(3);
-    {   // corner -= L_border D L_border^T of this block column: the 16 x 16 tiles of its lower triangle dealt to the waves, four
-        // matrix products each (the scalar form — 16 FMAs per entry fed by LDS reads 128 bytes apart, a 16-way bank conflict —
-        // was 73 % of a separator group's factorisation and 23 % of an interval's)
-      const int nbt = (nb + 15) >> 4, ntl = nbt * (nbt + 1) / 2;
-      for (int tl = wv; tl < ntl; tl += NW) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
-        const int tj = tl - ti * (ti + 1) / 2, ra = ti * 16 + lr, cb = tj * 16 + lr;
-        d4 cacc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int rr = ti * 16 + lq + 4 * g;
-          cacc[g] = (rr < nb && cb <= rr) ? C[ct(rr, cb)] : 0.0;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const double a = ra < nb ? -BL[ra * W + 4 * g + lq] : 0.0, bq = cb < nb ? BY[cb * W + 4 * g + lq] : 0.0;
-          cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, cacc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int rr = ti * 16 + lq + 4 * g;
-          if (rr < nb && cb <= rr) C[ct(rr, cb)] = cacc[g];
-        }
-      }
-    }
-    __syncthreads();
     IPM_TICK(4);
     J0 = J1;
+  }
+  if (G.Nb > 0 && nb > 0) {          // the last block column's corner update
+    corner_update(0, NW);
+    __syncthreads();
   }
   if (partial) {                                            // level 1 of the nested dissection: hand the corner over as it is
     for (int idx = t; idx < nb * nb; idx += nt) {
