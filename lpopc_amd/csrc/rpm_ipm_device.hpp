@@ -116,6 +116,8 @@ struct IpmDev {
   int n_cg_long, n_cg2_long;             // leading corner-gather destinations with >= 32 sources (a wave each)
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
+  size_t l2_dense_lds, last_dense_lds;   // the same for the groups of separators (partial, like level 1) and for the last level (that kernel then
+                                         // eliminates the corner's block columns as well); option "upper_dense"
   // df_on: that kernel builds its interval block from the Jacobian / Hessian / diagonal terms itself instead of reading what
   // ipm_fill_kernel wrote (which then fills only the as_nlive chunks as_live[] of the storage that do not lie inside a level-1 block): the structural
   // slots of level-1 sub-problem s are df_ki / df_hg [df_ptr[3 s], df_ptr[3 s + 3]) (coded like as_ki / as_hg; Jacobian entries from

@@ -988,7 +988,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 // are the left-looking kernel's bit for bit.  Partial elimination only (the band part; the border x border corner is handed
 // on as the Schur complement).
 __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
-                                                                  int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble, int forward) {
+                                                                  int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble, int forward,
+                                                                  int partial) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W, NWV = IPM_DENSE_TILE_WAVES, MAXS = IPM_DENSE_SLOTS;
   // the barriers of this kernel order LDS traffic only: __syncthreads() would also wait for the stores of L into the storage
@@ -1001,6 +1002,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   const KktGeom G = sub.g;
   double* K = Kall + size_t(bi) * kstride + sub.koff;
   const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr, ntl = NTB * (NTB + 1) / 2;
+  const int nbe = partial ? nbb : NTB;    // block columns to eliminate: the band part, or (the last level) the corner's as well
   extern __shared__ double lds[];
   double* Dg = lds;                       // 2 x W x (W + 1): the diagonal tile of block column J in copy J & 1 (the next one is handed over
                                           // while the eighth wave still stores the current one)
@@ -1071,8 +1073,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #else
 #define IPM_DTICK(i)
 #endif
-    for (int J = 0; J < nbb; ++J) {
-      const int J0 = W * J, w = min(W, G.Nb - J0);
+    for (int J = 0; J < nbe; ++J) {
+      const int J0 = row0(J), w = min(W, rend(J) - J0);
       double* DgJ = Dg + (J & 1) * DGN;
       IPM_LDS_BARRIER();          // B1: the owner of tile (J, J) has put it into its copy of Dg — and, from J = 1 on, block column J - 1's panel is in LDS
       IPM_DTICK(0);
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   }
   // slot s is a diagonal tile of width wd: its lower triangle goes to Dg for the eighth wave
 #define IPM_PUT_BODY(s, wd, dg) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int c = lq + 4 * g; if (lr < (wd) && c <= lr) (dg)[lr * (W + 1) + c] = acc[s][g]; } }
-  if (wv == 0) IPM_PUT_BODY(0, min(W, G.Nb), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
+  if (wv == 0) IPM_PUT_BODY(0, min(W, rend(0)), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
   IPM_LDS_BARRIER();              // B1 of block column 0
   IPM_LDS_BARRIER();              // B2: its diagonal block is factored
 #ifdef IPM_TIMING
@@ -1237,8 +1239,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       rsh[I * W + lr] -= a;
     }
   };
-  for (int J = 0; J < nbb; ++J) {
-    const int J0 = W * J, w = min(W, G.Nb - J0);
+  for (int J = 0; J < nbe; ++J) {
+    const int J0 = row0(J), w = min(W, rend(J) - J0);
     const int cs = colstart(J), cs1 = colstart(J + 1);
     IPM_TTICK(4);               // waiting at B2
     // the tiles below the diagonal one: Y^T = L11^-1 A^T, L^T = D^-1 Y^T; both go to LDS for the updates, L to the storage
@@ -1280,8 +1282,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     // panel's rows of block row J + 1 only, which their owner announces (hand_over) after its first tile.  One barrier then says
     // both "the panel is in LDS" and "the next diagonal tile is in its copy of Dg" (they were two, with this update between them)
     int s0 = first_slot_at(cs1);
-    if (J + 1 < nbb && cs1 % NWV == wv) {
-      const int w1 = min(W, G.Nb - (J0 + W));
+    if (J + 1 < nbe && cs1 % NWV == wv) {
+      const int w1 = min(W, rend(J + 1) - row0(J + 1));
       double* DgN = Dg + ((J + 1) & 1) * DGN;
       for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
         __builtin_amdgcn_s_sleep(1);
@@ -1304,7 +1306,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       default: break;
     }
     IPM_TTICK(3);               // update
-    if (J + 1 < nbb) IPM_LDS_BARRIER();   // B2 of block column J + 1
+    if (J + 1 < nbe) IPM_LDS_BARRIER();   // B2 of block column J + 1
   }
 #ifdef IPM_TIMING
   // (build with -DIPM_TIMING_SUB=<out of range> so that the left-looking kernel of the last level leaves these alone:
@@ -1320,7 +1322,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   // the Schur complement of the corner, unfactored, back into the corner's storage
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
-    if ((sIK[s] & 255) >= nbb && wv + NWV * s < ntl) {
+    if (partial && (sIK[s] & 255) >= nbb && wv + NWV * s < ntl) {
       const int r = row0(sIK[s] >> 8) + lr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -2149,8 +2151,14 @@ __global__ void kkt_vec_kernel(double* vall, long long vstride, const int* __res
 
 // level 1 assembled and forward-substituted inside kkt_factor_dense_kernel
 int kkt_level1_fused(const IpmDev& D) { return (D.n_l1 > 0 && D.l1_dense_lds && D.df_on && D.df_map) ? 1 : 0; }
-static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partial, int tiles_per_wave, size_t lds_bytes, hipStream_t st) {
+static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partial, int tiles_per_wave, size_t lds_bytes, hipStream_t st,
+                               size_t dense_lds = 0) {
   const dim3 grid(unsigned(D.B) * unsigned(n_here));
+  if (dense_lds) {   // every sub-problem of this level fits the register tiles
+    hipLaunchKernelGGL(kkt_factor_dense_kernel, grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, D, 0, 0,
+                       partial);
+    return;
+  }
   if (tiles_per_wave == 28)
     hipLaunchKernelGGL((kkt_factor_kernel<2, 8>), grid, dim3(512), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
   else if (tiles_per_wave == 38)
@@ -2189,15 +2197,15 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
   }
   if (D.l1_dense_lds)                                                                  // every interval up to its corner
     hipLaunchKernelGGL(kkt_factor_dense_kernel, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
-                       D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused);
+                       D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused, 1);
   else
     launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);
   corners(D.cg_ptr, D.cg_src, D.cg_dst, D.n_cg, D.n_cg_long);
   if (D.n_l2) {
-    launch_factor_subs(D, D.n_l1, D.n_l2, 1, tiles_per_wave, lds_bytes, st);          // every group of separators up to its corner
+    launch_factor_subs(D, D.n_l1, D.n_l2, 1, tiles_per_wave, lds_bytes, st, D.l2_dense_lds);   // every group of separators up to its corner
     corners(D.cg2_ptr, D.cg2_src, D.cg2_dst, D.n_cg2, D.n_cg2_long);
   }
-  launch_factor_subs(D, D.n_l1 + D.n_l2, 1, 0, tiles_per_wave, lds_bytes, st);        // last level: (group) separators + border
+  launch_factor_subs(D, D.n_l1 + D.n_l2, 1, 0, tiles_per_wave, lds_bytes, st, D.last_dense_lds);   // last level: (group) separators + border
 }
 void kkt_launch_solve(const IpmDev& D, int check_status, hipStream_t st, int forward_done) {
   const unsigned VB = unsigned(D.B) * unsigned(D.rhs_mult > 1 ? D.rhs_mult : 1);   // right-hand sides in D.rhs (rhs_mult per instance)

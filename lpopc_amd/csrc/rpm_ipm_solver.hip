@@ -23,6 +23,7 @@ struct rpm_ipm {
   int* h_cnt = nullptr;           // page-locked mirror of D.cnt
   size_t factor_lds = 0;
   size_t l1_dense_lds = 0;    // LDS of kkt_factor_dense_kernel when every level-1 sub-problem fits its register tiles, else 0
+  size_t l2_dense_lds = 0, last_dense_lds = 0;   // the same for the groups of separators and for the last level
   int factor_mt = IPM_MT;
   std::string err;
   std::vector<IpmInst> h_inst;
@@ -236,15 +237,24 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     D.n_l1 = p.nd ? D.n_sub - 1 - D.n_l2 : 0;
     D.max_sub_nt = 0;
     for (const KktSub& q : subs) D.max_sub_nt = std::max(D.max_sub_nt, q.g.Nt);
-    D.l1_dense_lds = 0;
+    D.l1_dense_lds = D.l2_dense_lds = D.last_dense_lds = 0;
     if (D.n_l1 > 0) {
-      int rows = 0;   // most 16-row blocks (band + border) of a level-1 sub-problem
-      for (int i = 0; i < D.n_l1; ++i) rows = std::max(rows, (subs[size_t(i)].g.Nb + IPM_W - 1) / IPM_W + (subs[size_t(i)].g.nb + IPM_W - 1) / IPM_W);
-      if (rows <= kkt_factor_dense_max_block_rows()) {
-        h->l1_dense_lds = kkt_factor_dense_lds_bytes(rows);
-        if (kkt_factor_dense_prepare(h->l1_dense_lds) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
-      }
+      auto dense_lds_of = [&](int first, int count) -> size_t {   // LDS of kkt_factor_dense_kernel for these sub-problems, 0: one does not fit
+        int rows = 0;   // most 16-row blocks (band + border)
+        for (int i = first; i < first + count; ++i)
+          rows = std::max(rows, (subs[size_t(i)].g.Nb + IPM_W - 1) / IPM_W + (subs[size_t(i)].g.nb + IPM_W - 1) / IPM_W);
+        return count > 0 && rows <= kkt_factor_dense_max_block_rows() ? kkt_factor_dense_lds_bytes(rows) : 0;
+      };
+      h->l1_dense_lds = dense_lds_of(0, D.n_l1);
+      h->l2_dense_lds = dense_lds_of(D.n_l1, D.n_l2);
+      h->last_dense_lds = dense_lds_of(D.n_l1 + D.n_l2, 1);
+      const size_t most = std::max(h->l1_dense_lds, std::max(h->l2_dense_lds, h->last_dense_lds));
+      if (most && kkt_factor_dense_prepare(most) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
       if (!(std::getenv("RPM_IPM_DENSE") && std::atoi(std::getenv("RPM_IPM_DENSE")) == 0)) D.l1_dense_lds = h->l1_dense_lds;   // option "level1_dense"
+      if (!(std::getenv("RPM_IPM_UPPER_DENSE") && std::atoi(std::getenv("RPM_IPM_UPPER_DENSE")) == 0)) {                      // option "upper_dense"
+        D.l2_dense_lds = h->l2_dense_lds;
+        D.last_dense_lds = h->last_dense_lds;
+      }
     }
     // level 1 assembled by kkt_factor_dense_kernel itself (IpmDev::df_on): per interval block the list of its structural slots and,
     // per register tile lane, which of them it holds; the fill leaves out the chunks that lie inside such a block
@@ -378,6 +388,10 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "level1_dense") {   // level 1 of the nested dissection on kkt_factor_dense_kernel (default where the interval blocks fit it)
     if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 17 block rows"; return RPM_E_UNSUPPORTED; }
     h->D.l1_dense_lds = value != 0.0 ? h->l1_dense_lds : 0;
+  }
+  else if (k == "upper_dense") {    // the levels above the interval blocks on kkt_factor_dense_kernel too (default where their sub-problems fit it)
+    h->D.l2_dense_lds = value != 0.0 ? h->l2_dense_lds : 0;
+    h->D.last_dense_lds = value != 0.0 ? h->last_dense_lds : 0;
   }
   else if (k == "fused_fill") {     // level-1 blocks assembled inside kkt_factor_dense_kernel (default where that kernel runs and the tables exist)
     if (value != 0.0 && !h->D.df_map) { h->err = "fused_fill: level 1 does not run on kkt_factor_dense_kernel"; return RPM_E_UNSUPPORTED; }

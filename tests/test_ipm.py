@@ -231,6 +231,38 @@ def test_register_resident_level_1_equals_the_left_looking_kernel(built, name, m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("group", [0, 48], ids=["two_levels", "three_levels"])
+@pytest.mark.parametrize("name,make,B", [("quadrotor_24x4", lambda: problems.quadrotor(24, 4), 2), ("launch_16x4", lambda: problems.launch(16, 4), 1),
+                                         ("launch_2x16", lambda: problems.launch(2, 16), 1)], ids=["quadrotor_24x4", "launch_16x4", "launch_2x16"])
+def test_register_resident_upper_levels(built, name, make, B, group):
+    """Option upper_dense (default where the sub-problems fit): the groups of separators and the last level on
+    kkt_factor_dense_kernel as well — the last level with the corner's block columns eliminated by the same kernel (blocked, where
+    kkt_factor_kernel runs the corner unblocked: the two agree to rounding, not bit for bit).  Both solve to 1e-11 of numpy with
+    the same inertia (the groups' partial elimination is the level-1 code path, whose bit-identity
+    test_register_resident_level_1_equals_the_left_looking_kernel holds)."""
+    from lpopc_amd.engine import BatchedIPM, NLPEngine
+    eng = NLPEngine(make(), _exact(), n_instances=B, device=0)
+    eng.set_option("ipm_nested", 1)
+    if group:
+        eng.set_option("ipm_nested_group", group)
+    ipm = BatchedIPM(eng)
+    dense, sign, filled = _random_kkt_dense(ipm, eng.n, B, 29)
+    rhs = np.random.RandomState(13).uniform(-1, 1, size=(B, sign.size))
+    sols = []
+    for on in (1, 0):
+        ipm.set_option("upper_dense", on)
+        sol, npos, nneg = ipm.debug_solve_dense(dense, rhs)
+        for bi in range(B):
+            ref = np.linalg.solve(dense[bi], rhs[bi])
+            assert np.max(np.abs(sol[bi] - ref)) <= 1e-11 * np.max(np.abs(ref))
+            assert npos[bi] == (sign > 0).sum() and nneg[bi] == (sign < 0).sum()
+        sols.append(sol)
+    assert np.max(np.abs(sols[0] - sols[1])) <= 1e-11 * np.max(np.abs(sols[1]))
+    ipm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hessian", ["exact", "limited-memory"])
 def test_level_1_assembled_in_the_factor_kernel_changes_nothing(built, hessian):
     """Option fused_fill (default where kkt_factor_dense_kernel runs): the interval blocks are built from the Jacobian, Hessian
