@@ -379,6 +379,9 @@ int rpm_synchronize(rpm_engine* e);
  * "ipm_nested_group" 0 (default: automatic) | positions per group: with nested dissection the separator system (block
  *                    tridiagonal along time) of a long mesh is cut once more into groups of this many of its positions, each
  *                    eliminated by a workgroup of its own (automatic: when that system is >= 512 long, groups of ~sqrt(length * bandwidth))
+ * "ipm_local_border" 1 (default) | 0, read by rpm_ipm_create: with nested dissection an interval's block carries rows only for the
+ *                    unknowns of the global border that its interior has entries with (its phase's t0 and tf, the phase's final
+ *                    states for the last interval); 0: every interval carries the whole border (rows of zeros in L)
  * "zero_copy"        1 (default): the tile kernel reads x straight from page-locked host memory and stores g straight into it
  *                    (the caller's arrays with "pin_host", else the engine's staging buffers) — no copy-engine operations,
  *                    one launch + one synchronisation per rpm_eval_g; 0: through the engine's HBM buffers with copy-engine transfers

@@ -551,6 +551,9 @@ int rpm_set_option(rpm_engine* h, const char* key, int value) {
     if (value != 0 && value != 1) return fail(e, RPM_E_INVALID, "const_once must be 0 or 1");
     e.opt_const_once = value;
     e.const_filled = nullptr;
+  } else if (k == "ipm_local_border") {
+    if (e.ipm_attached > 0) return fail(e, RPM_E_INVALID, "ipm_local_border must be set before rpm_ipm_create");
+    e.opt_ipm_local_border = value != 0.0;
   } else if (k == "ipm_nested_group") {
     if (value < 0) return fail(e, RPM_E_INVALID, "ipm_nested_group must be >= 0 (0 = automatic)");
     if (e.ipm_attached > 0) return fail(e, RPM_E_INVALID, "ipm_nested_group must be set before rpm_ipm_create");
@@ -608,6 +611,7 @@ int rpm_get_option(rpm_engine* h, const char* key, int* value) {
   else if (k == "delta_values") *value = e.opt_delta_values;
   else if (k == "ipm_nested") *value = e.opt_ipm_nested;
   else if (k == "ipm_nested_group") *value = e.opt_ipm_nested_group;
+  else if (k == "ipm_local_border") *value = e.opt_ipm_local_border;
   else if (k == "zero_copy") *value = e.opt_zero_copy;
   else if (k == "persistent_values") *value = e.opt_persistent_values;
   else if (k == "pin_host") *value = e.opt_pin_host;

@@ -179,6 +179,7 @@ struct Engine {
   int opt_delta_values = 0;      // host-pointer path: deliver only the runs of `values` that changed since the last delivery into the same array
   int last_delta_total = 0;      // runs of `values` this engine owns (rpm_get_option "delta_total_runs")
   int opt_ipm_nested_group = 0;  // rpm_ipm_create: positions per group when the separator system of the nested dissection is cut again; 0 = automatic (only when it is >= 512 long)
+  int opt_ipm_local_border = 1;  // rpm_ipm_create: an interval block carries only the rows of the global border that its interior has entries with (0: all of them)
   int opt_ipm_nested = -1;       // rpm_ipm_create: nested dissection of the KKT matrix over the mesh intervals (rpm_ipm.hpp): -1 when the structure allows, 0 never, 1 must
   int ipm_attached = 0;          // rpm_ipm solvers built on this engine: they size their buffers from stride_g/values
   // solution kept by finalize_solution (LpopcIpopt.cpp:237-243)

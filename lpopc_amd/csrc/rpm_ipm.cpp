@@ -355,12 +355,40 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
   std::vector<int> nstate0(KI, 0);
   for (int I = 0; I < KI; ++I)
     for (int u : sep[I]) nstate0[I] += sep_state[u];
+  // the unknowns of the global border that an interval's interior has entries with (its phase's t0, tf, the phase's final states
+  // for its last interval, ...): only these get rows in the interval's block — the others' rows of L would be zeros, carried
+  // through every panel, corner update, gather and substitution.  Engine option ipm_local_border 0: every interval carries them all.
+  std::vector<std::vector<int>> gb(KI);
+  if (e.opt_ipm_local_border) {
+    auto touch = [&](int ua, int uc) {
+      const int Ia = ivl_of[ua], Ic = ivl_of[uc];
+      if ((Ia >= 0) == (Ic >= 0)) return;
+      const int I = Ia >= 0 ? Ia : Ic, u = Ia >= 0 ? uc : ua;
+      if (sep_of[u] < 0) gb[I].push_back(l2pos[u] - Nb2);
+    };
+    for (int k = 0; k < e.nnz_jac; ++k)
+      if (!p.fixed[e.jac_j[k]]) touch(p.nv + e.jac_i[k], e.jac_j[k]);
+    for (int k = 0; k < e.nnz_h; ++k)
+      if (!p.fixed[e.hes_i[k]] && !p.fixed[e.hes_j[k]]) touch(e.hes_i[k], e.hes_j[k]);
+    for (int s = 0; s < p.ns; ++s) touch(p.nv + p.slack_row[s], p.n + s);
+    for (auto& v : gb) {
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+  } else {
+    for (auto& v : gb)
+      for (int j = 0; j < p.nb; ++j) v.push_back(j);
+  }
+  auto gb_index = [&](int I, int j) -> int {   // local number of global-border unknown j in interval I, or -1
+    const auto it = std::lower_bound(gb[I].begin(), gb[I].end(), j);
+    return it != gb[I].end() && *it == j ? int(it - gb[I].begin()) : -1;
+  };
   std::vector<int> base(KI), nI(KI), nbL(KI);
   int cur = 0;
   for (int I = 0; I < KI; ++I) {
     base[I] = cur;
     nI[I] = int(iv[I].interior.size());
-    nbL[I] = int(sep[I].size()) + (iv[I].last ? 0 : nstate0[I + 1]) + p.nb;   // own separator, the NEXT interval's first-node states, border
+    nbL[I] = int(sep[I].size()) + (iv[I].last ? 0 : nstate0[I + 1]) + int(gb[I].size());   // own separator, the NEXT interval's first-node states, its part of the border
     for (int q = 0; q < nI[I]; ++q) { const int u = iv[I].interior[q]; C.loc[u] = q; p.pos[u] = cur + q; }
     cur += nI[I] + nbL[I];
   }
@@ -373,7 +401,10 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
   auto lborder = [&](int I, int u) -> int {
     if (sep_of[u] == I) return l2pos[u] - iv[I].sep0;
     if (!iv[I].last && sep_of[u] == I + 1) return sep_state[u] ? int(sep[I].size()) + (l2pos[u] - iv[I + 1].sep0) : -1;
-    if (sep_of[u] < 0 && ivl_of[u] < 0) return int(sep[I].size()) + (iv[I].last ? 0 : nstate0[I + 1]) + (l2pos[u] - Nb2);
+    if (sep_of[u] < 0 && ivl_of[u] < 0) {
+      const int j = gb_index(I, l2pos[u] - Nb2);
+      return j < 0 ? -1 : int(sep[I].size()) + (iv[I].last ? 0 : nstate0[I + 1]) + j;
+    }
     return -1;
   };
 
@@ -535,7 +566,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
       if (!iv[I].last)
         for (int u : sep[I + 1])
           if (sep_state[u]) l2_of[q++] = l2pos[u];
-      for (int j = 0; j < p.nb; ++j) l2_of[q++] = Nb2 + j;
+      for (int j : gb[I]) l2_of[q++] = Nb2 + j;
       for (int r = 0; r < g.nb; ++r) {
         for (int c = 0; c <= r; ++c) {
           const long long o = l2_slot(l2_of[r], l2_of[c]);
@@ -637,6 +668,11 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
   p.nd_last.resize(KI);
   p.nd_nstate0 = nstate0;
   p.nd_sep_state = sep_state;
+  p.nd_gb_ptr.assign(1, 0);
+  for (int I = 0; I < KI; ++I) {
+    p.nd_gb.insert(p.nd_gb.end(), gb[I].begin(), gb[I].end());
+    p.nd_gb_ptr.push_back(int(p.nd_gb.size()));
+  }
   for (int I = 0; I < KI; ++I) { p.nd_sep0[I] = iv[I].sep0; p.nd_nsep[I] = int(sep[I].size()); p.nd_last[I] = iv[I].last ? 1 : 0; }
   return RPM_OK;
 }
@@ -653,7 +689,12 @@ long long ipm_plan_offset(const IpmPlan& p, int ua, int uc) {
   auto lborder = [&](int I, int u) -> int {
     if (p.nd_sep[u] == I) return p.nd_loc[u] - p.nd_sep0[I];
     if (!p.nd_last[I] && p.nd_sep[u] == I + 1) return p.nd_sep_state[u] ? p.nd_nsep[I] + (p.nd_loc[u] - p.nd_sep0[I + 1]) : -1;
-    if (p.nd_sep[u] < 0 && p.nd_ivl[u] < 0) return p.nd_nsep[I] + (p.nd_last[I] ? 0 : p.nd_nstate0[I + 1]) + (p.nd_loc[u] - Nb2);
+    if (p.nd_sep[u] < 0 && p.nd_ivl[u] < 0) {
+      const auto first = p.nd_gb.begin() + p.nd_gb_ptr[I], last = p.nd_gb.begin() + p.nd_gb_ptr[I + 1];
+      const auto it = std::lower_bound(first, last, p.nd_loc[u] - Nb2);
+      if (it == last || *it != p.nd_loc[u] - Nb2) return -1;
+      return p.nd_nsep[I] + (p.nd_last[I] ? 0 : p.nd_nstate0[I + 1]) + int(it - first);
+    }
     return -1;
   };
   const int Ia = p.nd_ivl[ua], Ic = p.nd_ivl[uc];

@@ -72,6 +72,7 @@ struct IpmPlan {
   std::vector<int> rs_dst, rs_src;    // solution scatter: rhs[rs_dst[i]] = rhs[rs_src[i]]
   std::vector<int> gap_pos;           // every position of a level-1 border work space (zeroed before the forward sweep)
   std::vector<int> nd_ivl, nd_loc, nd_sep, nd_sep0, nd_nsep, nd_last, nd_nstate0, nd_sep_state;   // classification kept for ipm_plan_offset
+  std::vector<int> nd_gb_ptr, nd_gb;     // per interval: the global-border unknowns (numbered inside the border) that have rows in its block, ascending
   int max_rows = 0;                   // largest 16 + b + nb over all sub-problems (rows of a block column)
   size_t max_factor_lds = 0;
   long long storage() const { return nd ? storage_nd : (long long)Nt * CS; }
