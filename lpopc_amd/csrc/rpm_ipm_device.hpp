@@ -115,6 +115,7 @@ struct IpmDev {
   int n_cg2, n_rg2, n_rs2;
   int n_cg_long, n_cg2_long;             // leading corner-gather destinations with >= 32 sources (a wave each)
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
+  int df_tiles;                         // tiles per level-1 sub-problem in df_map (>= IPM_DENSE_TILES)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
   size_t l2_dense_lds, last_dense_lds;   // the same for the groups of separators (partial, like level 1) and for the last level (that kernel then
                                          // eliminates the corner's block columns as well); option "upper_dense"
@@ -146,6 +147,19 @@ struct IpmDev {
 
 constexpr int IPM_DENSE_SLOTS = 22, IPM_DENSE_TILE_WAVES = 7, IPM_DENSE_LDS_ROW = 18;   // kkt_factor_dense_kernel: tiles per wave, tile waves, doubles per LDS row
 constexpr int IPM_DENSE_TILES = IPM_DENSE_SLOTS * IPM_DENSE_TILE_WAVES;
+// kkt_factor_dense_kernel keeps the trailing IPM_DENSE_ROWS block rows of a block in registers; a block of up to IPM_DENSE_EARLY more
+// eliminates its first ("early") block columns through the storage: their tiles are loaded, used and put back by the wave that owns them
+constexpr int IPM_DENSE_ROWS = 17, IPM_DENSE_EARLY = 7;
+static_assert(IPM_DENSE_ROWS * (IPM_DENSE_ROWS + 1) / 2 <= IPM_DENSE_TILES, "resident tiles");
+__host__ __device__ inline int ipm_dense_early(int block_rows) { return block_rows > IPM_DENSE_ROWS ? block_rows - IPM_DENSE_ROWS : 0; }
+// number of tile (I, Kb), Kb <= I, of a block of `block_rows` block rows: the resident ones (Kb >= early columns) column by column
+// from 0 — tile t sits in slot t / 7 of wave t % 7 —, the early ones after them
+__host__ __device__ inline int ipm_dense_tile(int block_rows, int I, int Kb) {
+  const int E = ipm_dense_early(block_rows), R = block_rows - E;
+  if (Kb >= E) { const int kr = Kb - E; return kr * R - kr * (kr - 1) / 2 + I - Kb; }
+  return R * (R + 1) / 2 + Kb * block_rows - Kb * (Kb - 1) / 2 + I - Kb;
+}
+__host__ __device__ inline int ipm_dense_tiles_of(int block_rows) { return block_rows * (block_rows + 1) / 2; }
 constexpr int IPM_FILL_CHUNK = 4096;   // doubles of KKT storage one workgroup of ipm_fill_kernel zeroes and fills at a time (2048: 76 us, 4096: 70 us, 8192: 82 us on the metric problem)
 constexpr int IPM_VEC_BLOCKS = 64;   // most workgroups per instance of a vector kernel
 constexpr int IPM_VEC_PART = 24;     // doubles of partial results per workgroup

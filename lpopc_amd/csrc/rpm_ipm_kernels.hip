@@ -1001,7 +1001,9 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   const KktSub sub = subs[sidx];
   const KktGeom G = sub.g;
   double* K = Kall + size_t(bi) * kstride + sub.koff;
-  const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr, ntl = NTB * (NTB + 1) / 2;
+  const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr;
+  // the trailing R block rows live in registers; the E block columns before them ("early") go through the storage
+  const int E = ipm_dense_early(NTB), R = NTB - E, ntl = R * (R + 1) / 2;
   const int nbe = partial ? nbb : NTB;    // block columns to eliminate: the band part, or (the last level) the corner's as well
   extern __shared__ double lds[];
   double* Dg = lds;                       // 2 x W x (W + 1): the diagonal tile of block column J in copy J & 1 (the next one is handed over
@@ -1031,7 +1033,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   if (assemble) {
     if (wv != NWV) {
 #pragma unroll
-      for (int s = 0; s < MAXS; ++s) mp[s] = D.df_map[(size_t(sidx) * IPM_DENSE_TILES + wv + NWV * s) * 64 + lane];
+      for (int s = 0; s < MAXS; ++s) mp[s] = D.df_map[(size_t(sidx) * D.df_tiles + wv + NWV * s) * 64 + lane];
     }
     const int ea = D.df_ptr[3 * sidx], eb = D.df_ptr[3 * sidx + 1], ec = D.df_ptr[3 * sidx + 2], ed = D.df_ptr[3 * sidx + 3];
     const SlotValue value(D, bi);
@@ -1181,17 +1183,63 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   // per tile, so that the LDS reads and matrix products of successive tiles overlap.
 #define IPM_REP22(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21)
   static_assert(MAXS == 22, "IPM_REP22");
-  auto colstart = [&](int Kb) { return Kb * NTB - Kb * (Kb - 1) / 2; };
+  auto colstart = [&](int Kr) { return Kr * R - Kr * (Kr - 1) / 2; };   // first resident tile of block column E + Kr
+  // a tile of an early block column: from / to the storage, in the register tiles' layout (tile (I, Kb) belongs to wave I % 7)
+  auto t_load = [&](int I, int Kb) {
+    d4 a;
+    const int r = row0(I) + lr;
+    const bool rv = r < rend(I), border = r >= G.Nb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cc = row0(Kb) + lq + 4 * g;
+      a[g] = (rv && cc < rend(Kb) && cc <= r && (border || r - cc <= G.b)) ? K[G.at(r, cc)] : 0.0;
+    }
+    return a;
+  };
+  auto t_store = [&](const d4& a, int I, int Kb) {
+    const int r = row0(I) + lr;
+    const bool rv = r < rend(I), border = r >= G.Nb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cc = row0(Kb) + lq + 4 * g;
+      if (rv && cc < rend(Kb) && cc <= r && (border || r - cc <= G.b)) K[G.at(r, cc)] = a[g];
+    }
+  };
+  auto t_update = [&](d4 a, int I, int Kb) {       // A(I, Kb) -= L(I, J) D L(Kb, J)^T from the panel in LDS (IPM_UPD_BODY's products)
+    const double* bl = BL + (I * W + lr) * BS + lq;
+    const double* by = BY + (Kb * W + lr) * BS + lq;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-by[4 * g], bl[4 * g], a, 0, 0, 0);
+    return a;
+  };
+  auto t_put = [&](const d4& a, int wd, double* dg) {   // a diagonal tile of width wd: its lower triangle to Dg
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = lq + 4 * g;
+      if (lr < wd && c <= lr) dg[lr * (W + 1) + c] = a[g];
+    }
+  };
+  if (assemble && E > 0) {       // the early tiles are built in the storage (the values' LDS space is the panel's)
+    for (int Kb = 0; Kb < E; ++Kb)
+      for (int I = Kb; I < NTB; ++I) {
+        if (I % NWV != wv) continue;
+        const unsigned long long m = D.df_map[(size_t(sidx) * D.df_tiles + ipm_dense_tile(NTB, I, Kb)) * 64 + lane];
+        d4 a;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = vals[(m >> (16 * g)) & 0xffff];
+        t_store(a, I, Kb);
+      }
+  }
   int sIK[MAXS];                // block row << 8 | block column of the slot's tile (wave-uniform); unused slots: tile (0, 0), never stored
   d4 acc[MAXS];
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
     const int tl = wv + NWV * s;
     int Kb = 0;
-    while (Kb + 1 < NTB && colstart(Kb + 1) <= tl) ++Kb;
+    while (Kb + 1 < R && colstart(Kb + 1) <= tl) ++Kb;
     const bool have = tl < ntl;
-    const int I = have ? Kb + (tl - colstart(Kb)) : 0;
-    Kb = have ? Kb : 0;
+    const int I = have ? E + Kb + (tl - colstart(Kb)) : 0;
+    Kb = have ? E + Kb : 0;
     sIK[s] = __builtin_amdgcn_readfirstlane(I << 8 | Kb);
     if (assemble) {
 #pragma unroll
@@ -1218,7 +1266,10 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   }
   // slot s is a diagonal tile of width wd: its lower triangle goes to Dg for the eighth wave
 #define IPM_PUT_BODY(s, wd, dg) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { const int c = lq + 4 * g; if (lr < (wd) && c <= lr) (dg)[lr * (W + 1) + c] = acc[s][g]; } }
-  if (wv == 0) IPM_PUT_BODY(0, min(W, rend(0)), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
+  if (wv == 0) {
+    if (E == 0) IPM_PUT_BODY(0, min(W, rend(0)), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
+    else t_put(t_load(0, 0), min(W, rend(0)), Dg);
+  }
   IPM_LDS_BARRIER();              // B1 of block column 0
   IPM_LDS_BARRIER();              // B2: its diagonal block is factored
 #ifdef IPM_TIMING
@@ -1241,7 +1292,66 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   };
   for (int J = 0; J < nbe; ++J) {
     const int J0 = row0(J), w = min(W, rend(J) - J0);
-    const int cs = colstart(J), cs1 = colstart(J + 1);
+    if (J < E) {
+      // ---- an early block column: the same steps with its tiles (and those of the early columns to its right) taken from the
+      // storage and put back, each by the wave that owns it; the resident tiles take their update as always
+      IPM_TTICK(4);
+      for (int I = J + 1; I < NTB; ++I) {
+        if (I % NWV != wv) continue;
+        const d4 a = t_load(I, J);
+        d4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], a[g], y, 0, 0, 0);
+        const int r = row0(I) + lr;
+        const bool rv = r < rend(I), border = r >= G.Nb;
+        const int kstep = border ? G.CS : G.CS - 1;
+        double* kp = K + (size_t(J0) * G.CS + (border ? G.b + 1 + r - G.Nb : r - J0)) + lq * kstep;
+        const int lo_ = (I * W + lr) * BS + lq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = lq + 4 * g;
+          const double l = y[g] * invd[c];
+          const bool ok = rv && c < w;
+          if (ok && (border || r - (J0 + c) <= G.b)) kp[4 * g * kstep] = l;
+          BL[lo_ + 4 * g] = ok ? l : 0.0;
+          BY[lo_ + 4 * g] = ok ? (border ? y[g] : l * dv[c]) : 0.0;
+        }
+        if (I == J + 1) __hip_atomic_store(&hand_over, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      IPM_TTICK(0);
+      int s0 = 0;
+      if (J + 1 < nbe) {        // the next diagonal tile, before the workgroup meets
+        const int w1 = min(W, rend(J + 1) - row0(J + 1));
+        double* DgN = Dg + ((J + 1) & 1) * DGN;
+        if (J + 1 < E) {
+          if ((J + 1) % NWV == wv) t_put(t_update(t_load(J + 1, J + 1), J + 1, J + 1), w1, DgN);   // (this wave wrote the panel's rows it needs)
+        } else if (wv == 0) {   // the first resident tile: slot 0 of wave 0
+          for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
+            __builtin_amdgcn_s_sleep(1);
+          IPM_UPD_BODY(0) IPM_PUT_BODY(0, w1, DgN)
+          s0 = 1;
+        }
+      }
+      IPM_TTICK(2);
+      IPM_LDS_BARRIER();          // the panel is in LDS; B1 of block column J + 1
+      IPM_TTICK(1);
+      if (forward) forward_share(J);
+      switch (s0) {
+#define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        IPM_REP22(IPM_UPD)
+#undef IPM_UPD
+        default: break;
+      }
+      for (int Kb = J + 1; Kb < E; ++Kb)
+        for (int I = Kb + (Kb == J + 1 ? 1 : 0); I < NTB; ++I) {
+          if (I % NWV != wv) continue;
+          t_store(t_update(t_load(I, Kb), I, Kb), I, Kb);
+        }
+      IPM_TTICK(3);
+      if (J + 1 < nbe) IPM_LDS_BARRIER();   // B2 of block column J + 1
+      continue;
+    }
+    const int cs = colstart(J - E), cs1 = colstart(J - E + 1);
     IPM_TTICK(4);               // waiting at B2
     // the tiles below the diagonal one: Y^T = L11^-1 A^T, L^T = D^-1 Y^T; both go to LDS for the updates, L to the storage
     {
@@ -1338,10 +1448,8 @@ size_t kkt_factor_dense_lds_bytes(int block_rows) {
   return (2 * size_t(IPM_W) * (IPM_W + 1) + size_t(IPM_W) * IPM_DENSE_LDS_ROW + 2 * IPM_W + 2 * size_t(block_rows) * IPM_W * IPM_DENSE_LDS_ROW +
           size_t(block_rows) * IPM_W + IPM_W) * sizeof(double);
 }
-int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of this many block rows
-  int n = 1;
-  while ((n + 1) * (n + 2) / 2 <= IPM_DENSE_TILE_WAVES * IPM_DENSE_SLOTS) ++n;
-  return n;
+int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hold the lower triangle of IPM_DENSE_ROWS block rows; the early columns on top
+  return IPM_DENSE_ROWS + IPM_DENSE_EARLY;
 }
 hipError_t kkt_factor_dense_prepare(size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;

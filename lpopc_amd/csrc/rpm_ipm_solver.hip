@@ -262,10 +262,14 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     D.df_ptr = D.df_ki = D.df_hg = D.as_live = nullptr;
     D.as_nlive = 0;
     D.df_map = nullptr;
+    D.df_tiles = IPM_DENSE_TILES;
     if (h->l1_dense_lds && D.as_nchunk > 0 && !(std::getenv("RPM_IPM_FUSED_FILL") && std::atoi(std::getenv("RPM_IPM_FUSED_FILL")) == 0)) {
       // per block the Jacobian entries first, then the Hessian slots, then the rest (slack entries, diagonals): three plain loops in the kernel
       std::vector<int> f_ptr(3 * size_t(D.n_l1) + 1, 0), f_ki, f_hg, skip(size_t(D.as_nchunk), 0);
-      std::vector<unsigned long long> f_map(size_t(D.n_l1) * IPM_DENSE_TILES * 64, 0ull);
+      int df_tiles = IPM_DENSE_TILES;
+      for (int si = 0; si < D.n_l1; ++si)
+        df_tiles = std::max(df_tiles, ipm_dense_tiles_of((subs[size_t(si)].g.Nb + IPM_W - 1) / IPM_W + (subs[size_t(si)].g.nb + IPM_W - 1) / IPM_W));
+      std::vector<unsigned long long> f_map(size_t(D.n_l1) * df_tiles * 64, 0ull);
       bool ok = true;
       size_t e2 = 0;
       for (int si = 0; si < D.n_l1 && ok; ++si) {
@@ -288,9 +292,9 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
             if (i < j || i >= g.Nt || (band && (j >= g.Nb || i - j > g.b)) || (long long)j * g.CS + (band ? i - j : g.b + 1 + i - g.Nb) != o) { ok = false; break; }
             const int I = band ? i / IPM_W : nbb + (i - g.Nb) / IPM_W, Kb = j < g.Nb ? j / IPM_W : nbb + (j - g.Nb) / IPM_W;
             const int lr = i - (I < nbb ? IPM_W * I : g.Nb + IPM_W * (I - nbb)), cc = j - (Kb < nbb ? IPM_W * Kb : g.Nb + IPM_W * (Kb - nbb));
-            const int tile = Kb * NTB - Kb * (Kb - 1) / 2 + I - Kb;
-            if (tile >= IPM_DENSE_TILES || ++number > 0xffff) { ok = false; break; }
-            f_map[(size_t(si) * IPM_DENSE_TILES + tile) * 64 + size_t((cc & 3) * 16 + lr)] |= (unsigned long long)number << (16 * (cc >> 2));
+            const int tile = ipm_dense_tile(NTB, I, Kb);
+            if (tile >= df_tiles || ++number > 0xffff) { ok = false; break; }
+            f_map[(size_t(si) * df_tiles + tile) * 64 + size_t((cc & 3) * 16 + lr)] |= (unsigned long long)number << (16 * (cc >> 2));
             f_ki.push_back(ents[q].ki);
             f_hg.push_back(ents[q].hg);
           }
@@ -308,6 +312,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
           if (!skip[size_t(c)]) live.push_back(c);
         D.as_nlive = int(live.size());
         A_(ipm_alloc_c(h, &D.as_live, live)); A_(ipm_alloc_c(h, &D.df_map, f_map));
+        D.df_tiles = df_tiles;
         D.df_on = 1;
       }
     }
@@ -386,7 +391,7 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   }
   else if (k == "restoration_penalty") o.resto_rho = value;
   else if (k == "level1_dense") {   // level 1 of the nested dissection on kkt_factor_dense_kernel (default where the interval blocks fit it)
-    if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 17 block rows"; return RPM_E_UNSUPPORTED; }
+    if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 24 block rows"; return RPM_E_UNSUPPORTED; }
     h->D.l1_dense_lds = value != 0.0 ? h->l1_dense_lds : 0;
   }
   else if (k == "upper_dense") {    // the levels above the interval blocks on kkt_factor_dense_kernel too (default where their sub-problems fit it)
