@@ -249,7 +249,7 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       "sigma_cap" (0 = off; experimental clamp on z/s in the KKT matrix),
  *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start),
  *                       "level1_dense" (1 where it applies: the interval blocks of the nested dissection are factored out of
- *                       registers, kkt_factor_dense_kernel, when each has at most 24 block rows of 16 (17 resident, the first 7 block columns through the storage); 0 = the left-looking
+ *                       registers, kkt_factor_dense_kernel, when each has at most 21 block rows of 16 (17 resident, the first 4 block columns through the storage); 0 = the left-looking
  *                       kernel for every level; 1 on a layout it does not fit: RPM_E_UNSUPPORTED),
  *                       "fused_fill" (1 where level1_dense runs: that kernel assembles its interval block from the Jacobian,
  *                       Hessian and diagonal terms itself and carries the level-1 forward substitution of the iteration's

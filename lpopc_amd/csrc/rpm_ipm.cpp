@@ -219,8 +219,13 @@ struct L3Map {
   }
   int n_prev(int g) const { return g > 0 ? p.l3_w : 0; }
   int n_own(int g) const { return g < p.l3_G - 1 ? p.l3_w : 0; }
+  int n_gb(int g) const { return p.l3_gb_ptr[g + 1] - p.l3_gb_ptr[g]; }
   int lborder(int g, int a) const {                                             // local border index of a (not interior) seen from group g, or -1
-    if (a >= p.l3_Nb2) return n_prev(g) + n_own(g) + (a - p.l3_Nb2);
+    if (a >= p.l3_Nb2) {
+      const auto first = p.l3_gb.begin() + p.l3_gb_ptr[g], last = p.l3_gb.begin() + p.l3_gb_ptr[g + 1];
+      const auto it = std::lower_bound(first, last, a - p.l3_Nb2);
+      return it != last && *it == a - p.l3_Nb2 ? n_prev(g) + n_own(g) + int(it - first) : -1;
+    }
     const int ga = group(a), idx = a - (ga * p.l3_S + p.l3_S - p.l3_w);
     if (ga == g - 1) return idx;
     if (ga == g) return n_prev(g) + idx;
@@ -447,6 +452,47 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
       if (G >= 2) { p.n_l2 = G; p.l3_S = S; p.l3_w = w; p.l3_G = G; p.l3_Nb2 = Nb2; }
     }
   }
+  if (p.n_l2) {
+    // the global-border unknowns a group's interior has entries with — entries of the KKT matrix itself, and of the intervals' Schur
+    // complements (every pair of an interval's local border): only these get rows in the group's block, as with the intervals
+    std::vector<std::vector<int>> gb2(size_t(p.l3_G));
+    if (e.opt_ipm_local_border) {
+      const L3Map M(p);
+      auto touch = [&](int a, int c) {
+        if (a < c) std::swap(a, c);
+        if (a >= Nb2 && c < Nb2 && M.interior(c)) gb2[size_t(M.group(c))].push_back(a - Nb2);
+      };
+      auto entry = [&](int ua, int uc) {
+        if (ivl_of[ua] < 0 && ivl_of[uc] < 0) touch(l2pos[ua], l2pos[uc]);
+      };
+      for (int k = 0; k < e.nnz_jac; ++k)
+        if (!p.fixed[e.jac_j[k]]) entry(p.nv + e.jac_i[k], e.jac_j[k]);
+      for (int k = 0; k < e.nnz_h; ++k)
+        if (!p.fixed[e.hes_i[k]] && !p.fixed[e.hes_j[k]]) entry(e.hes_i[k], e.hes_j[k]);
+      for (int s = 0; s < p.ns; ++s) entry(p.nv + p.slack_row[s], p.n + s);
+      for (int I = 0; I < KI; ++I) {
+        std::vector<int> seps;                       // the separator positions in I's local border
+        for (int u : sep[I]) seps.push_back(l2pos[u]);
+        if (!iv[I].last)
+          for (int u : sep[I + 1])
+            if (sep_state[u]) seps.push_back(l2pos[u]);
+        for (int a : seps)
+          for (int j : gb[I]) touch(a, Nb2 + j);
+      }
+      for (auto& v : gb2) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+      }
+    } else {
+      for (auto& v : gb2)
+        for (int j = 0; j < p.nb; ++j) v.push_back(j);
+    }
+    p.l3_gb_ptr.assign(1, 0);
+    for (const auto& v : gb2) {
+      p.l3_gb.insert(p.l3_gb.end(), v.begin(), v.end());
+      p.l3_gb_ptr.push_back(int(p.l3_gb.size()));
+    }
+  }
 
   // ---- sub-problem geometry and storage
   long long koff = 0;
@@ -485,7 +531,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
     if (p.n_l2) {
       for (int g = 0; g < p.l3_G; ++g) {
         const int n_g = g < p.l3_G - 1 ? p.l3_S - p.l3_w : Nb2 - g * p.l3_S;
-        push(n_g, (g > 0 ? p.l3_w : 0) + (g < p.l3_G - 1 ? p.l3_w : 0) + p.nb, b2);
+        push(n_g, (g > 0 ? p.l3_w : 0) + (g < p.l3_G - 1 ? p.l3_w : 0) + (p.l3_gb_ptr[size_t(g) + 1] - p.l3_gb_ptr[size_t(g)]), b2);
       }
       p.l3_base = roff;
       push((p.l3_G - 1) * p.l3_w, p.nb, 2 * p.l3_w - 1);
@@ -612,7 +658,7 @@ static int build_ipm_plan_nd(Engine& e, IpmPlan& p, std::string* why) {
       std::vector<int> l3_of;                      // last-level position of local border index
       if (g > 0) for (int j = 0; j < p.l3_w; ++j) l3_of.push_back((g - 1) * p.l3_w + j);
       if (g < p.l3_G - 1) for (int j = 0; j < p.l3_w; ++j) l3_of.push_back(g * p.l3_w + j);
-      for (int j = 0; j < p.nb; ++j) l3_of.push_back(G3.Nb + j);
+      for (int q2 = p.l3_gb_ptr[size_t(g)]; q2 < p.l3_gb_ptr[size_t(g) + 1]; ++q2) l3_of.push_back(G3.Nb + p.l3_gb[size_t(q2)]);
       for (int r = 0; r < q.nb; ++r) {
         for (int c = 0; c <= r; ++c) {
           if (l3_of[r] < G3.Nb && l3_of[r] - l3_of[c] > G3.b) return fail("nested dissection: third-level band too narrow");

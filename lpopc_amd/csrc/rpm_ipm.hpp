@@ -63,6 +63,7 @@ struct IpmPlan {
   // group's separator, its own, the global border), factored up to their corners by a workgroup each; all group separators in
   // order + the global border are the last level.  Delta-III 4 x 64 x 16: one chain of 112 block columns -> 8 + 16.
   int n_l2 = 0, l3_S = 0, l3_w = 0, l3_G = 0, l3_Nb2 = 0, l3_base = 0;
+  std::vector<int> l3_gb_ptr, l3_gb;     // per group: the global-border unknowns (numbered inside the border) that have rows in its block, ascending
   int n_cg_long = 0, n_cg2_long = 0;   // the corner-gather tables start with the destinations that have >= 32 sources (a wave each on the device)
   std::vector<int> cg2_ptr, cg2_src, cg2_dst, rg2_ptr, rg2_src, rg2_dst, rs2_dst, rs2_src;   // second gather / scatter stage (level 2 -> last level)
   std::vector<int> cg_ptr, cg_src;    // corner gather: level-2 storage offset cg_dst[i] += sum of K[cg_src[cg_ptr[i] .. cg_ptr[i+1])]

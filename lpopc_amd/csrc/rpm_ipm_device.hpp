@@ -149,7 +149,8 @@ constexpr int IPM_DENSE_SLOTS = 22, IPM_DENSE_TILE_WAVES = 7, IPM_DENSE_LDS_ROW 
 constexpr int IPM_DENSE_TILES = IPM_DENSE_SLOTS * IPM_DENSE_TILE_WAVES;
 // kkt_factor_dense_kernel keeps the trailing IPM_DENSE_ROWS block rows of a block in registers; a block of up to IPM_DENSE_EARLY more
 // eliminates its first ("early") block columns through the storage: their tiles are loaded, used and put back by the wave that owns them
-constexpr int IPM_DENSE_ROWS = 17, IPM_DENSE_EARLY = 7;
+// (4: three tiles per wave and early column wait in registers beside the resident ones; a fourth spills)
+constexpr int IPM_DENSE_ROWS = 17, IPM_DENSE_EARLY = 4;
 static_assert(IPM_DENSE_ROWS * (IPM_DENSE_ROWS + 1) / 2 <= IPM_DENSE_TILES, "resident tiles");
 __host__ __device__ inline int ipm_dense_early(int block_rows) { return block_rows > IPM_DENSE_ROWS ? block_rows - IPM_DENSE_ROWS : 0; }
 // number of tile (I, Kb), Kb <= I, of a block of `block_rows` block rows: the resident ones (Kb >= early columns) column by column

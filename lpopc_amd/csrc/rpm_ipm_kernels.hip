@@ -987,6 +987,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 // block ~12 times from the L2 / Infinity Cache, a 16-column step every 25 us.  Same products in the same order, so the factors
 // are the left-looking kernel's bit for bit.  Partial elimination only (the band part; the border x border corner is handed
 // on as the Schur complement).
+template <bool EARLY>   // EARLY: blocks of more than IPM_DENSE_ROWS block rows (the steps for their first block columns cost the plain kernel 15 %)
 __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
                                                                   int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble, int forward,
                                                                   int partial) {
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   double* K = Kall + size_t(bi) * kstride + sub.koff;
   const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr;
   // the trailing R block rows live in registers; the E block columns before them ("early") go through the storage
-  const int E = ipm_dense_early(NTB), R = NTB - E, ntl = R * (R + 1) / 2;
+  const int E = EARLY ? ipm_dense_early(NTB) : 0, R = NTB - E, ntl = R * (R + 1) / 2;
   const int nbe = partial ? nbb : NTB;    // block columns to eliminate: the band part, or (the last level) the corner's as well
   extern __shared__ double lds[];
   double* Dg = lds;                       // 2 x W x (W + 1): the diagonal tile of block column J in copy J & 1 (the next one is handed over
@@ -1270,10 +1271,22 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     if (E == 0) IPM_PUT_BODY(0, min(W, rend(0)), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
     else t_put(t_load(0, 0), min(W, rend(0)), Dg);
   }
+  // early block column J: this wave's tiles (I, J), I > J, wait in ebuf (I = first such I + 7 q), tile (J + 1, J + 1) in edg with
+  // the wave that owns it — fetched a step ahead, so that no trip to the storage lies on the chain of diagonal blocks
+  constexpr int EQ = (IPM_DENSE_ROWS + IPM_DENSE_EARLY - 1 + NWV - 1) / NWV;
+  d4 ebuf[EQ], edg;
+  auto first_own = [&](int from) { return from + (wv - from % NWV + NWV) % NWV; };   // first I >= from with I % 7 == wv
+  if (E > 0) {
+    const int f0 = first_own(1);
+#pragma unroll
+    for (int q = 0; q < EQ; ++q)
+      if (f0 + NWV * q < NTB) ebuf[q] = t_load(f0 + NWV * q, 0);
+    if (E > 1 && 1 % NWV == wv) edg = t_load(1, 1);
+  }
   IPM_LDS_BARRIER();              // B1 of block column 0
   IPM_LDS_BARRIER();              // B2: its diagonal block is factored
 #ifdef IPM_TIMING
-  long long tw[5] = {0, 0, 0, 0, 0}, twp = wall_clock64();
+  long long tw[6] = {0, 0, 0, 0, 0, 0}, twp = wall_clock64();
 #define IPM_TTICK(i) do { const long long n_ = wall_clock64(); tw[i] += n_ - twp; twp = n_; } while (0)
 #else
 #define IPM_TTICK(i)
@@ -1294,14 +1307,16 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     const int J0 = row0(J), w = min(W, rend(J) - J0);
     if (J < E) {
       // ---- an early block column: the same steps with its tiles (and those of the early columns to its right) taken from the
-      // storage and put back, each by the wave that owns it; the resident tiles take their update as always
-      IPM_TTICK(4);
-      for (int I = J + 1; I < NTB; ++I) {
-        if (I % NWV != wv) continue;
-        const d4 a = t_load(I, J);
+      // storage, each by the wave that owns it; the resident tiles take their update as always
+      IPM_TTICK(5);
+      const int f0 = first_own(J + 1);
+#pragma unroll
+      for (int q = 0; q < EQ; ++q) {
+        const int I = f0 + NWV * q;
+        if (I >= NTB) break;
         d4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], a[g], y, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], ebuf[q][g], y, 0, 0, 0);
         const int r = row0(I) + lr;
         const bool rv = r < rend(I), border = r >= G.Nb;
         const int kstep = border ? G.CS : G.CS - 1;
@@ -1318,13 +1333,13 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         }
         if (I == J + 1) __hip_atomic_store(&hand_over, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      IPM_TTICK(0);
+      IPM_TTICK(5);
       int s0 = 0;
       if (J + 1 < nbe) {        // the next diagonal tile, before the workgroup meets
         const int w1 = min(W, rend(J + 1) - row0(J + 1));
         double* DgN = Dg + ((J + 1) & 1) * DGN;
         if (J + 1 < E) {
-          if ((J + 1) % NWV == wv) t_put(t_update(t_load(J + 1, J + 1), J + 1, J + 1), w1, DgN);   // (this wave wrote the panel's rows it needs)
+          if ((J + 1) % NWV == wv) t_put(t_update(edg, J + 1, J + 1), w1, DgN);   // (this wave wrote the panel's rows it needs)
         } else if (wv == 0) {   // the first resident tile: slot 0 of wave 0
           for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
             __builtin_amdgcn_s_sleep(1);
@@ -1332,9 +1347,9 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
           s0 = 1;
         }
       }
-      IPM_TTICK(2);
+      IPM_TTICK(5);
       IPM_LDS_BARRIER();          // the panel is in LDS; B1 of block column J + 1
-      IPM_TTICK(1);
+      IPM_TTICK(5);
       if (forward) forward_share(J);
       switch (s0) {
 #define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);
@@ -1342,12 +1357,19 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #undef IPM_UPD
         default: break;
       }
-      for (int Kb = J + 1; Kb < E; ++Kb)
-        for (int I = Kb + (Kb == J + 1 ? 1 : 0); I < NTB; ++I) {
-          if (I % NWV != wv) continue;
-          t_store(t_update(t_load(I, Kb), I, Kb), I, Kb);
-        }
-      IPM_TTICK(3);
+      if (J + 1 < E) {          // the next early column's tiles take their update and stay in registers for its panel (fetched only now:
+        const int f1 = first_own(J + 2);   // in flight during the update above they would push the resident tiles out of the registers)
+#pragma unroll
+        for (int q = 0; q < EQ; ++q)
+          if (f1 + NWV * q < NTB) ebuf[q] = t_load(f1 + NWV * q, J + 1);
+#pragma unroll
+        for (int q = 0; q < EQ; ++q)
+          if (f1 + NWV * q < NTB) ebuf[q] = t_update(ebuf[q], f1 + NWV * q, J + 1);
+      }
+      for (int Kb = J + 2; Kb < E; ++Kb)      // early columns further right: through the storage
+        for (int I = first_own(Kb); I < NTB; I += NWV) t_store(t_update(t_load(I, Kb), I, Kb), I, Kb);
+      if (J + 2 < E && (J + 2) % NWV == wv) edg = t_load(J + 2, J + 2);
+      IPM_TTICK(5);
       if (J + 1 < nbe) IPM_LDS_BARRIER();   // B2 of block column J + 1
       continue;
     }
@@ -1421,7 +1443,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
 #ifdef IPM_TIMING
   // (build with -DIPM_TIMING_SUB=<out of range> so that the left-looking kernel of the last level leaves these alone:
   //  wave 0's panel | wait at B3 | next diagonal tile + B1 | update | wait at B2, 100 MHz ticks per interval block)
-  if (t == 0 && sidx == 0) { inst[bi].dbg[0] = tw[0]; inst[bi].dbg[1] = tw[1]; inst[bi].dbg[2] = tw[2]; inst[bi].dbg[3] = tw[3]; inst[bi].dbg[4] = tw[4]; }
+  if (t == 0 && sidx == 0) { inst[bi].dbg[0] = tw[0]; inst[bi].dbg[1] = tw[1]; inst[bi].dbg[2] = tw[2]; inst[bi].dbg[3] = tw[3]; inst[bi].dbg[4] = tw[4]; inst[bi].dbg[5] = tw[5]; }
 #endif
 #undef IPM_UPD_BODY
 #undef IPM_PUT_BODY
@@ -1453,8 +1475,13 @@ int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hol
 }
 hipError_t kkt_factor_dense_prepare(size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+  const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            int(std::min(lds_bytes, kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS))));
+  if (er != hipSuccess || lds_bytes <= kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS)) return er;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
 }
+// (the LDS size says how many block rows a level's largest block has)
+static bool dense_early(size_t lds_bytes) { return lds_bytes > kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS); }
 
 // L y = r, then x = L^-T D^-1 y, in place in rhs: one workgroup per instance, IPM_W columns per step.  The diagonal
 // blocks hold L11^-1, so a step's own 16 unknowns are 16 parallel dot products.  The right-hand side lives in LDS when it
@@ -2263,8 +2290,12 @@ static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partia
                                size_t dense_lds = 0) {
   const dim3 grid(unsigned(D.B) * unsigned(n_here));
   if (dense_lds) {   // every sub-problem of this level fits the register tiles
-    hipLaunchKernelGGL(kkt_factor_dense_kernel, grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, D, 0, 0,
-                       partial);
+    if (dense_early(dense_lds))
+      hipLaunchKernelGGL(kkt_factor_dense_kernel<true>, grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, D,
+                         0, 0, partial);
+    else
+      hipLaunchKernelGGL(kkt_factor_dense_kernel<false>, grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, D,
+                         0, 0, partial);
     return;
   }
   if (tiles_per_wave == 28)
@@ -2303,8 +2334,11 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
     const unsigned blocks = unsigned(std::max(1, std::min(256, (D.n_gap + 255) / 256)));
     hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, D.gap_pos, nullptr, D.n_gap, 0, D.inst, 3, D.B);
   }
-  if (D.l1_dense_lds)                                                                  // every interval up to its corner
-    hipLaunchKernelGGL(kkt_factor_dense_kernel, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
+  if (D.l1_dense_lds && dense_early(D.l1_dense_lds))                                   // every interval up to its corner
+    hipLaunchKernelGGL(kkt_factor_dense_kernel<true>, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
+                       D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused, 1);
+  else if (D.l1_dense_lds)
+    hipLaunchKernelGGL(kkt_factor_dense_kernel<false>, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
                        D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused, 1);
   else
     launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);

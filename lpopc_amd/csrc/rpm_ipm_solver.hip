@@ -247,6 +247,8 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
       };
       h->l1_dense_lds = dense_lds_of(0, D.n_l1);
       h->l2_dense_lds = dense_lds_of(D.n_l1, D.n_l2);
+      for (int i = D.n_l1; i < D.n_l1 + D.n_l2; ++i)     // groups of a narrow band stay on kkt_factor_kernel, which skips what lies outside the band
+        if (2 * subs[size_t(i)].g.b < subs[size_t(i)].g.Nb) h->l2_dense_lds = 0;
       h->last_dense_lds = dense_lds_of(D.n_l1 + D.n_l2, 1);
       const size_t most = std::max(h->l1_dense_lds, std::max(h->l2_dense_lds, h->last_dense_lds));
       if (most && kkt_factor_dense_prepare(most) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
@@ -391,7 +393,7 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   }
   else if (k == "restoration_penalty") o.resto_rho = value;
   else if (k == "level1_dense") {   // level 1 of the nested dissection on kkt_factor_dense_kernel (default where the interval blocks fit it)
-    if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 24 block rows"; return RPM_E_UNSUPPORTED; }
+    if (value != 0.0 && !h->l1_dense_lds) { h->err = "level1_dense: no nested dissection, or an interval block of more than 21 block rows"; return RPM_E_UNSUPPORTED; }
     h->D.l1_dense_lds = value != 0.0 ? h->l1_dense_lds : 0;
   }
   else if (k == "upper_dense") {    // the levels above the interval blocks on kkt_factor_dense_kernel too (default where their sub-problems fit it)
@@ -590,8 +592,8 @@ int rpm_ipm_debug_solve_dense(rpm_ipm* h, const double* k_dense, const double* r
   IPM_TRY(h, hipMemcpy(inst.data(), D.inst, inst.size() * sizeof(IpmInst), hipMemcpyDeviceToHost));
 #ifdef IPM_TIMING
   // kkt_factor_dense_kernel (build with -DIPM_TIMING_SUB=<out of range>): tile wave 0 and the diagonal wave of interval block 0
-  fprintf(stderr, "level-1 phases of instance 0 [100 MHz ticks]: panel %lld  wait B3 %lld  next diagonal tile + B1 %lld  update %lld  wait B2 %lld | diagonal wave: waiting %lld  factoring %lld\n",
-          inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[6], inst[0].dbg[7]);
+  fprintf(stderr, "level-1 phases of instance 0 [100 MHz ticks]: panel %lld  wait B3 %lld  next diagonal tile + B1 %lld  update %lld  wait B2 %lld  early block columns %lld | diagonal wave: waiting %lld  factoring %lld\n",
+          inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[5], inst[0].dbg[6], inst[0].dbg[7]);
   // kkt_factor_kernel (-DIPM_TIMING_SUB=<sub-problem>): the same record read as the left-looking kernel's phases
   fprintf(stderr, "left-looking phases of instance 0 [100 MHz ticks]: T %lld  k-loop %lld  diag %lld  panel %lld  corner %lld  tail %lld\n",
           inst[0].dbg[0], inst[0].dbg[1], inst[0].dbg[2], inst[0].dbg[3], inst[0].dbg[4], inst[0].dbg[5]);

@@ -1,6 +1,7 @@
 """Phase clocks of kkt_factor_dense_kernel on the sweep's interval blocks (experiment build, perf exploration only):
 make -C lpopc_amd/csrc librpm_exp_ipmt.so EXPFLAGS="-DIPM_TIMING -DIPM_TIMING_SUB=100000" [more -D...]
-RPM_HIP_LIB=lpopc_amd/csrc/librpm_exp_ipmt.so python tests/experiments/dense_phase_clocks.py [instances]"""
+RPM_HIP_LIB=lpopc_amd/csrc/librpm_exp_ipmt.so python tests/experiments/dense_phase_clocks.py [instances] [launch]
+(launch: the metric problem's interval blocks, 19 block rows, on a 4 x 2 x 16 mesh)"""
 import os
 import sys
 import time
@@ -16,7 +17,7 @@ from lpopc_amd.engine import BatchedIPM, NLPEngine
 from test_ipm import _exact, _random_kkt_dense
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-eng = NLPEngine(problems.quadrotor(8, 8), _exact(), n_instances=B, device=0)
+eng = NLPEngine(problems.launch(2, 16) if "launch" in sys.argv[2:] else problems.quadrotor(8, 8), _exact(), n_instances=B, device=0)
 eng.set_option("ipm_nested", 1)
 ipm = BatchedIPM(eng)
 dense, sign, filled = _random_kkt_dense(ipm, eng.n, 1, 23)
