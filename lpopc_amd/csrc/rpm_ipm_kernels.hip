@@ -1494,6 +1494,9 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
   // (the border work space receives -L_border y, this interval's contribution to the separator system's right-hand side),
   // phase 2 = backward over the band blocks only (the work space then holds the separator / border solution)
   constexpr int W = IPM_W;
+  // with the right-hand side in LDS the barriers order LDS traffic only: __syncthreads() would also wait for the factor entries
+  // fetched for the NEXT step (s_waitcnt vmcnt(0)), a trip to the L2 / HBM on the chain of every step
+#define SOLVE_BARRIER() do { if (RL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads(); } while (0)
   // several right-hand sides per instance (IpmDev::rhs_mult): right-hand side bi belongs to instance bi % kmod
   const int bi = blockIdx.x / n_here, bk = bi % kmod, t = threadIdx.x, nt = blockDim.x;
   if (check_status && (inst[bk].status != 0 || (check_status == 2 && !inst[bk].soc_req))) return;
@@ -1508,7 +1511,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
   const int nbb = (G.Nb + W - 1) / W, ncb = (G.nb + W - 1) / W, nblk = nbb + ncb;
   if (RL) {
     for (int i = t; i < G.Nt; i += nt) rsh[i] = rg[i];
-    __syncthreads();
+    SOLVE_BARRIER();
   }
   struct Blk { int J0, J1, nrb, nr, w; };
   auto blk_of = [&](int blk) {
@@ -1535,7 +1538,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     const Blk B = blk_of(blk);
     if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     if (t < W) zs[t] = t < B.w ? r[B.J0 + t] : 0.0;
-    __syncthreads();
+    SOLVE_BARRIER();
     if (t < W) {                // y = L11^-1 r: 16 lanes, one row each
       double y = zs[t];
 #pragma unroll
@@ -1544,7 +1547,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       ys[t] = y;
       if (t < B.w) r[B.J0 + t] = y;
     }
-    __syncthreads();
+    SOLVE_BARRIER();
     for (int q = t; q < B.nr; q += nt) {
       const int row = panel_row(G, B.J0, B.J1, B.nrb, q);
       double acc = 0.0;
@@ -1556,7 +1559,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       r[row] -= acc;
     }
     fetch(blk + 1, dg, l);      // in flight across the barrier and the next step's diagonal solve
-    __syncthreads();
+    SOLVE_BARRIER();
   }
   if (bwd_begin > 0) fetch(bwd_begin - 1, dg, l);
   for (int blk = bwd_begin - 1; blk >= 0; --blk) {
@@ -1593,9 +1596,9 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       u += __shfl_xor(u, 1);
       if ((ln & 3) == 0) red[t >> 6][ln >> 2] = u;
     }
-    __syncthreads();
+    SOLVE_BARRIER();
     if (t < W) zs[t] = t < B.w ? r[B.J0 + t] / Dg[t * (W + 1) + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]) : 0.0;
-    __syncthreads();
+    SOLVE_BARRIER();
     if (t < B.w) {              // x = L11^-T z
       double x = zs[t];
 #pragma unroll
@@ -1603,10 +1606,11 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
         if (k > t && k < B.w) x = __builtin_fma(Dg[k * (W + 1) + t], zs[k], x);
       r[B.J0 + t] = x;
     }
-    __syncthreads();
+    SOLVE_BARRIER();
   }
   if (RL)
     for (int i = t; i < G.Nt; i += nt) rg[i] = rsh[i];
+#undef SOLVE_BARRIER
 }
 
 // ------------------------------------------------------------------------------------------------ inertia correction
