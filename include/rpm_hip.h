@@ -249,8 +249,14 @@ int rpm_hpliu_refine(rpm_hpliu* h, rpm_engine* e, const double* x, const double*
  *                       "sigma_cap" (0 = off; experimental clamp on z/s in the KKT matrix),
  *                       "init_ls_multipliers" (0; 1 = least-squares multipliers at the first iterate, Ipopt's default start),
  *                       "level1_dense" (1 where it applies: the interval blocks of the nested dissection are factored out of
- *                       registers, kkt_factor_dense_kernel, when each has at most 21 block rows of 16 (17 resident, the first 4 block columns through the storage); 0 = the left-looking
- *                       kernel for every level; 1 on a layout it does not fit: RPM_E_UNSUPPORTED),
+ *                       registers, kkt_factor_dense_kernel, when each has at most 21 block rows of 16 (17 resident, the first
+ *                       4 block columns through the storage); 0 = the left-looking kernel; 1 on a layout it does not fit:
+ *                       RPM_E_UNSUPPORTED),
+ *                       "upper_dense" (1 where it applies: the last level of the nested dissection — and the groups of
+ *                       separators of a three-level layout when their band is at least half as wide as long — on that kernel
+ *                       too, the last level with its border x border corner eliminated there as well (panels of the corner's
+ *                       block columns by substitution); 2 = the corner by the left-looking kernel's unblocked elimination
+ *                       (bit for bit what 0 gives); 0 = the left-looking kernel for them; results agree to rounding),
  *                       "fused_fill" (1 where level1_dense runs: that kernel assembles its interval block from the Jacobian,
  *                       Hessian and diagonal terms itself and carries the level-1 forward substitution of the iteration's
  *                       right-hand side along, the fill kernel leaves level-1 storage alone; 0 = separate kernels; same

@@ -117,6 +117,7 @@ struct IpmDev {
   int max_sub_nt;                        // largest sub-problem order (right-hand side kept in LDS when it fits)
   int df_tiles;                         // tiles per level-1 sub-problem in df_map (>= IPM_DENSE_TILES)
   size_t l1_dense_lds;                   // > 0: level 1 runs kkt_factor_dense_kernel (every interval block fits its register tiles) with this much LDS
+  int last_dense_corner;                 // 1: the last level's corner eliminated by kkt_factor_dense_kernel too (0, option "upper_dense" 2: by kkt_factor_kernel)
   size_t l2_dense_lds, last_dense_lds;   // the same for the groups of separators (partial, like level 1) and for the last level (that kernel then
                                          // eliminates the corner's block columns as well); option "upper_dense"
   // df_on: that kernel builds its interval block from the Jacobian / Hessian / diagonal terms itself instead of reading what

@@ -673,8 +673,9 @@ __device__ inline int panel_row(const KktGeom& G, int J0, int J1, int nrb, int q
 template <int MT, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? IPM_LB : (MT == 6 ? 2 : 1))) void kkt_factor_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0,
                                                                                int n_here, int n_sub, IpmInst* inst, int* piv, int partial) {
-  // workgroup = (instance, sub-problem sub0 + s).  partial: nested dissection level 1 — eliminate the band part only and
-  // leave the Schur complement of the border x border corner, unfactored, in the corner's storage.
+  // workgroup = (instance, sub-problem sub0 + s).  partial 1: nested dissection level 1 — eliminate the band part only and
+  // leave the Schur complement of the border x border corner, unfactored, in the corner's storage.  partial 2: the corner only
+  // (what kkt_factor_dense_kernel left of a last level whose band part it eliminated; its pivot counts are added to).
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int W = IPM_W;
   const int bi = blockIdx.x / n_here, sidx = sub0 + int(blockIdx.x) % n_here, t = threadIdx.x, nt = blockDim.x;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
       }
     }
   };
-  for (int J0 = 0; J0 < G.Nb;) {
+  for (int J0 = partial == 2 ? G.Nb : 0; J0 < G.Nb;) {
     const int J1 = min(J0 + W, G.Nb), w = J1 - J0;
     const int kbase = max(J0 - G.b, 0), nk = J0 - kbase, ngrp = (nk + 3) >> 2;
     const int nrb = max(min(J1 - 1 + G.b, G.Nb - 1) - J1 + 1, 0), rows = w + nrb + nb, ntile = (rows + 15) >> 4;
@@ -905,11 +906,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
     IPM_TICK(4);
     J0 = J1;
   }
-  if (G.Nb > 0 && nb > 0) {          // the last block column's corner update
+  if (G.Nb > 0 && nb > 0 && partial != 2) {          // the last block column's corner update
     corner_update(0, NW);
     __syncthreads();
   }
-  if (partial) {                                            // level 1 of the nested dissection: hand the corner over as it is
+  if (partial == 2) __syncthreads();   // (the corner is in LDS)
+  if (partial == 1) {                                            // level 1 of the nested dissection: hand the corner over as it is
     for (int idx = t; idx < nb * nb; idx += nt) {
       const int r = idx / nb, c = idx % nb;
       if (r >= c) K[G.at(G.Nb + r, G.Nb + c)] = C[ct(r, c)];
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
   if (nbad) atomicAdd(&cnt[2], nbad);
   __syncthreads();
   IPM_TICK(5);
-  if (t < 3) piv[(size_t(bi) * n_sub + sidx) * 3 + t] = cnt[t];
+  if (t < 3) piv[(size_t(bi) * n_sub + sidx) * 3 + t] = (partial == 2 ? piv[(size_t(bi) * n_sub + sidx) * 3 + t] : 0) + cnt[t];
 #ifdef IPM_TIMING
   if (t == 0 && (IPM_TIMING_SUB < 0 || sidx == IPM_TIMING_SUB))
     for (int i = 0; i < 6; ++i) inst[bi].dbg[i] = tc[i];
@@ -987,7 +989,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (MT == 2 ? 4 : 1) : (MT == 4 ? I
 // block ~12 times from the L2 / Infinity Cache, a 16-column step every 25 us.  Same products in the same order, so the factors
 // are the left-looking kernel's bit for bit.  Partial elimination only (the band part; the border x border corner is handed
 // on as the Schur complement).
-template <bool EARLY>   // EARLY: blocks of more than IPM_DENSE_ROWS block rows (the steps for their first block columns cost the plain kernel 15 %)
+// EARLY: blocks of more than IPM_DENSE_ROWS block rows (the steps for their first block columns cost the plain kernel 15 %).
+// CORNER: a last level — with partial = 0 the corner's block columns are eliminated too, their panels solved by SUBSTITUTION with
+// L11 (a lane's 16 steps, each a broadcast among the four lanes of a row) and a true division by d, as kkt_factor_kernel's unblocked
+// corner does, instead of the product with the explicit L11^-1: the global border holds the pivots of -delta_c and the
+// multipliers of the linkages, and with the inverse there 3 of 28 perturbed starts of the metric problem ended in a failed line search
+template <bool EARLY, bool CORNER>
 __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
                                                                   int n_sub, IpmInst* inst, int* piv, IpmDev D, int assemble, int forward,
                                                                   int partial) {
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   const int nbb = (G.Nb + W - 1) / W, nbr = (G.nb + W - 1) / W, NTB = nbb + nbr;
   // the trailing R block rows live in registers; the E block columns before them ("early") go through the storage
   const int E = EARLY ? ipm_dense_early(NTB) : 0, R = NTB - E, ntl = R * (R + 1) / 2;
-  const int nbe = partial ? nbb : NTB;    // block columns to eliminate: the band part, or (the last level) the corner's as well
+  const int nbe = (CORNER && !partial) ? NTB : nbb;    // block columns to eliminate: the band part, or (the last level) the corner's as well
   extern __shared__ double lds[];
   double* Dg = lds;                       // 2 x W x (W + 1): the diagonal tile of block column J in copy J & 1 (the next one is handed over
                                           // while the eighth wave still stores the current one)
@@ -1303,6 +1310,21 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       rsh[I * W + lr] -= a;
     }
   };
+  // a corner tile's panel solve by substitution: Y(r, c) = A(r, c) - sum_{k < c} Y(r, k) L11(c, k), L11 below the diagonal of Dg
+  auto corner_subst = [&](const d4& a, int J) {
+    const double* DgJ = Dg + (J & 1) * DGN;
+    d4 y = a;
+#pragma unroll
+    for (int c = 0; c < W - 1; ++c) {
+      const double yc = __shfl(y[c >> 2], lr + 16 * (c & 3));   // Y(r, c) is final: from the lane of this row that holds column c
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = lq + 4 * g;
+        if (j > c) y[g] = __builtin_fma(-yc, DgJ[j * (W + 1) + c], y[g]);
+      }
+    }
+    return y;
+  };
   for (int J = 0; J < nbe; ++J) {
     const int J0 = row0(J), w = min(W, rend(J) - J0);
     if (J < E) {
@@ -1382,7 +1404,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       switch (sa) {
 #define IPM_PANEL(s) case s: if (s < sb) {                                                                                   \
           d4 y = {0.0, 0.0, 0.0, 0.0};                                                                                       \
-          _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], acc[s][g], y, 0, 0, 0); \
+          if (CORNER && J >= nbb) y = corner_subst(acc[s], J);                                                               \
+          else { _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], acc[s][g], y, 0, 0, 0); } \
           int ik = sIK[s];                                                                                                   \
           asm volatile("" : "+s"(ik));                                                                                       \
           const int I = ik >> 8, r = row0(I) + lr;                                                                           \
@@ -1394,7 +1417,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
           const int lo_ = (I * W + lr) * BS + lq;                                                                            \
           _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
             const int c = lq + 4 * g;                                                                                        \
-            const double l = y[g] * invd[c];                                                                                 \
+            const double l = (CORNER && J >= nbb) ? y[g] / dv[c] : y[g] * invd[c];                                           \
             const bool ok = rv && c < w;                                                                                     \
             if (ok && (border || r - (J0 + c) <= G.b)) kp[4 * g * kstep] = l;                                                \
             BL[lo_ + 4 * g] = ok ? l : 0.0;                                                                                  \
@@ -1475,10 +1498,14 @@ int kkt_factor_dense_max_block_rows() {   // 7 waves x IPM_DENSE_SLOTS tiles hol
 }
 hipError_t kkt_factor_dense_prepare(size_t lds_bytes) {
   if (lds_bytes <= 48 * 1024) return hipSuccess;
-  const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            int(std::min(lds_bytes, kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS))));
+  const int plain = int(std::min(lds_bytes, kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS)));
+  hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, plain);
+  if (er == hipSuccess)
+    er = hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plain);
   if (er != hipSuccess || lds_bytes <= kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS)) return er;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+  er = hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+  if (er != hipSuccess) return er;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kkt_factor_dense_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
 }
 // (the LDS size says how many block rows a level's largest block has)
 static bool dense_early(size_t lds_bytes) { return lds_bytes > kkt_factor_dense_lds_bytes(IPM_DENSE_ROWS); }
@@ -2294,13 +2321,18 @@ static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partia
                                size_t dense_lds = 0) {
   const dim3 grid(unsigned(D.B) * unsigned(n_here));
   if (dense_lds) {   // every sub-problem of this level fits the register tiles
-    if (dense_early(dense_lds))
-      hipLaunchKernelGGL(kkt_factor_dense_kernel<true>, grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, D,
-                         0, 0, partial);
-    else
-      hipLaunchKernelGGL(kkt_factor_dense_kernel<false>, grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, D,
-                         0, 0, partial);
-    return;
+    // a last level: its corner there too (D.last_dense_corner; the panels of the corner's block columns by substitution, see the
+    // kernel), or by kkt_factor_kernel's unblocked elimination (partial = 2: 143 us for the metric problem's 73 x 73)
+    const bool corner = !partial && D.last_dense_corner;
+    const int dense_partial = corner ? 0 : 1;
+#define IPM_LAUNCH_DENSE(EARLY_, CORNER_)                                                                                          \
+    hipLaunchKernelGGL((kkt_factor_dense_kernel<EARLY_, CORNER_>), grid, dim3(512), dense_lds, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, \
+                       D.inst, D.piv, D, 0, 0, dense_partial)
+    if (dense_early(dense_lds)) { if (corner) IPM_LAUNCH_DENSE(true, true); else IPM_LAUNCH_DENSE(true, false); }
+    else { if (corner) IPM_LAUNCH_DENSE(false, true); else IPM_LAUNCH_DENSE(false, false); }
+#undef IPM_LAUNCH_DENSE
+    if (partial || corner) return;
+    partial = 2;       // the corner alone, below
   }
   if (tiles_per_wave == 28)
     hipLaunchKernelGGL((kkt_factor_kernel<2, 8>), grid, dim3(512), lds_bytes, st, D.K, D.kstride, D.subs, sub0, n_here, D.n_sub, D.inst, D.piv, partial);
@@ -2339,10 +2371,10 @@ void kkt_launch_factor(const IpmDev& D, int tiles_per_wave, size_t lds_bytes, hi
     hipLaunchKernelGGL(kkt_vec_kernel, dim3(blocks, unsigned(D.B)), dim3(256), 0, st, D.rhs, (long long)D.Nt, D.gap_pos, nullptr, D.n_gap, 0, D.inst, 3, D.B);
   }
   if (D.l1_dense_lds && dense_early(D.l1_dense_lds))                                   // every interval up to its corner
-    hipLaunchKernelGGL(kkt_factor_dense_kernel<true>, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
+    hipLaunchKernelGGL((kkt_factor_dense_kernel<true, false>), dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
                        D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused, 1);
   else if (D.l1_dense_lds)
-    hipLaunchKernelGGL(kkt_factor_dense_kernel<false>, dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
+    hipLaunchKernelGGL((kkt_factor_dense_kernel<false, false>), dim3(unsigned(D.B) * unsigned(D.n_l1)), dim3(512), D.l1_dense_lds, st, D.K, D.kstride, D.subs, 0,
                        D.n_l1, D.n_sub, D.inst, D.piv, D, fused, fused, 1);
   else
     launch_factor_subs(D, 0, D.n_l1, 1, tiles_per_wave, lds_bytes, st);

@@ -238,6 +238,7 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
     D.max_sub_nt = 0;
     for (const KktSub& q : subs) D.max_sub_nt = std::max(D.max_sub_nt, q.g.Nt);
     D.l1_dense_lds = D.l2_dense_lds = D.last_dense_lds = 0;
+    D.last_dense_corner = 1;
     if (D.n_l1 > 0) {
       auto dense_lds_of = [&](int first, int count) -> size_t {   // LDS of kkt_factor_dense_kernel for these sub-problems, 0: one does not fit
         int rows = 0;   // most 16-row blocks (band + border)
@@ -399,6 +400,7 @@ int rpm_ipm_set_option(rpm_ipm* h, const char* key, double value) {
   else if (k == "upper_dense") {    // the levels above the interval blocks on kkt_factor_dense_kernel too (default where their sub-problems fit it)
     h->D.l2_dense_lds = value != 0.0 ? h->l2_dense_lds : 0;
     h->D.last_dense_lds = value != 0.0 ? h->last_dense_lds : 0;
+    h->D.last_dense_corner = value == 2.0 ? 0 : 1;   // 2: the last level's corner by kkt_factor_kernel's unblocked elimination
   }
   else if (k == "fused_fill") {     // level-1 blocks assembled inside kkt_factor_dense_kernel (default where that kernel runs and the tables exist)
     if (value != 0.0 && !h->D.df_map) { h->err = "fused_fill: level 1 does not run on kkt_factor_dense_kernel"; return RPM_E_UNSUPPORTED; }

@@ -238,11 +238,10 @@ def test_register_resident_level_1_equals_the_left_looking_kernel(built, name, m
 @pytest.mark.parametrize("name,make,B", [("quadrotor_24x4", lambda: problems.quadrotor(24, 4), 2), ("launch_16x4", lambda: problems.launch(16, 4), 1),
                                          ("launch_2x16", lambda: problems.launch(2, 16), 1)], ids=["quadrotor_24x4", "launch_16x4", "launch_2x16"])
 def test_register_resident_upper_levels(built, name, make, B, group):
-    """Option upper_dense (default where the sub-problems fit): the groups of separators and the last level on
-    kkt_factor_dense_kernel as well — the last level with the corner's block columns eliminated by the same kernel (blocked, where
-    kkt_factor_kernel runs the corner unblocked: the two agree to rounding, not bit for bit).  Both solve to 1e-11 of numpy with
-    the same inertia (the groups' partial elimination is the level-1 code path, whose bit-identity
-    test_register_resident_level_1_equals_the_left_looking_kernel holds)."""
+    """Option upper_dense (1, the default where the sub-problems fit): the last level (and wide-band groups of separators) on
+    kkt_factor_dense_kernel, the corner's block columns included (their panels by substitution: agrees with kkt_factor_kernel to
+    rounding); 2: the band part there, the corner by kkt_factor_kernel's unblocked elimination (partial = 2) — bit for bit what
+    kkt_factor_kernel alone gives.  All solve to 1e-11 of numpy with the same inertia."""
     from lpopc_amd.engine import BatchedIPM, NLPEngine
     eng = NLPEngine(make(), _exact(), n_instances=B, device=0)
     eng.set_option("ipm_nested", 1)
@@ -252,7 +251,7 @@ def test_register_resident_upper_levels(built, name, make, B, group):
     dense, sign, filled = _random_kkt_dense(ipm, eng.n, B, 29)
     rhs = np.random.RandomState(13).uniform(-1, 1, size=(B, sign.size))
     sols = []
-    for on in (1, 0):
+    for on in (2, 0, 1):
         ipm.set_option("upper_dense", on)
         sol, npos, nneg = ipm.debug_solve_dense(dense, rhs)
         for bi in range(B):
@@ -260,7 +259,8 @@ def test_register_resident_upper_levels(built, name, make, B, group):
             assert np.max(np.abs(sol[bi] - ref)) <= 1e-11 * np.max(np.abs(ref))
             assert npos[bi] == (sign > 0).sum() and nneg[bi] == (sign < 0).sum()
         sols.append(sol)
-    assert np.max(np.abs(sols[0] - sols[1])) <= 1e-11 * np.max(np.abs(sols[1]))
+    assert np.array_equal(sols[0], sols[1])
+    assert np.max(np.abs(sols[2] - sols[1])) <= 1e-11 * np.max(np.abs(sols[1]))
     ipm.close()
     eng.close()
 

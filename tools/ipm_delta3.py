@@ -1,6 +1,6 @@
 """Row f-2 on the metric problem: solve Delta-III (4 phases x K intervals x Nk LGR points) on the device from lpopc's default
 guess.  Prints one JSON object (status 0 converged, 1 acceptable level; final mass in kg).
-Run on the GPU box: python tools/ipm_delta3.py [K] [Nk] [max_iter] [nested -1|0|1] [key=value solver options ...]"""
+Run on the GPU box: python tools/ipm_delta3.py [K] [Nk] [max_iter] [nested -1|0|1] [key=value solver options, eng:key=value engine options ...]"""
 import json
 import os
 import sys
@@ -15,12 +15,15 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 Nk = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 nested = int(sys.argv[4]) if len(sys.argv) > 4 else -1
-extra = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[5:])
+extra = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[5:] if not kv.startswith("eng:"))
+eng_extra = dict((kv[4:].split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[5:] if kv.startswith("eng:"))
 M_SCALE = 301454.0      # kg: total lift-off mass, the example's mass unit (example/launch/Launch.cpp)
 o = Options()
 o.SetStringValue("hessian-approximation", "exact")
 eng = NLPEngine(problems.launch(K, Nk), o, device=0)
 eng.set_option("ipm_nested", nested)
+for k, v in eng_extra.items():
+    eng.set_option(k, v)
 ipm = BatchedIPM(eng, max_iter=iters, trace=iters, **extra)
 x0 = eng.get_starting_point()[None, :]
 if os.environ.get("IPM_PERTURB_SEED"):     # the path is chaotic: a start perturbed by 1e-10 (relative) is another sample of it
