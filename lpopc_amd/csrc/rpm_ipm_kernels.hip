@@ -1401,11 +1401,37 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     {
       const int sa = first_slot_at(cs + 1), sb = min(MAXS, first_slot_at(cs1));   // slots [sa, sb)
       const bool first_owner = (cs + 1) % NWV == wv;   // this wave's first tile of the column is (J + 1, J): the rows the next diagonal tile needs
+      if (CORNER && J >= nbb) {
+        // a corner block column: one copy of the substitution code for all slots (inside the switch it would be there 22 times)
+        for (int sl = sa; sl < sb; ++sl) {
+          d4 a = {0.0, 0.0, 0.0, 0.0};
+          switch (sl) {
+#define IPM_PICK(s) case s: a = acc[s]; break;
+            IPM_REP22(IPM_PICK)
+#undef IPM_PICK
+            default: break;
+          }
+          const d4 y = corner_subst(a, J);
+          const int I = J + (wv + NWV * sl - cs), r = row0(I) + lr;
+          const bool rv = r < rend(I);
+          double* kp = K + (size_t(J0) * G.CS + (G.b + 1 + r - G.Nb)) + lq * G.CS;      // (every row below a corner column is a border row)
+          const int lo_ = (I * W + lr) * BS + lq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = lq + 4 * g;
+            const bool ok = rv && c < w;
+            const double l = ok ? y[g] / dv[c] : 0.0;
+            if (ok) kp[4 * g * G.CS] = l;
+            BL[lo_ + 4 * g] = l;
+            BY[lo_ + 4 * g] = ok ? y[g] : 0.0;
+          }
+          if (sl == sa && first_owner) __hip_atomic_store(&hand_over, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else
       switch (sa) {
 #define IPM_PANEL(s) case s: if (s < sb) {                                                                                   \
           d4 y = {0.0, 0.0, 0.0, 0.0};                                                                                       \
-          if (CORNER && J >= nbb) y = corner_subst(acc[s], J);                                                               \
-          else { _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], acc[s][g], y, 0, 0, 0); } \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[lr * IPM_DENSE_LDS_ROW + 4 * g + lq], acc[s][g], y, 0, 0, 0); \
           int ik = sIK[s];                                                                                                   \
           asm volatile("" : "+s"(ik));                                                                                       \
           const int I = ik >> 8, r = row0(I) + lr;                                                                           \
@@ -1417,7 +1443,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
           const int lo_ = (I * W + lr) * BS + lq;                                                                            \
           _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
             const int c = lq + 4 * g;                                                                                        \
-            const double l = (CORNER && J >= nbb) ? y[g] / dv[c] : y[g] * invd[c];                                           \
+            const double l = y[g] * invd[c];                                                                                 \
             const bool ok = rv && c < w;                                                                                     \
             if (ok && (border || r - (J0 + c) <= G.b)) kp[4 * g * kstep] = l;                                                \
             BL[lo_ + 4 * g] = ok ? l : 0.0;                                                                                  \

@@ -251,6 +251,9 @@ int rpm_ipm_create(rpm_engine* eng, rpm_ipm** out) {
       for (int i = D.n_l1; i < D.n_l1 + D.n_l2; ++i)     // groups of a narrow band stay on kkt_factor_kernel, which skips what lies outside the band
         if (2 * subs[size_t(i)].g.b < subs[size_t(i)].g.Nb) h->l2_dense_lds = 0;
       h->last_dense_lds = dense_lds_of(D.n_l1 + D.n_l2, 1);
+      // (one workgroup per CU: a sweep of many small last levels is better off on kkt_factor_kernel, several workgroups per CU —
+      // 1024 quadrotor instances 0.12 against 0.30 ms)
+      if (B > 256) h->last_dense_lds = 0;
       const size_t most = std::max(h->l1_dense_lds, std::max(h->l2_dense_lds, h->last_dense_lds));
       if (most && kkt_factor_dense_prepare(most) != hipSuccess) { h->err = "hipFuncSetAttribute"; return fail(RPM_E_DEVICE); }
       if (!(std::getenv("RPM_IPM_DENSE") && std::atoi(std::getenv("RPM_IPM_DENSE")) == 0)) D.l1_dense_lds = h->l1_dense_lds;   // option "level1_dense"
