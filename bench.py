@@ -359,6 +359,21 @@ def sequential_section(ctx, args, prob, xs):
     return seq, s2["ms_per_step"]
 
 
+
+def _perturbed_starts(ipm, x0, seeds=(1, 2, 3, 4, 5)):
+    """The metric problem from starts perturbed by 1e-10 (relative; tools/ipm_delta3.py's IPM_PERTURB_SEED): how many end at the
+    optimum (status 0 or the acceptable level, within 0.05 kg of the published 7529.71), median time and iteration count."""
+    import numpy as np
+    runs = []
+    for seed in seeds:
+        xs = x0 * (1 + 1e-10 * np.random.RandomState(seed).uniform(-1, 1, x0.shape))
+        t0 = time.perf_counter()
+        r = ipm.solve(xs)
+        runs.append((int(r["status"][0]), time.perf_counter() - t0, -float(r["obj"][0]) * 301454.0, int(r["iterations"][0])))
+    good = [q for q in runs if q[0] in (0, 1) and abs(q[2] - 7529.71) < 0.05]
+    return {"starts": len(runs), "at_the_optimum": len(good), "median_solve_s": float(np.median([q[1] for q in runs])),
+            "median_iterations": int(np.median([q[3] for q in runs])), "statuses": [q[0] for q in runs]}
+
 def device_ipm_section(ctx, args):
     """Row f-2 beside the callbacks: the METRIC problem solved on the device from lpopc's default guess (callbacks, exact
     Hessian, KKT assembly, nested-dissection LDL^T, substitution, filter line search with second-order corrections,
@@ -394,6 +409,8 @@ def device_ipm_section(ctx, args):
                              "with_mu_strategy_monotone": monotone,
                              "note": "Delta-III %dx%dx%d from lpopc's default guess; status 0 converged (1e-8), 1 acceptable level; published optimum 7529.71 kg" % (
                                  4, args.intervals, args.nodes)}
+    # the path is chaotic (a start perturbed by 1e-10 takes another one, 300 ... 900 iterations): the same solve from five such starts
+    out["metric_problem"]["perturbed_starts"] = _perturbed_starts(ipm, x0)
     try:   # Ipopt's own default NLP scaling (gradient-based; an option here): 28 672 of the 32 801 rows are scaled down
         ipm.set_option("nlp_scaling", 1)
         t0 = time.perf_counter()
@@ -403,8 +420,7 @@ def device_ipm_section(ctx, args):
         out["metric_problem"]["with_nlp_scaling_gradient_based"] = {
             "solve_s": dts, "status": int(rs["status"][0]), "iterations": int(rs["iterations"][0]), "factorizations": sts["factorizations"],
             "final_mass_kg": -float(rs["obj"][0]) * 301454.0, "kkt_error": float(rs["kkt_error"][0]),
-            "note": "option nlp_scaling = 1 (Ipopt's nlp_scaling_method default); 8 starts perturbed by 1e-10: median 342 iterations / 0.82 s, "
-                    "6 of 8 to 1e-8 and 2 to the acceptable level, against 687 / 1.96 s and 8 of 8 without (tools/ipm_delta3_ensemble.py)"}
+            "note": "option nlp_scaling = 1 (Ipopt's nlp_scaling_method default; off by default here: ensembles over meshes in DESIGN.md f-2)"}
         ipm.set_option("nlp_scaling", 0)
     except Exception as ex:
         out["metric_problem"]["with_nlp_scaling_gradient_based"] = {"error": repr(ex)}
@@ -422,7 +438,8 @@ def device_ipm_section(ctx, args):
         out["metric_problem_limited_memory"] = {
             "solve_s": dt, "status": int(r["status"][0]), "iterations": int(r["iterations"][0]), "ms_per_ipm_iteration": 1e3 * dt / max(1, st["iterations"]),
             "final_mass_kg": -float(r["obj"][0]) * 301454.0, "kkt_error": float(r["kkt_error"][0]), "factorizations": st["factorizations"],
-            "half_bandwidth": info["half_bandwidth"], "hessian": "limited-memory BFGS, history 6 (lpopc's default option)"}
+            "half_bandwidth": info["half_bandwidth"], "hessian": "limited-memory BFGS, history 6 (lpopc's default option)",
+            "perturbed_starts": _perturbed_starts(ipm, eng.get_starting_point()[None, :])}
         ipm.close()
         eng.close()
     except Exception as ex:
