@@ -1278,8 +1278,8 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     if (E == 0) IPM_PUT_BODY(0, min(W, rend(0)), Dg)    // tile (0, 0) is tile number 0: slot 0 of wave 0
     else t_put(t_load(0, 0), min(W, rend(0)), Dg);
   }
-  // early block column J: this wave's tiles (I, J), I > J, wait in ebuf (I = first such I + 7 q), tile (J + 1, J + 1) in edg with
-  // the wave that owns it — fetched a step ahead, so that no trip to the storage lies on the chain of diagonal blocks
+  // early block column J: this wave's tiles (I, J), I > J, in ebuf (I = first such I + 7 q) for its panel only — kept across the
+  // resident tiles' update they pushed those out of the registers —, tile (J + 1, J + 1) in edg with the wave that owns it, fetched a step ahead
   constexpr int EQ = (IPM_DENSE_ROWS + IPM_DENSE_EARLY - 1 + NWV - 1) / NWV;
   d4 ebuf[EQ], edg;
   auto first_own = [&](int from) { return from + (wv - from % NWV + NWV) % NWV; };   // first I >= from with I % 7 == wv
@@ -1294,9 +1294,16 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   IPM_LDS_BARRIER();              // B2: its diagonal block is factored
 #ifdef IPM_TIMING
   long long tw[6] = {0, 0, 0, 0, 0, 0}, twp = wall_clock64();
+#ifdef IPM_TIMING_EARLY   // the phases of the EARLY block columns in the record's places, everything else in "early"
+#define IPM_ETICK(i) do { const long long n_ = wall_clock64(); tw[i] += n_ - twp; twp = n_; } while (0)
+#define IPM_TTICK(i) do { const long long n_ = wall_clock64(); tw[5] += n_ - twp; twp = n_; } while (0)
+#else
 #define IPM_TTICK(i) do { const long long n_ = wall_clock64(); tw[i] += n_ - twp; twp = n_; } while (0)
+#define IPM_ETICK(i) IPM_TTICK(5)
+#endif
 #else
 #define IPM_TTICK(i)
+#define IPM_ETICK(i)
 #endif
   // forward: r(row) -= L(row, J) y for every row below block column J, thread p owns row p of the tile rows.  Off the chain of
   // diagonal blocks: after the next diagonal tile has been handed over (the panel and y stay in LDS until the next B2)
@@ -1327,11 +1334,20 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   };
   for (int J = 0; J < nbe; ++J) {
     const int J0 = row0(J), w = min(W, rend(J) - J0);
-    if (J < E) {
+    int s0_early = 0;
+    if (EARLY && J < E) {
       // ---- an early block column: the same steps with its tiles (and those of the early columns to its right) taken from the
       // storage, each by the wave that owns it; the resident tiles take their update as always
-      IPM_TTICK(5);
+      IPM_ETICK(4);
       const int f0 = first_own(J + 1);
+      if (J > 0) {              // this column's tiles: fetched now (they have the updates of the columns before J - 1), updated with
+#pragma unroll                  // column J - 1's panel, which is still in LDS
+        for (int q = 0; q < EQ; ++q)
+          if (f0 + NWV * q < NTB) ebuf[q] = t_load(f0 + NWV * q, J);
+#pragma unroll
+        for (int q = 0; q < EQ; ++q)
+          if (f0 + NWV * q < NTB) ebuf[q] = t_update(ebuf[q], f0 + NWV * q, J);
+      }
 #pragma unroll
       for (int q = 0; q < EQ; ++q) {
         const int I = f0 + NWV * q;
@@ -1355,7 +1371,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         }
         if (I == J + 1) __hip_atomic_store(&hand_over, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      IPM_TTICK(5);
+      IPM_ETICK(0);
       int s0 = 0;
       if (J + 1 < nbe) {        // the next diagonal tile, before the workgroup meets
         const int w1 = min(W, rend(J + 1) - row0(J + 1));
@@ -1369,33 +1385,10 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
           s0 = 1;
         }
       }
-      IPM_TTICK(5);
-      IPM_LDS_BARRIER();          // the panel is in LDS; B1 of block column J + 1
-      IPM_TTICK(5);
-      if (forward) forward_share(J);
-      switch (s0) {
-#define IPM_UPD(s) case s: IPM_UPD_BODY(s) if (s & 1) __builtin_amdgcn_sched_barrier(0);
-        IPM_REP22(IPM_UPD)
-#undef IPM_UPD
-        default: break;
-      }
-      if (J + 1 < E) {          // the next early column's tiles take their update and stay in registers for its panel (fetched only now:
-        const int f1 = first_own(J + 2);   // in flight during the update above they would push the resident tiles out of the registers)
-#pragma unroll
-        for (int q = 0; q < EQ; ++q)
-          if (f1 + NWV * q < NTB) ebuf[q] = t_load(f1 + NWV * q, J + 1);
-#pragma unroll
-        for (int q = 0; q < EQ; ++q)
-          if (f1 + NWV * q < NTB) ebuf[q] = t_update(ebuf[q], f1 + NWV * q, J + 1);
-      }
-      for (int Kb = J + 2; Kb < E; ++Kb)      // early columns further right: through the storage
-        for (int I = first_own(Kb); I < NTB; I += NWV) t_store(t_update(t_load(I, Kb), I, Kb), I, Kb);
-      if (J + 2 < E && (J + 2) % NWV == wv) edg = t_load(J + 2, J + 2);
-      IPM_TTICK(5);
-      if (J + 1 < nbe) IPM_LDS_BARRIER();   // B2 of block column J + 1
-      continue;
+      s0_early = s0;
     }
-    const int cs = colstart(J - E), cs1 = colstart(J - E + 1);
+    const int cs = colstart(max(J - E, 0)), cs1 = colstart(max(J - E, 0) + 1);
+    if (!(EARLY && J < E)) {
     IPM_TTICK(4);               // waiting at B2
     // the tiles below the diagonal one: Y^T = L11^-1 A^T, L^T = D^-1 Y^T; both go to LDS for the updates, L to the storage
     {
@@ -1459,11 +1452,12 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       }
     }
     IPM_TTICK(0);               // panel
+    }
     // every tile to the right takes its update; the next diagonal tile first and BEFORE the workgroup meets: its owner needs the
     // panel's rows of block row J + 1 only, which their owner announces (hand_over) after its first tile.  One barrier then says
     // both "the panel is in LDS" and "the next diagonal tile is in its copy of Dg" (they were two, with this update between them)
-    int s0 = first_slot_at(cs1);
-    if (J + 1 < nbe && cs1 % NWV == wv) {
+    int s0 = (EARLY && J < E) ? s0_early : first_slot_at(cs1);
+    if (!(EARLY && J < E) && J + 1 < nbe && cs1 % NWV == wv) {
       const int w1 = min(W, rend(J + 1) - row0(J + 1));
       double* DgN = Dg + ((J + 1) & 1) * DGN;
       for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
@@ -1485,6 +1479,11 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
       IPM_REP22(IPM_UPD)
 #undef IPM_UPD
       default: break;
+    }
+    if (EARLY && J < E) {
+      for (int Kb = J + 2; Kb < E; ++Kb)      // early columns further right: through the storage
+        for (int I = first_own(Kb); I < NTB; I += NWV) t_store(t_update(t_load(I, Kb), I, Kb), I, Kb);
+      if (J + 2 < E && (J + 2) % NWV == wv) edg = t_load(J + 2, J + 2);
     }
     IPM_TTICK(3);               // update
     if (J + 1 < nbe) IPM_LDS_BARRIER();   // B2 of block column J + 1
