@@ -60,6 +60,17 @@ def test_ragged_mesh_tiles_cover_every_node(built):
         assert np.array_equal(e.eval_jac_g_structure()[0], o.jac_structure()[0])
 
 
+def test_solver_layout_options_round_trip(built):
+    """The engine options the device solver's layout reads at rpm_ipm_create (host side only): defaults, set / get, bad values."""
+    e = NLPEngine(problems.brachistochrone())
+    assert e.get_option("ipm_local_border") == 1 and e.get_option("ipm_nested_group") == 0
+    e.set_option("ipm_local_border", 0)
+    e.set_option("ipm_nested_group", 48)
+    assert e.get_option("ipm_local_border") == 0 and e.get_option("ipm_nested_group") == 48
+    with pytest.raises(RpmError):
+        e.set_option("ipm_nested_group", -1)
+
+
 def test_no_gpu_means_loud_failure_not_fallback(built):
     import torch
     if torch.cuda.is_available():
