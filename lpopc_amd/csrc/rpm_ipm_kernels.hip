@@ -1538,7 +1538,7 @@ static bool dense_early(size_t lds_bytes) { return lds_bytes > kkt_factor_dense_
 // L y = r, then x = L^-T D^-1 y, in place in rhs: one workgroup per instance, IPM_W columns per step.  The diagonal
 // blocks hold L11^-1, so a step's own 16 unknowns are 16 parallel dot products.  The right-hand side lives in LDS when it
 // fits (RL); the diagonal block and each thread's panel row of the NEXT step are fetched while the current one is worked.
-template <bool RL>
+template <bool RL, int PF = 1>
 __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long long kstride, const KktSub* subs, int sub0, int n_here,
                                                         const IpmInst* inst, double* rhs_all, long long rhs_stride, int check_status,
                                                         int phase, int kmod) {
@@ -1583,10 +1583,11 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     for (int c = 0; c < W; ++c)
       l[c] = (row >= 0 && c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0;
   };
-  double dg, l[W];
+  // PF = 2 (launches of few workgroups, where occupancy is no concern): two steps' shares on their way — a step is a few hundred cycles of
+  // LDS work between barriers, a trip to the L2 / HBM takes longer
+  double dg0, l0[W], dg1, l1[W];
   const int fwd_end = phase == 1 ? nbb : (phase == 2 ? 0 : nblk), bwd_begin = phase == 2 ? nbb : (phase == 1 ? 0 : nblk);
-  if (fwd_end > 0) fetch(0, dg, l);
-  for (int blk = 0; blk < fwd_end; ++blk) {
+  auto forward_step = [&](int blk, double& dg, double (&l)[W]) {
     const Blk B = blk_of(blk);
     if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     if (t < W) zs[t] = t < B.w ? r[B.J0 + t] : 0.0;
@@ -1610,11 +1611,15 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       }
       r[row] -= acc;
     }
-    fetch(blk + 1, dg, l);      // in flight across the barrier and the next step's diagonal solve
+    fetch(blk + PF, dg, l);     // in flight across the barrier and the next PF - 1 steps
     SOLVE_BARRIER();
+  };
+  if (fwd_end > 0) { fetch(0, dg0, l0); if (PF == 2) fetch(1 < fwd_end ? 1 : -1, dg1, l1); }
+  for (int blk = 0; blk < fwd_end; blk += PF) {
+    forward_step(blk, dg0, l0);
+    if (PF == 2 && blk + 1 < fwd_end) forward_step(blk + 1, dg1, l1);
   }
-  if (bwd_begin > 0) fetch(bwd_begin - 1, dg, l);
-  for (int blk = bwd_begin - 1; blk >= 0; --blk) {
+  auto backward_step = [&](int blk, double& dg, double (&l)[W]) {
     const Blk B = blk_of(blk);
     if (di < W && dj <= di) Dg[di * (W + 1) + dj] = dg;
     double p[W];
@@ -1629,7 +1634,7 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
         p[c] = __builtin_fma(lv, xr, p[c]);
       }
     }
-    fetch(blk - 1, dg, l);      // in flight across the reduction and the diagonal solve
+    fetch(blk - PF, dg, l);     // in flight across the reduction, the diagonal solve and the next PF - 1 steps
     {   // the 16 sums over the wave, each by the same tree as `for (o = 32; o; o >>= 1) v += shfl_down(v, o)` (lane l + lane l + o:
         // the same pairs, a + b for b + a at most), but the columns are dealt out while the lanes fold: 8 + 4 + 2 + 1 + 1 + 1
         // exchanges instead of 16 x 6 — column c's sum ends in lane 4 c.  (The LDS pipe, which carries the exchanges, bounded the
@@ -1659,6 +1664,11 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
       r[B.J0 + t] = x;
     }
     SOLVE_BARRIER();
+  };
+  if (bwd_begin > 0) { fetch(bwd_begin - 1, dg0, l0); if (PF == 2) fetch(bwd_begin - 2, dg1, l1); }
+  for (int blk = bwd_begin - 1; blk >= 0; blk -= PF) {
+    backward_step(blk, dg0, l0);
+    if (PF == 2 && blk - 1 >= 0) backward_step(blk - 1, dg1, l1);
   }
   if (RL)
     for (int i = t; i < G.Nt; i += nt) rg[i] = rsh[i];
@@ -2373,7 +2383,10 @@ static void launch_factor_subs(const IpmDev& D, int sub0, int n_here, int partia
 }
 static void launch_solve_subs(const IpmDev& D, int sub0, int n_here, int phase, int check_status, hipStream_t st) {
   const dim3 grid(unsigned(D.B) * unsigned(D.rhs_mult > 1 ? D.rhs_mult : 1) * unsigned(n_here));
-  if (size_t(D.max_sub_nt) * sizeof(double) <= 48 * 1024)
+  if (size_t(D.max_sub_nt) * sizeof(double) <= 48 * 1024 && grid.x <= 512)        // few workgroups: two steps' factor entries in flight
+    hipLaunchKernelGGL((kkt_solve_kernel<true, 2>), grid, dim3(256), size_t(D.max_sub_nt) * sizeof(double), st, D.K, D.kstride, D.subs, sub0, n_here,
+                       D.inst, D.rhs, (long long)D.Nt, check_status, phase, D.B);
+  else if (size_t(D.max_sub_nt) * sizeof(double) <= 48 * 1024)
     hipLaunchKernelGGL(kkt_solve_kernel<true>, grid, dim3(256), size_t(D.max_sub_nt) * sizeof(double), st, D.K, D.kstride, D.subs, sub0, n_here,
                        D.inst, D.rhs, (long long)D.Nt, check_status, phase, D.B);
   else
