@@ -1579,9 +1579,13 @@ __global__ __launch_bounds__(256) void kkt_solve_kernel(const double* Kall, long
     const Blk B = blk_of(blk);
     dg = (di < B.w && dj <= di) ? K[G.at(B.J0 + di, B.J0 + dj)] : 0.0;
     const int row = t < B.nr ? panel_row(G, B.J0, B.J1, B.nrb, t) : -1;
+    // one 64-bit address (row, column J0) and a 32-bit step per column (a G.at() per entry is a 64-bit multiply each: most of a step's instructions)
+    const bool brd = row >= G.Nb;
+    const int kstep = brd ? G.CS : G.CS - 1;
+    const double* kp = K + (size_t(B.J0) * G.CS + (brd ? G.b + 1 + row - G.Nb : max(row - B.J0, 0)));
 #pragma unroll
     for (int c = 0; c < W; ++c)
-      l[c] = (row >= 0 && c < B.w && (row >= G.Nb || row - (B.J0 + c) <= G.b)) ? K[G.at(row, B.J0 + c)] : 0.0;
+      l[c] = (row >= 0 && c < B.w && (brd || row - (B.J0 + c) <= G.b)) ? kp[c * kstep] : 0.0;
   };
   // PF = 2 (launches of few workgroups, where occupancy is no concern): two steps' shares on their way — a step is a few hundred cycles of
   // LDS work between barriers, a trip to the L2 / HBM takes longer
