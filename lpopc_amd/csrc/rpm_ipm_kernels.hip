@@ -1031,6 +1031,13 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
   // hand_over: block column J's panel rows of block row J + 1 are in LDS (value J + 1) — all the owner of the next diagonal tile waits for
   __shared__ int hand_over;
   if (t == 0) hand_over = 0;
+  // The owner of those rows always reaches its store (no early exit lies before it), so the wait ends; the bound is there so that the
+  // grid drains whatever happens — and if it were ever hit the factorisation is NOT delivered: the instance ends with status 5.
+  auto wait_hand_over = [&](int value) {
+    int spin = 0;
+    while (__hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < value && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    if (spin >= (1 << 22)) inst[bi].status = 5;
+  };
   auto row0 = [&](int I) { return I < nbb ? W * I : G.Nb + W * (I - nbb); };
   auto rend = [&](int I) { return I < nbb ? G.Nb : G.Nt; };
   // assemble: the block is built here, not read — the values of its structural slots (a few per cent of the storage) go to LDS
@@ -1379,8 +1386,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
         if (J + 1 < E) {
           if ((J + 1) % NWV == wv) t_put(t_update(edg, J + 1, J + 1), w1, DgN);   // (this wave wrote the panel's rows it needs)
         } else if (wv == 0) {   // the first resident tile: slot 0 of wave 0
-          for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
-            __builtin_amdgcn_s_sleep(1);
+          wait_hand_over(J + 1);
           IPM_UPD_BODY(0) IPM_PUT_BODY(0, w1, DgN)
           s0 = 1;
         }
@@ -1460,8 +1466,7 @@ __global__ __launch_bounds__(512, 1) void kkt_factor_dense_kernel(double* Kall, 
     if (!(EARLY && J < E) && J + 1 < nbe && cs1 % NWV == wv) {
       const int w1 = min(W, rend(J + 1) - row0(J + 1));
       double* DgN = Dg + ((J + 1) & 1) * DGN;
-      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&hand_over, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 1; ++spin)
-        __builtin_amdgcn_s_sleep(1);
+      wait_hand_over(J + 1);
       switch (s0) {
 #define IPM_NEXT(s) case s: IPM_UPD_BODY(s) IPM_PUT_BODY(s, w1, DgN) break;
         IPM_REP22(IPM_NEXT)
